@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of libfri's encode hot path (transform + quantisation) at 4096x4096 on MI355X.
+
+A "step" is one pass of K1 (address map + residue transform + quantiser) over one synthetic 8-bit
+4096x4096 plane per GPU, input already resident in HBM. Steps rotate over enough distinct image/coefficient
+slots to exceed the 256 MiB Infinity Cache, so the timed traffic really goes to HBM. Ranks hold independent
+images (one process per GPU, no data-path collective): weak scaling.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W = H = 4096
+CHANNELS = 1
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (a port, not libfri itself: no Rust toolchain here) on a bounded sample of the same workload."""
+    import numpy as np
+
+    from oracle import fri_oracle
+    from tests.common import gen_image
+
+    ones = np.ones(32, np.int32)
+    n_pix, t_used, n_img = 0, 0.0, 0
+    while n_img < 2 and t_used < seconds_budget:
+        img = gen_image("noise", W, H, CHANNELS, 1000 + n_img)
+        t0 = time.perf_counter()
+        wl = fri_oracle.Wavelet(img, H, W, CHANNELS)  # from_raster: lattice + address map + residue transform
+        wl.quantize(ones)
+        t_used += time.perf_counter() - t0
+        wl.close()
+        n_pix += W * H
+        n_img += 1
+    return {
+        "value": round(n_pix / t_used / 1e6, 3),
+        "unit": "Mpixels/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n_img} x {W}x{H}x{CHANNELS} noise image(s), transform+quant via oracle/fri_oracle.c (C restatement of libfri; single thread like the reference), {t_used:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--slots", type=int, default=8, help="distinct image/coefficient buffer pairs the steps rotate over")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also time K2 (predict+histogram), K3 (inverse) and RGB")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import frave_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1", file=sys.stderr)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = frave_amd.Context(local_rank)  # raises if the HIP library or a gfx950 GPU is missing: no fallback
+    plan = frave_amd.Plan(ctx, W, H, CHANNELS)
+    F = plan.num_cells
+    alg_bytes = plan.pixel_bytes + plan.coef_count * 4  # u8 read once + int32 coefficient write
+
+    gen = torch.Generator(device="cuda").manual_seed(0xF7A5E000 + rank)
+    d_px = torch.randint(0, 256, (args.slots, plan.pixel_bytes), dtype=torch.uint8, device="cuda", generator=gen)
+    d_co = torch.empty((args.slots, plan.coef_count), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    px0, co0 = d_px.data_ptr(), d_co.data_ptr()
+    pstride, cstride = plan.pixel_bytes, plan.coef_count
+
+    def step(i):
+        k = i % args.slots
+        plan.transform_quant_dev(px0 + k * pstride, co0 + k * cstride * 4, stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel, timed with HIP events on the launch stream (same stream as above)
+    kernel_us = plan.time_transform_quant_dev(args.slots, px0, pstride, co0, cstride, max(args.steps, 50), stream=stream)
+    achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
+
+    out = {
+        "metric": "Mpixels/s encode (transform+quant) at 4096x4096",
+        "value": round(world * args.steps * W * H / elapsed / 1e6, 1),
+        "unit": "Mpixels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8->i32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"1 x {W}x{H} 8-bit plane per GPU per step (BASELINE config 2), K1 = address map + residue transform + quant, "
+                        f"F={F} cells, {args.slots} rotating HBM-resident slots",
+            "channels": CHANNELS,
+            "parallelism": f"independent images, 1 per GPU x {world}",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "kernel": "fwd_transform_quant_kernel<1>",
+            "kernel_us": round(kernel_us, 3),
+            "algorithmic_bytes_per_launch": alg_bytes,
+        },
+    }
+
+    if args.extras and rank == 0:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        vp = np.tile(np.array([0.25, 0.25, 0.25, 0.125, 0.0625, 0.0625], np.float32), (3, 1))
+        wp = np.tile(np.array([1.0, 0.5, 0.25, 0.25, 0.125, 0.125], np.float32), (3, 1))
+        d_b = torch.empty(F * 512, dtype=torch.uint8, device="cuda")
+        d_p = torch.empty(F * 512, dtype=torch.int32, device="cuda")
+        d_h = torch.empty(10 * 1024, dtype=torch.int32, device="cuda")
+        d_o = torch.empty(1, dtype=torch.int64, device="cuda")
+        d_back = torch.empty(plan.pixel_bytes, dtype=torch.uint8, device="cuda")
+        reps = 20
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(reps):
+                fn()
+            ev1.record()
+            torch.cuda.synchronize()
+            return ev0.elapsed_time(ev1) / reps * 1e3
+
+        k2_us = timed(lambda: plan.predict_histogram_dev(co0, 0, vp, wp, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=stream))
+        k3_us = timed(lambda: plan.inverse_transform_dev(co0, d_back.data_ptr(), stream=stream))
+        assert torch.equal(d_back, d_px[0]), "K3(K1(x)) != x"
+        out["extras"] = {
+            "k2_predict_histogram_us": round(k2_us, 2),
+            "k2_Mpixels_per_s": round(W * H / k2_us, 1),
+            "k3_inverse_us": round(k3_us, 2),
+            "k3_Mpixels_per_s": round(W * H / k3_us, 1),
+        }
+
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,252 @@
+"""ctypes binding of include/fri_hip.h. Plumbing only -- every compute call goes to libfri_hip.so."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfri_hip.so")
+NONE = -(2 ** 31)
+
+# every symbol include/fri_hip.h declares (tests/test_abi_symbols.py checks the header against this list)
+SYMBOLS = [
+    "fri_hip_strerror", "fri_hip_version", "fri_hip_ctx_create", "fri_hip_ctx_destroy", "fri_hip_backend",
+    "fri_hip_last_hip_error", "fri_hip_plan_create", "fri_hip_plan_destroy", "fri_hip_plan_num_cells",
+    "fri_hip_plan_num_bfs_cells", "fri_hip_plan_num_interior_cells", "fri_hip_plan_coef_count", "fri_hip_plan_pixel_bytes",
+    "fri_hip_plan_centers", "fri_hip_plan_valid_mask", "fri_hip_plan_num_some", "fri_hip_plan_neighbour_cells",
+    "fri_hip_plan_neighbour_table", "fri_hip_transform_quant", "fri_hip_transform_quant_dev",
+    "fri_hip_transform_quant_batch_dev", "fri_hip_transform_quant_batch", "fri_hip_predict_histogram",
+    "fri_hip_predict_histogram_dev", "fri_hip_inverse_transform", "fri_hip_inverse_transform_dev",
+    "fri_hip_time_transform_quant_dev",
+]
+
+
+class FriHipError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        msg = load_library().fri_hip_strerror(code).decode()
+        super().__init__(f"{where}: {msg} ({code}){': ' + detail if detail else ''}")
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False):
+    """Compile frave_amd/libfri_hip.so for gfx950 with hipcc (works without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    if force and os.path.exists(_SO):
+        os.remove(_SO)
+    subprocess.check_call(["make", "-s", "-C", src_dir])
+    return _SO
+
+
+_lib = None
+
+
+def load_library():
+    """Load libfri_hip.so. Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise FileNotFoundError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                                "frave_amd has no CPU fallback.")
+    L = C.CDLL(_SO)
+    vp, u32, i32, sz = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t
+    L.fri_hip_strerror.restype = C.c_char_p
+    L.fri_hip_strerror.argtypes = [i32]
+    L.fri_hip_version.restype = C.c_char_p
+    L.fri_hip_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.fri_hip_ctx_destroy.argtypes = [vp]
+    L.fri_hip_backend.restype = C.c_char_p
+    L.fri_hip_backend.argtypes = [vp]
+    L.fri_hip_last_hip_error.restype = C.c_char_p
+    L.fri_hip_last_hip_error.argtypes = [vp]
+    L.fri_hip_plan_create.argtypes = [vp, u32, u32, u32, C.POINTER(vp)]
+    L.fri_hip_plan_destroy.argtypes = [vp]
+    for n in ("num_cells", "num_bfs_cells", "num_interior_cells"):
+        f = getattr(L, "fri_hip_plan_" + n)
+        f.restype, f.argtypes = u32, [vp]
+    for n in ("coef_count", "pixel_bytes"):
+        f = getattr(L, "fri_hip_plan_" + n)
+        f.restype, f.argtypes = sz, [vp]
+    L.fri_hip_plan_num_some.restype = C.c_uint64
+    L.fri_hip_plan_num_some.argtypes = [vp]
+    for n in ("centers", "valid_mask", "neighbour_cells", "neighbour_table"):
+        getattr(L, "fri_hip_plan_" + n).argtypes = [vp, vp]
+    L.fri_hip_transform_quant.argtypes = [vp, vp, vp, vp]
+    L.fri_hip_transform_quant_dev.argtypes = [vp, vp, vp, vp, vp]
+    L.fri_hip_transform_quant_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, vp]
+    L.fri_hip_transform_quant_batch.argtypes = [vp, u32, vp, vp, vp]
+    L.fri_hip_predict_histogram.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp]
+    L.fri_hip_predict_histogram_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
+    L.fri_hip_inverse_transform.argtypes = [vp, vp, vp, vp]
+    L.fri_hip_inverse_transform_dev.argtypes = [vp, vp, vp, vp, vp]
+    L.fri_hip_time_transform_quant_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, u32, vp, C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _q(q):
+    q = np.ones(32, np.int32) if q is None else np.ascontiguousarray(q, np.int32)
+    assert q.size == 32
+    return q
+
+
+def _check(rc, where, ctx=None):
+    if rc != 0:
+        detail = ""
+        if ctx is not None and ctx._h:
+            detail = load_library().fri_hip_last_hip_error(ctx._h).decode()
+        raise FriHipError(rc, where, detail)
+
+
+class Context:
+    """fri_hip_ctx: one per (host thread, GPU). Raises FriHipError(NO_DEVICE) without a gfx950 GPU."""
+
+    def __init__(self, device=0):
+        self._h = None
+        h = C.c_void_p()
+        _check(load_library().fri_hip_ctx_create(device, C.byref(h)), "fri_hip_ctx_create")
+        self._h = h
+        self.device = device
+
+    @property
+    def backend(self):
+        return load_library().fri_hip_backend(self._h).decode()
+
+    def close(self):
+        if self._h:
+            load_library().fri_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    """fri_hip_plan: geometry of one (width, height, channels). ctx=None gives a host-only plan (getters only)."""
+
+    def __init__(self, ctx, width, height, channels):
+        self._h = None
+        self.ctx = ctx
+        self.width, self.height, self.channels = width, height, channels
+        h = C.c_void_p()
+        _check(load_library().fri_hip_plan_create(ctx._h if ctx else None, width, height, channels, C.byref(h)), "fri_hip_plan_create", ctx)
+        self._h = h
+        L = load_library()
+        self.num_cells = L.fri_hip_plan_num_cells(h)
+        self.num_bfs_cells = L.fri_hip_plan_num_bfs_cells(h)
+        self.num_interior_cells = L.fri_hip_plan_num_interior_cells(h)
+        self.coef_count = L.fri_hip_plan_coef_count(h)
+        self.pixel_bytes = L.fri_hip_plan_pixel_bytes(h)
+        self.num_some = L.fri_hip_plan_num_some(h)
+
+    def close(self):
+        if self._h:
+            load_library().fri_hip_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- getters -------------------------------------------------------------------------------
+    def centers(self):
+        out = np.empty((self.num_cells, 2), np.int32)
+        _check(load_library().fri_hip_plan_centers(self._h, _p(out)), "fri_hip_plan_centers")
+        return out
+
+    def valid_mask(self):
+        out = np.empty((self.num_cells, 16), np.uint32)
+        _check(load_library().fri_hip_plan_valid_mask(self._h, _p(out)), "fri_hip_plan_valid_mask")
+        return out
+
+    def valid_bits(self):
+        """bool [F][512] expansion of valid_mask()."""
+        m = self.valid_mask()
+        return ((m[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).astype(bool).reshape(self.num_cells, 512)
+
+    def neighbour_cells(self):
+        out = np.empty((self.num_cells, 8), np.int32)
+        _check(load_library().fri_hip_plan_neighbour_cells(self._h, _p(out)), "fri_hip_plan_neighbour_cells")
+        return out
+
+    def neighbour_table(self):
+        out = np.empty((512, 6), np.uint16)
+        _check(load_library().fri_hip_plan_neighbour_table(self._h, _p(out)), "fri_hip_plan_neighbour_table")
+        return out
+
+    # ---- host-pointer entry points -------------------------------------------------------------
+    def transform_quant(self, pixels, qmatrix=None):
+        px = np.ascontiguousarray(pixels, np.uint8).reshape(-1)
+        assert px.size == self.pixel_bytes
+        out = np.empty((self.channels, self.num_cells, 512), np.int32)
+        q = _q(qmatrix)
+        _check(load_library().fri_hip_transform_quant(self._h, _p(px), _p(q), _p(out)), "fri_hip_transform_quant", self.ctx)
+        return out
+
+    def transform_quant_batch(self, images, qmatrix=None):
+        imgs = [np.ascontiguousarray(i, np.uint8).reshape(-1) for i in images]
+        outs = [np.empty((self.channels, self.num_cells, 512), np.int32) for _ in imgs]
+        n = len(imgs)
+        pin = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        pout = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        q = _q(qmatrix)
+        _check(load_library().fri_hip_transform_quant_batch(self._h, n, pin, _p(q), pout), "fri_hip_transform_quant_batch", self.ctx)
+        return outs
+
+    def predict_histogram(self, coefs, channel, value_params, width_params):
+        co = np.ascontiguousarray(coefs, np.int32)
+        assert co.size == self.coef_count
+        vp = np.ascontiguousarray(value_params, np.float32).reshape(3, 6)
+        wp = np.ascontiguousarray(width_params, np.float32).reshape(3, 6)
+        bucket = np.empty((self.num_cells, 512), np.uint8)
+        pred = np.empty((self.num_cells, 512), np.int32)
+        hist = np.empty((10, 1024), np.uint32)
+        oob = C.c_uint64(0)
+        _check(load_library().fri_hip_predict_histogram(self._h, _p(co), channel, _p(vp), _p(wp), _p(bucket), _p(pred), _p(hist), C.addressof(oob)),
+               "fri_hip_predict_histogram", self.ctx)
+        return bucket, pred, hist, oob.value
+
+    def inverse_transform(self, coefs, qmatrix=None):
+        co = np.ascontiguousarray(coefs, np.int32)
+        assert co.size == self.coef_count
+        out = np.empty(self.pixel_bytes, np.uint8)
+        q = _q(qmatrix)
+        _check(load_library().fri_hip_inverse_transform(self._h, _p(co), _p(q), _p(out)), "fri_hip_inverse_transform", self.ctx)
+        return out
+
+    # ---- device-pointer entry points (pointers are ints, e.g. torch.Tensor.data_ptr()) ---------
+    def transform_quant_dev(self, d_pixels, d_coefs, qmatrix=None, stream=0, n_images=1, pixel_stride=0, coef_stride=0):
+        q = _q(qmatrix)
+        _check(load_library().fri_hip_transform_quant_batch_dev(self._h, n_images, d_pixels, pixel_stride, _p(q), d_coefs, coef_stride, stream),
+               "fri_hip_transform_quant_batch_dev", self.ctx)
+
+    def predict_histogram_dev(self, d_coefs, channel, value_params, width_params, d_bucket, d_prediction, d_hist, d_oob, stream=0):
+        vp = np.ascontiguousarray(value_params, np.float32).reshape(3, 6)
+        wp = np.ascontiguousarray(width_params, np.float32).reshape(3, 6)
+        _check(load_library().fri_hip_predict_histogram_dev(self._h, d_coefs, channel, _p(vp), _p(wp), d_bucket, d_prediction, d_hist, d_oob, stream),
+               "fri_hip_predict_histogram_dev", self.ctx)
+
+    def inverse_transform_dev(self, d_coefs, d_pixels, qmatrix=None, stream=0):
+        q = _q(qmatrix)
+        _check(load_library().fri_hip_inverse_transform_dev(self._h, d_coefs, _p(q), d_pixels, stream), "fri_hip_inverse_transform_dev", self.ctx)
+
+    def time_transform_quant_dev(self, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, iters, qmatrix=None, stream=0):
+        q = _q(qmatrix)
+        us = C.c_double(0)
+        _check(load_library().fri_hip_time_transform_quant_dev(self._h, n_images, d_pixels, pixel_stride, _p(q), d_coefs, coef_stride, iters, stream,
+                                                               C.byref(us)), "fri_hip_time_transform_quant_dev", self.ctx)
+        return us.value

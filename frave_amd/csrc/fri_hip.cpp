@@ -1,0 +1,410 @@
+// fri_hip.cpp -- the C ABI of libfri_hip.so (include/fri_hip.h). Host-side glue only: plan construction,
+// table upload, staging for the host-pointer entry points, launches. No CPU compute fallback.
+#include "fri_hip.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "geometry.hpp"
+#include "kernels.hpp"
+
+using namespace fri;
+
+struct fri_hip_ctx {
+    int device = -1;
+    std::string arch;
+    std::string last_error;
+};
+
+namespace {
+
+constexpr int kBatchSlots = 3;
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    uint8_t *h_pixels = nullptr; // pinned
+    int32_t *h_coefs = nullptr;  // pinned
+    uint8_t *d_pixels = nullptr;
+    int32_t *d_coefs = nullptr;
+    int pending = -1; // image index whose result sits in h_coefs once the stream drains
+};
+
+} // namespace
+
+struct fri_hip_plan {
+    fri_hip_ctx *ctx = nullptr;
+    Geometry geo;
+    DevicePlan dev;
+    std::vector<void *> owned; // device allocations backing dev.*
+    // staging for the host-pointer entry points (lazy)
+    uint8_t *d_pixels = nullptr;
+    int32_t *d_coefs = nullptr;
+    uint8_t *d_bucket = nullptr;
+    int32_t *d_prediction = nullptr;
+    uint32_t *d_hist = nullptr;
+    unsigned long long *d_oob = nullptr;
+    Slot slots[kBatchSlots];
+    bool slots_ready = false;
+};
+
+namespace {
+
+int fail_hip(fri_hip_ctx *ctx, hipError_t e, const char *what) {
+    if (ctx) {
+        ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    }
+    return e == hipErrorOutOfMemory ? FRI_HIP_ERR_OUT_OF_MEMORY : FRI_HIP_ERR_HIP;
+}
+
+#define HIP_TRY(ctx, expr)                                 \
+    do {                                                   \
+        hipError_t e_ = (expr);                            \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #expr); \
+    } while (0)
+
+template <typename T>
+int upload(fri_hip_plan *p, const std::vector<T> &v, const T *&out) {
+    void *d = nullptr;
+    size_t bytes = v.size() * sizeof(T);
+    if (!bytes) bytes = sizeof(T);
+    HIP_TRY(p->ctx, hipMalloc(&d, bytes));
+    p->owned.push_back(d);
+    if (!v.empty()) HIP_TRY(p->ctx, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    out = static_cast<const T *>(d);
+    return FRI_HIP_OK;
+}
+
+int check_q(const int32_t q[32], QMatrix &out) {
+    if (!q) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 32; i++) out.q[i] = q[i];
+    for (int i = 0; i <= 9; i++) // layers a depth-9 cell can reach (quantization.rs:13)
+        if (q[i] == 0) return FRI_HIP_ERR_DIVIDE_BY_ZERO;
+    return FRI_HIP_OK;
+}
+
+int need_device(const fri_hip_plan *p) {
+    if (!p) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    if (!p->ctx) return FRI_HIP_ERR_NO_DEVICE;
+    return FRI_HIP_OK;
+}
+
+int env_int(const char *name) {
+    const char *s = std::getenv(name);
+    return s ? std::atoi(s) : 0;
+}
+
+int ensure_staging(fri_hip_plan *p) {
+    fri_hip_ctx *c = p->ctx;
+    const size_t F = p->geo.centers.size();
+    if (!p->d_pixels) HIP_TRY(c, hipMalloc((void **)&p->d_pixels, fri_hip_plan_pixel_bytes(p)));
+    if (!p->d_coefs) HIP_TRY(c, hipMalloc((void **)&p->d_coefs, fri_hip_plan_coef_count(p) * sizeof(int32_t)));
+    if (!p->d_bucket) HIP_TRY(c, hipMalloc((void **)&p->d_bucket, F * kCell));
+    if (!p->d_prediction) HIP_TRY(c, hipMalloc((void **)&p->d_prediction, F * kCell * sizeof(int32_t)));
+    if (!p->d_hist) HIP_TRY(c, hipMalloc((void **)&p->d_hist, 10 * 1024 * sizeof(uint32_t)));
+    if (!p->d_oob) HIP_TRY(c, hipMalloc((void **)&p->d_oob, sizeof(unsigned long long)));
+    return FRI_HIP_OK;
+}
+
+int ensure_slots(fri_hip_plan *p) {
+    if (p->slots_ready) return FRI_HIP_OK;
+    fri_hip_ctx *c = p->ctx;
+    const size_t pb = fri_hip_plan_pixel_bytes(p), cb = fri_hip_plan_coef_count(p) * sizeof(int32_t);
+    for (Slot &s : p->slots) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipHostMalloc((void **)&s.h_pixels, pb, hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void **)&s.h_coefs, cb, hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc((void **)&s.d_pixels, pb));
+        HIP_TRY(c, hipMalloc((void **)&s.d_coefs, cb));
+    }
+    p->slots_ready = true;
+    return FRI_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *fri_hip_strerror(int code) {
+    switch (code) {
+    case FRI_HIP_OK: return "ok";
+    case FRI_HIP_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case FRI_HIP_ERR_HIP: return "HIP runtime error (see fri_hip_last_hip_error)";
+    case FRI_HIP_ERR_NO_DEVICE: return "no gfx950 device bound (there is no CPU fallback)";
+    case FRI_HIP_ERR_OUT_OF_MEMORY: return "out of device or pinned memory";
+    case FRI_HIP_ERR_DIVIDE_BY_ZERO: return "quantisation matrix has a zero divisor";
+    case FRI_HIP_ERR_EMPTY_LATTICE: return "no cell of the lattice touches the image";
+    default: return "unknown error";
+    }
+}
+
+const char *fri_hip_version(void) { return "frave_amd/libfri_hip 0.1 (gfx950)"; }
+
+int fri_hip_ctx_create(int device, fri_hip_ctx **out) {
+    if (!out) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRI_HIP_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FRI_HIP_ERR_HIP;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FRI_HIP_ERR_NO_DEVICE; // kernels are built for gfx950 only
+    if (hipSetDevice(device) != hipSuccess) return FRI_HIP_ERR_HIP;
+    fri_hip_ctx *c = new (std::nothrow) fri_hip_ctx;
+    if (!c) return FRI_HIP_ERR_OUT_OF_MEMORY;
+    c->device = device;
+    c->arch = prop.gcnArchName;
+    *out = c;
+    return FRI_HIP_OK;
+}
+
+int fri_hip_ctx_destroy(fri_hip_ctx *ctx) {
+    delete ctx;
+    return FRI_HIP_OK;
+}
+
+const char *fri_hip_backend(const fri_hip_ctx *ctx) { return ctx ? "hip:gfx950" : "none"; }
+const char *fri_hip_last_hip_error(const fri_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint32_t channels, fri_hip_plan **out) {
+    if (!out) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    const StaticTables &st = static_tables();
+    if (!st.error.empty() || !device_footprint_matches(st)) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    fri_hip_plan *p = new (std::nothrow) fri_hip_plan;
+    if (!p) return FRI_HIP_ERR_OUT_OF_MEMORY;
+    p->ctx = ctx;
+    std::string err = build_geometry(width, height, channels, env_int("FRI_HIP_BAND_ROWS"), env_int("FRI_HIP_CELLS_PER_TILE"), p->geo);
+    if (!err.empty()) {
+        int rc = err == "empty lattice" ? FRI_HIP_ERR_EMPTY_LATTICE : FRI_HIP_ERR_INVALID_ARGUMENT;
+        delete p;
+        return rc;
+    }
+    if (ctx) {
+        if (hipSetDevice(ctx->device) != hipSuccess) {
+            delete p;
+            return FRI_HIP_ERR_HIP;
+        }
+        const Geometry &g = p->geo;
+        DevicePlan &d = p->dev;
+        int rc = FRI_HIP_OK;
+        std::vector<uint16_t> tab(&st.nbr_table[0][0], &st.nbr_table[0][0] + kCell * 6);
+        if ((rc = upload(p, g.tiles, d.tiles)) || (rc = upload(p, g.tile_cells, d.tile_cells)) || (rc = upload(p, g.centers, d.centers)) ||
+            (rc = upload(p, g.interior, d.interior)) || (rc = upload(p, g.valid_mask, d.valid_mask)) ||
+            (rc = upload(p, g.nbr_cells, d.nbr_cells)) || (rc = upload(p, tab, d.nbr_table))) {
+            fri_hip_plan_destroy(p);
+            return rc;
+        }
+        d.n_tiles = (uint32_t)g.tiles.size();
+        d.F = (uint32_t)g.centers.size();
+        d.width = (int32_t)g.width;
+        d.height = (int32_t)g.height;
+        d.channels = (int32_t)g.channels;
+        d.lds_pitch = g.lds_pitch;
+        d.lds_rows = g.lds_rows;
+        hipDeviceProp_t prop;
+        d.hist_blocks = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? (uint32_t)prop.multiProcessorCount : 256u;
+        int hb = env_int("FRI_HIP_HIST_BLOCKS");
+        if (hb > 0) d.hist_blocks = (uint32_t)hb;
+    }
+    *out = p;
+    return FRI_HIP_OK;
+}
+
+int fri_hip_plan_destroy(fri_hip_plan *p) {
+    if (!p) return FRI_HIP_OK;
+    if (p->ctx) {
+        (void)hipSetDevice(p->ctx->device);
+        for (void *d : p->owned) (void)hipFree(d);
+        for (void *d : {(void *)p->d_pixels, (void *)p->d_coefs, (void *)p->d_bucket, (void *)p->d_prediction, (void *)p->d_hist, (void *)p->d_oob})
+            if (d) (void)hipFree(d);
+        for (Slot &s : p->slots) {
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+            if (s.h_pixels) (void)hipHostFree(s.h_pixels);
+            if (s.h_coefs) (void)hipHostFree(s.h_coefs);
+            if (s.d_pixels) (void)hipFree(s.d_pixels);
+            if (s.d_coefs) (void)hipFree(s.d_coefs);
+        }
+    }
+    delete p;
+    return FRI_HIP_OK;
+}
+
+uint32_t fri_hip_plan_num_cells(const fri_hip_plan *p) { return p ? (uint32_t)p->geo.centers.size() : 0; }
+uint32_t fri_hip_plan_num_bfs_cells(const fri_hip_plan *p) { return p ? p->geo.n_bfs_cells : 0; }
+uint32_t fri_hip_plan_num_interior_cells(const fri_hip_plan *p) { return p ? p->geo.n_interior : 0; }
+size_t fri_hip_plan_coef_count(const fri_hip_plan *p) { return p ? (size_t)p->geo.channels * p->geo.centers.size() * kCell : 0; }
+size_t fri_hip_plan_pixel_bytes(const fri_hip_plan *p) { return p ? (size_t)p->geo.width * p->geo.height * p->geo.channels : 0; }
+uint64_t fri_hip_plan_num_some(const fri_hip_plan *p) { return p ? p->geo.n_some : 0; }
+
+int fri_hip_plan_centers(const fri_hip_plan *p, int32_t *centers) {
+    if (!p || !centers) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    std::memcpy(centers, p->geo.centers.data(), p->geo.centers.size() * sizeof(Int2));
+    return FRI_HIP_OK;
+}
+int fri_hip_plan_valid_mask(const fri_hip_plan *p, uint32_t *mask) {
+    if (!p || !mask) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    std::memcpy(mask, p->geo.valid_mask.data(), p->geo.valid_mask.size() * sizeof(uint32_t));
+    return FRI_HIP_OK;
+}
+int fri_hip_plan_neighbour_cells(const fri_hip_plan *p, int32_t *ids) {
+    if (!p || !ids) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    std::memcpy(ids, p->geo.nbr_cells.data(), p->geo.nbr_cells.size() * sizeof(int32_t));
+    return FRI_HIP_OK;
+}
+int fri_hip_plan_neighbour_table(const fri_hip_plan *p, uint16_t *table) {
+    if (!p || !table) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    std::memcpy(table, &static_tables().nbr_table[0][0], sizeof(uint16_t) * kCell * 6);
+    return FRI_HIP_OK;
+}
+
+/* ---- forward -------------------------------------------------------------------------------- */
+int fri_hip_transform_quant_batch_dev(fri_hip_plan *p, uint32_t n_images, const uint8_t *d_pixels, size_t pixel_stride,
+                                      const int32_t qmatrix[32], int32_t *d_coefs, size_t coef_stride, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_pixels || !d_coefs || !n_images || n_images > 65535u) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    if (n_images > 1 && (pixel_stride < fri_hip_plan_pixel_bytes(p) || coef_stride < fri_hip_plan_coef_count(p))) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    QMatrix q;
+    if (int rc = check_q(qmatrix, q)) return rc;
+    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, q, (hipStream_t)stream));
+    return FRI_HIP_OK;
+}
+
+int fri_hip_transform_quant_dev(fri_hip_plan *p, const uint8_t *d_pixels, const int32_t qmatrix[32], int32_t *d_coefs, void *stream) {
+    return fri_hip_transform_quant_batch_dev(p, 1, d_pixels, 0, qmatrix, d_coefs, 0, stream);
+}
+
+int fri_hip_transform_quant(fri_hip_plan *p, const uint8_t *pixels, const int32_t qmatrix[32], int32_t *coefs) {
+    if (int rc = need_device(p)) return rc;
+    if (!pixels || !coefs) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    QMatrix q;
+    if (int rc = check_q(qmatrix, q)) return rc;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    if (int rc = ensure_staging(p)) return rc;
+    HIP_TRY(p->ctx, hipMemcpy(p->d_pixels, pixels, fri_hip_plan_pixel_bytes(p), hipMemcpyHostToDevice));
+    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, 1, p->d_pixels, 0, p->d_coefs, 0, q, nullptr));
+    HIP_TRY(p->ctx, hipMemcpy(coefs, p->d_coefs, fri_hip_plan_coef_count(p) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return FRI_HIP_OK;
+}
+
+int fri_hip_transform_quant_batch(fri_hip_plan *p, uint32_t n_images, const uint8_t *const *pixels, const int32_t qmatrix[32],
+                                  int32_t *const *coefs) {
+    if (int rc = need_device(p)) return rc;
+    if (!pixels || !coefs) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    QMatrix q;
+    if (int rc = check_q(qmatrix, q)) return rc;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    if (int rc = ensure_slots(p)) return rc;
+    const size_t pb = fri_hip_plan_pixel_bytes(p), cb = fri_hip_plan_coef_count(p) * sizeof(int32_t);
+    auto drain = [&](Slot &s) -> int {
+        if (s.pending < 0) return FRI_HIP_OK;
+        HIP_TRY(p->ctx, hipStreamSynchronize(s.stream));
+        std::memcpy(coefs[s.pending], s.h_coefs, cb);
+        s.pending = -1;
+        return FRI_HIP_OK;
+    };
+    for (Slot &s : p->slots) s.pending = -1;
+    for (uint32_t i = 0; i < n_images; i++) {
+        if (!pixels[i] || !coefs[i]) return FRI_HIP_ERR_INVALID_ARGUMENT;
+        Slot &s = p->slots[i % kBatchSlots];
+        if (int rc = drain(s)) return rc; // H2D / kernel / D2H of the other slots keep running meanwhile
+        std::memcpy(s.h_pixels, pixels[i], pb);
+        HIP_TRY(p->ctx, hipMemcpyAsync(s.d_pixels, s.h_pixels, pb, hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, 1, s.d_pixels, 0, s.d_coefs, 0, q, s.stream));
+        HIP_TRY(p->ctx, hipMemcpyAsync(s.h_coefs, s.d_coefs, cb, hipMemcpyDeviceToHost, s.stream));
+        s.pending = (int)i;
+    }
+    for (Slot &s : p->slots)
+        if (int rc = drain(s)) return rc;
+    return FRI_HIP_OK;
+}
+
+/* ---- prediction + histogram ----------------------------------------------------------------- */
+int fri_hip_predict_histogram_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t channel, const float value_params[3][6],
+                                  const float width_params[3][6], uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist,
+                                  uint64_t *d_n_out_of_alphabet, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_coefs || !value_params || !width_params || !d_hist || !d_n_out_of_alphabet || channel >= p->geo.channels) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    PredictParams pp;
+    std::memcpy(pp.value, value_params, sizeof(pp.value));
+    std::memcpy(pp.width, width_params, sizeof(pp.width));
+    const int32_t *plane = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
+    HIP_TRY(p->ctx, launch_predict_histogram(p->dev, plane, pp, d_bucket, d_prediction, d_hist, (unsigned long long *)d_n_out_of_alphabet, (hipStream_t)stream));
+    return FRI_HIP_OK;
+}
+
+int fri_hip_predict_histogram(fri_hip_plan *p, const int32_t *coefs, uint32_t channel, const float value_params[3][6],
+                              const float width_params[3][6], uint8_t *bucket, int32_t *prediction, uint32_t *hist,
+                              uint64_t *n_out_of_alphabet) {
+    if (int rc = need_device(p)) return rc;
+    if (!coefs || !hist || channel >= p->geo.channels) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    if (int rc = ensure_staging(p)) return rc;
+    const size_t F = p->geo.centers.size();
+    HIP_TRY(p->ctx, hipMemcpy(p->d_coefs, coefs, fri_hip_plan_coef_count(p) * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (int rc = fri_hip_predict_histogram_dev(p, p->d_coefs, channel, value_params, width_params, p->d_bucket, p->d_prediction, p->d_hist,
+                                               (uint64_t *)p->d_oob, nullptr))
+        return rc;
+    HIP_TRY(p->ctx, hipMemcpy(hist, p->d_hist, 10 * 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (bucket) HIP_TRY(p->ctx, hipMemcpy(bucket, p->d_bucket, F * kCell, hipMemcpyDeviceToHost));
+    if (prediction) HIP_TRY(p->ctx, hipMemcpy(prediction, p->d_prediction, F * kCell * sizeof(int32_t), hipMemcpyDeviceToHost));
+    unsigned long long oob = 0;
+    HIP_TRY(p->ctx, hipMemcpy(&oob, p->d_oob, sizeof(oob), hipMemcpyDeviceToHost));
+    if (n_out_of_alphabet) *n_out_of_alphabet = oob;
+    return FRI_HIP_OK;
+}
+
+/* ---- inverse ---------------------------------------------------------------------------------- */
+int fri_hip_inverse_transform_dev(fri_hip_plan *p, const int32_t *d_coefs, const int32_t qmatrix[32], uint8_t *d_pixels, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_coefs || !d_pixels) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    QMatrix q;
+    if (int rc = check_q(qmatrix, q)) return rc;
+    HIP_TRY(p->ctx, launch_inverse_transform(p->dev, d_coefs, q, d_pixels, (hipStream_t)stream));
+    return FRI_HIP_OK;
+}
+
+int fri_hip_inverse_transform(fri_hip_plan *p, const int32_t *coefs, const int32_t qmatrix[32], uint8_t *pixels) {
+    if (int rc = need_device(p)) return rc;
+    if (!coefs || !pixels) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    if (int rc = ensure_staging(p)) return rc;
+    HIP_TRY(p->ctx, hipMemcpy(p->d_coefs, coefs, fri_hip_plan_coef_count(p) * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (int rc = fri_hip_inverse_transform_dev(p, p->d_coefs, qmatrix, p->d_pixels, nullptr)) return rc;
+    HIP_TRY(p->ctx, hipMemcpy(pixels, p->d_pixels, fri_hip_plan_pixel_bytes(p), hipMemcpyDeviceToHost));
+    return FRI_HIP_OK;
+}
+
+/* ---- timing helper ------------------------------------------------------------------------------ */
+int fri_hip_time_transform_quant_dev(fri_hip_plan *p, uint32_t n_images, const uint8_t *d_pixels, size_t pixel_stride,
+                                     const int32_t qmatrix[32], int32_t *d_coefs, size_t coef_stride, uint32_t iters, void *stream,
+                                     double *mean_us) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_pixels || !d_coefs || !n_images || !iters || !mean_us) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    QMatrix q;
+    if (int rc = check_q(qmatrix, q)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(p->ctx, hipEventCreate(&e0));
+    HIP_TRY(p->ctx, hipEventCreate(&e1));
+    HIP_TRY(p->ctx, hipEventRecord(e0, s));
+    for (uint32_t i = 0; i < iters; i++) {
+        const uint32_t k = i % n_images;
+        HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, 1, d_pixels + (size_t)k * pixel_stride, 0, d_coefs + (size_t)k * coef_stride, 0, q, s));
+    }
+    HIP_TRY(p->ctx, hipEventRecord(e1, s));
+    HIP_TRY(p->ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(p->ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *mean_us = (double)ms * 1000.0 / iters;
+    return FRI_HIP_OK;
+}
+
+} // extern "C"

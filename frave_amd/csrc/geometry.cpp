@@ -1,0 +1,356 @@
+// geometry.cpp -- see geometry.hpp. Host only, no HIP.
+//
+// Citations are relative to /root/reference/crates/libfri/src/.
+#include "geometry.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+
+namespace fri {
+
+namespace {
+
+// fractal.rs:51-86, entries 0..10 (all that depth 9 uses: digits 0..8, plus 9 and 10 for the cell lattice).
+constexpr Int2 kLiterals[11] = {{0, 1}, {-1, 1}, {2, 0}, {-3, -1}, {5, -1}, {1, 3}, {-11, -1}, {9, -5}, {13, 7}, {-31, 3}, {5, -17}};
+
+inline Int2 add(Int2 a, Int2 b) { return {a.x + b.x, a.y + b.y}; }
+inline Int2 sub(Int2 a, Int2 b) { return {a.x - b.x, a.y - b.y}; }
+inline Int2 neg(Int2 a) { return {-a.x, -a.y}; }
+inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+inline int pos_mod(int a, int m) {
+    int r = a % m;
+    return r < 0 ? r + m : r;
+}
+
+struct LatticeBasis {
+    Int2 zl, zmd;
+    int det;
+    // (dx, dy) = a*zl + b*zmd  ->  (a, b); exact iff (dx, dy) is a lattice point
+    bool coords(Int2 d, int &a, int &b) const {
+        long na = (long)d.x * zmd.y - (long)d.y * zmd.x;
+        long nb = (long)zl.x * d.y - (long)zl.y * d.x;
+        if (na % det || nb % det) return false;
+        a = (int)(na / det);
+        b = (int)(nb / det);
+        return true;
+    }
+};
+
+StaticTables make_static() {
+    StaticTables t{};
+    std::memcpy(t.literals, kLiterals, sizeof(kLiterals));
+    // Fractal::new (wavelet_transform.rs:42-69): leaf 512+s sits at centre + sum_k bit_k(s) * LITERALS[k]
+    for (int s = 0; s < kCell; s++) {
+        Int2 o{0, 0};
+        for (int k = 0; k < kDepth; k++)
+            if (s >> k & 1) o = add(o, kLiterals[k]);
+        t.leaf_off[s] = o;
+    }
+    nearby_vectors(kDepth, t.v9);
+    LatticeBasis lb{t.v9[0], t.v9[5], 0};
+    lb.det = lb.zl.x * lb.zmd.y - lb.zl.y * lb.zmd.x;
+    if (lb.det != kCell) {
+        t.error = "cell lattice determinant is not 512";
+        return t;
+    }
+    // Z^2 / Lambda is cyclic: r = (dx + 181*dy) mod 512 separates the 512 leaves of a cell.
+    if (pos_mod(lb.zl.x + 181 * lb.zl.y, kCell) != 0 || pos_mod(lb.zmd.x + 181 * lb.zmd.y, kCell) != 0) {
+        t.error = "residue functional does not vanish on the cell lattice";
+        return t;
+    }
+    bool seen[kCell] = {};
+    for (int s = 0; s < kCell; s++) {
+        int r = pos_mod(t.leaf_off[s].x + 181 * t.leaf_off[s].y, kCell);
+        if (seen[r]) {
+            t.error = "leaf offsets are not a complete residue system";
+            return t;
+        }
+        seen[r] = true;
+        t.residue_lut[r] = (uint16_t)s;
+    }
+    t.nbr_delta[0] = {0, 0};
+    for (int i = 0; i < 6; i++) {
+        int a, b;
+        if (!lb.coords(t.v9[i], a, b)) {
+            t.error = "V9 is not in the lattice";
+            return t;
+        }
+        t.nbr_delta[1 + i] = {a, b};
+    }
+    t.nbr_delta[7] = {0, 0};
+
+    // locate(q): q (relative to the cell centre) = delta + leaf_off[s]  ->  (neighbour slot, s)
+    auto locate = [&](Int2 q, int &slot, int &s) -> bool {
+        s = t.residue_lut[pos_mod(q.x + 181 * q.y, kCell)];
+        int a, b;
+        if (!lb.coords(sub(q, t.leaf_off[s]), a, b)) return false;
+        for (int i = 0; i < 7; i++)
+            if (t.nbr_delta[i].x == a && t.nbr_delta[i].y == b) {
+                slot = i;
+                return true;
+            }
+        return false;
+    };
+
+    for (int p = 0; p < kCell; p++)
+        for (int k = 0; k < 6; k++) t.nbr_table[p][k] = 0x8000;
+    // Heap index 0 (DC) and 1 (root): get_lf_context_bucket (prediction.rs:86-149) with current_depth 0:
+    // left = centre + V9[4], up_left = centre + V9[5], up_right = centre + V9[0], same heap index in that cell.
+    for (int p = 0; p < 2; p++) {
+        const int slots[3] = {1 + 4, 1 + 5, 1 + 0};
+        for (int k = 0; k < 3; k++) t.nbr_table[p][k] = (uint16_t)(p | (slots[k] << 9));
+    }
+    // Levels 1..8: ContextModeler::get_neighbour_values (context_modeling.rs:25-77).
+    for (int level = 1; level < kDepth; level++) {
+        const int d = kDepth - level;
+        Int2 V[6];
+        nearby_vectors(d, V);
+        const int low_mask = (1 << d) - 1;
+        // gpm[lvl] membership of a position, static part: it is a node of level `lvl` of cell `slot`
+        auto is_node = [&](Int2 q, int lvl, int &slot, int &s) -> bool {
+            if (!locate(q, slot, s)) {
+                slot = -1;
+                return false;
+            }
+            return (s & ((1 << (kDepth - lvl)) - 1)) == 0;
+        };
+        for (int p = 1 << level; p < (2 << level); p++) {
+            const Int2 P = t.leaf_off[(p - (1 << level)) << d];
+            Int2 left = add(P, V[4]), right = add(P, V[1]);
+            Int2 up_left = add(P, V[5]), up_right = add(P, V[0]);
+            Int2 down_left = add(P, V[3]), down_right = add(P, V[2]);
+            if (d == 2) {
+                // wavelet_transform.rs:115-177: the probes index the global map by `depth` (= 2), i.e. level 2's key set.
+                int s0, sl0, s1, sl1;
+                bool a0 = is_node(add(P, V[0]), 2, sl0, s0), a1 = is_node(add(P, Int2{-1, -1}), 2, sl1, s1);
+                if ((a0 && sl0 != 0) || (a1 && sl1 != 0)) {
+                    t.error = "level-7 up probe depends on a neighbouring cell";
+                    return t;
+                }
+                if (!a0 && a1) {
+                    up_right = add(P, Int2{-1, -1});
+                    up_left = add(up_right, V[4]);
+                }
+                bool b0 = is_node(add(P, V[3]), 2, sl0, s0), b1 = is_node(add(P, Int2{1, 1}), 2, sl1, s1);
+                if ((b0 && sl0 != 0) || (b1 && sl1 != 0)) {
+                    t.error = "level-7 down probe depends on a neighbouring cell";
+                    return t;
+                }
+                if (!b0 && b1) {
+                    down_left = add(P, Int2{1, 1});
+                    down_right = add(down_left, V[1]);
+                }
+            }
+            const Int2 q[6] = {left, up_left, up_right, right, down_left, down_right};
+            for (int k = 0; k < 6; k++) {
+                int slot, s;
+                if (!locate(q[k], slot, s)) {
+                    t.error = "neighbour position outside the 7-cell neighbourhood";
+                    return t;
+                }
+                if (s & low_mask) continue; // not a level-`level` node anywhere: global_position_map[level].get() is None -> 0
+                int heap = (kCell + s) >> d;
+                if (k >= 3) heap >>= 1; // above-level values read the parent (context_modeling.rs:66)
+                t.nbr_table[p][k] = (uint16_t)(heap | (slot << 9));
+            }
+        }
+    }
+    return t;
+}
+
+} // namespace
+
+void nearby_vectors(int depth, Int2 out[6]) {
+    Int2 zl, zmd;
+    if (depth == 1) {
+        zl = {-1, 1};
+        zmd = {0, 2};
+    } else if (depth == 2) {
+        zl = {-2, 0};
+        zmd = {0, -2};
+    } else if (depth == 3) {
+        zl = {-3, -1};
+        zmd = {-1, -3};
+    } else {
+        zl = kLiterals[depth];
+        zmd = add(kLiterals[depth + 1], zl);
+    }
+    out[0] = zl;
+    out[1] = sub(zl, zmd);
+    out[2] = neg(zmd);
+    out[3] = neg(zl);
+    out[4] = sub(zmd, zl);
+    out[5] = zmd;
+}
+
+const StaticTables &static_tables() {
+    static const StaticTables t = make_static();
+    return t;
+}
+
+std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, int band_rows, int cells_per_tile, Geometry &g) {
+    const StaticTables &st = static_tables();
+    if (!st.error.empty()) return st.error;
+    if (!width || !height || (channels != 1 && channels != 3)) return "width/height must be > 0 and channels 1 or 3";
+    if ((uint64_t)width * height * channels >= (1ull << 32)) return "image larger than the reference's u32 pixel index (images.rs:94)";
+    g = Geometry{};
+    g.width = width;
+    g.height = height;
+    g.channels = channels;
+    const int W = (int)width, H = (int)height;
+    const Int2 c0{W / 2, H / 2}; // wavelet_transform.rs:452
+    const Int2 zl = st.v9[0], zmd = st.v9[5];
+    // Lattice-coordinate window that holds every in-bounds centre plus one ring of neighbours.
+    int amin = INT_MAX, amax = INT_MIN, bmin = INT_MAX, bmax = INT_MIN;
+    for (int cx : {0 - c0.x, W - c0.x})
+        for (int cy : {0 - c0.y, H - c0.y}) {
+            long na = (long)cx * zmd.y - (long)cy * zmd.x, nb = (long)zl.x * cy - (long)zl.y * cx;
+            int a = (int)floor_div((int)na, kCell), b = (int)floor_div((int)nb, kCell);
+            amin = std::min(amin, a);
+            amax = std::max(amax, a + 1);
+            bmin = std::min(bmin, b);
+            bmax = std::max(bmax, b + 1);
+        }
+    amin -= 2;
+    bmin -= 2;
+    amax += 2;
+    bmax += 2;
+    const int adim = amax - amin + 1, bdim = bmax - bmin + 1;
+    std::vector<int32_t> grid((size_t)adim * bdim, -2); // -2 unseen, -1 seen/not retained, >=0 cell id
+    auto at = [&](int a, int b) -> int32_t & { return grid[(size_t)(a - amin) * bdim + (b - bmin)]; };
+
+    // fractal_divide (wavelet_transform.rs:450-484) in lattice coordinates.
+    struct AB {
+        int a, b;
+    };
+    std::deque<AB> to_add;
+    std::vector<AB> found;
+    to_add.push_back({0, 0});
+    at(0, 0) = -1;
+    while (!to_add.empty()) {
+        AB cur = to_add.front();
+        to_add.pop_front();
+        found.push_back(cur);
+        Int2 pos{c0.x + cur.a * zl.x + cur.b * zmd.x, c0.y + cur.a * zl.y + cur.b * zmd.y};
+        if (pos.x < 0 || pos.y < 0 || pos.x > W || pos.y > H) continue; // boundary cell: kept, not expanded (:459-466)
+        for (int i = 1; i <= 6; i++) {
+            int na = cur.a + st.nbr_delta[i].x, nb = cur.b + st.nbr_delta[i].y;
+            if (na < amin || na > amax || nb < bmin || nb > bmax) return "internal: lattice window too small";
+            if (at(na, nb) == -2) {
+                at(na, nb) = -1;
+                to_add.push_back({na, nb});
+            }
+        }
+    }
+    g.n_bfs_cells = (uint32_t)found.size();
+
+    // retain(): keep cells with a Some DC <=> at least one leaf inside the image (wavelet_transform.rs:415-416).
+    struct Cand {
+        Int2 c;
+        AB ab;
+    };
+    std::vector<Cand> kept;
+    kept.reserve(found.size());
+    for (AB ab : found) {
+        Int2 c{c0.x + ab.a * zl.x + ab.b * zmd.x, c0.y + ab.a * zl.y + ab.b * zmd.y};
+        bool any = false;
+        if (c.x - 15 >= 0 && c.x + 30 < W && c.y - 8 >= 0 && c.y + 12 < H) {
+            any = true;
+        } else {
+            for (int s = 0; s < kCell && !any; s++) {
+                int x = c.x + st.leaf_off[s].x, y = c.y + st.leaf_off[s].y;
+                any = x >= 0 && y >= 0 && x < W && y < H; // images.rs:90
+            }
+        }
+        if (any) kept.push_back({c, ab});
+    }
+    if (kept.empty()) return "empty lattice";
+    std::sort(kept.begin(), kept.end(), [](const Cand &l, const Cand &r) { return l.c.y != r.c.y ? l.c.y < r.c.y : l.c.x < r.c.x; }); // utils.rs:17-32
+    const size_t F = kept.size();
+    g.centers.resize(F);
+    g.interior.assign(F, 0);
+    g.valid_mask.assign(F * 16, 0);
+    g.nbr_cells.assign(F * kNbr, -1);
+    for (size_t k = 0; k < F; k++) {
+        g.centers[k] = kept[k].c;
+        at(kept[k].ab.a, kept[k].ab.b) = (int32_t)k;
+    }
+    for (size_t k = 0; k < F; k++) {
+        const Int2 c = kept[k].c;
+        uint8_t nodev[2 * kCell];
+        int nvalid = 0;
+        for (int s = 0; s < kCell; s++) {
+            int x = c.x + st.leaf_off[s].x, y = c.y + st.leaf_off[s].y;
+            bool v = x >= 0 && y >= 0 && x < W && y < H;
+            nodev[kCell + s] = v;
+            nvalid += v;
+        }
+        for (int p = kCell - 1; p >= 1; p--) nodev[p] = nodev[2 * p] | nodev[2 * p + 1];
+        uint32_t *m = &g.valid_mask[k * 16];
+        if (nodev[1]) m[0] |= 1u; // DC = low_pass[1] (wavelet_transform.rs:221)
+        for (int p = 1; p < kCell; p++)
+            if (nodev[p]) m[p >> 5] |= 1u << (p & 31);
+        for (int i = 0; i < 16; i++) g.n_some += (uint64_t)__builtin_popcount(m[i]);
+        g.interior[k] = nvalid == kCell;
+        g.n_interior += nvalid == kCell;
+        for (int i = 0; i < 7; i++) {
+            int na = kept[k].ab.a + st.nbr_delta[i].x, nb = kept[k].ab.b + st.nbr_delta[i].y;
+            int32_t id = -1;
+            if (na >= amin && na <= amax && nb >= bmin && nb <= bmax) id = at(na, nb);
+            g.nbr_cells[k * kNbr + i] = id >= 0 ? id : -1;
+        }
+    }
+
+    // Tiling for the LDS-staged forward/inverse kernels: bands of `band_rows` centre rows, cut into
+    // runs of `cells_per_tile` cells sorted by x. Every 512-pixel-wide window holds exactly one centre
+    // per row (centres satisfy x + 181*y = const mod 512), so a run spans about
+    // 512 * cells_per_tile / band_rows pixels in x.
+    if (band_rows <= 0) band_rows = channels == 1 ? 64 : 32;
+    if (cells_per_tile <= 0) cells_per_tile = channels == 1 ? 32 : 12;
+    g.band_rows = band_rows;
+    g.cells_per_tile = cells_per_tile;
+    const int cy_min = g.centers.front().y;
+    std::vector<int32_t> order(F);
+    for (size_t k = 0; k < F; k++) order[k] = (int32_t)k;
+    auto band = [&](int32_t k) { return (g.centers[k].y - cy_min) / band_rows; };
+    std::sort(order.begin(), order.end(), [&](int32_t l, int32_t r) {
+        int bl = band(l), br = band(r);
+        if (bl != br) return bl < br;
+        if (g.centers[l].x != g.centers[r].x) return g.centers[l].x < g.centers[r].x;
+        return g.centers[l].y < g.centers[r].y;
+    });
+    g.tile_cells.assign(order.begin(), order.end());
+    size_t i = 0;
+    int max_w = 0, max_r = 0;
+    while (i < F) {
+        size_t j = i;
+        int b = band(order[i]);
+        int x0 = INT_MAX, x1 = INT_MIN, y0 = INT_MAX, y1 = INT_MIN;
+        while (j < F && (int)(j - i) < cells_per_tile && band(order[j]) == b) {
+            Int2 c = g.centers[order[j]];
+            x0 = std::min(x0, c.x - 15);
+            x1 = std::max(x1, c.x + 30);
+            y0 = std::min(y0, c.y - 8);
+            y1 = std::max(y1, c.y + 12);
+            j++;
+        }
+        x0 = std::max(x0, 0);
+        y0 = std::max(y0, 0);
+        x1 = std::min(x1, W - 1);
+        y1 = std::min(y1, H - 1);
+        Tile t{x0, y0, x1 - x0 + 1, y1 - y0 + 1, (int32_t)i, (int32_t)(j - i)};
+        max_w = std::max(max_w, t.width_px);
+        max_r = std::max(max_r, t.n_rows);
+        g.tiles.push_back(t);
+        i = j;
+    }
+    // A staged row starts at the 16-byte boundary at or below its first byte: up to 15 bytes of lead-in.
+    g.lds_pitch = ((max_w * (int)channels + 15 + 15) / 16) * 16;
+    g.lds_rows = max_r;
+    return "";
+}
+
+} // namespace fri

@@ -1,0 +1,65 @@
+// geometry.hpp -- host-side geometry of the tame-twindragon cell lattice for one (width, height).
+//
+// Everything the reference re-derives per image with hash maps (Fractal::new, fractal_divide, the
+// retain() filter, get_global_position_map; stages/wavelet_transform.rs:42-69, 405-484 of
+// /root/reference/crates/libfri/src) is a function of (width, height) only. It is computed once
+// here as dense tables and uploaded to HBM by the plan.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace fri {
+
+struct Int2 {
+    int32_t x, y;  // x = Complex.re, y = Complex.im (wavelet_transform.rs:198-199)
+};
+
+constexpr int kDepth = 9;          // BASE_FRAC_DEPTH, wavelet_transform.rs:39
+constexpr int kCell = 1 << kDepth; // 512 leaves / coefficients per cell
+constexpr int kNbr = 8;            // neighbour-cell list stride: self + 6 lattice neighbours (+1 pad)
+
+// Static (image independent) tables derived from LITERALS (fractal.rs:51-86).
+struct StaticTables {
+    Int2 literals[11];
+    Int2 leaf_off[kCell];       // leaf suffix s -> pixel offset from the cell centre
+    uint16_t residue_lut[kCell]; // ((dx + 181*dy) mod 512) -> leaf suffix s
+    Int2 v9[6];                 // get_nearby_vectors(9): cell lattice neighbours
+    Int2 nbr_delta[kNbr];       // lattice-coordinate deltas (da, db) of the neighbour-cell list
+    // Neighbour map for the gather (context_modeling.rs:25-77 + wavelet_transform.rs:97-177):
+    // entry [p][k], k = left, up_left, up_right, right, down_left, down_right.
+    // bits 0-8 heap index, bits 9-11 neighbour-cell slot, bit 15 = position is not a node of that level.
+    uint16_t nbr_table[kCell][6];
+    std::string error; // non-empty if a structural assumption failed
+};
+const StaticTables &static_tables();
+void nearby_vectors(int depth, Int2 out[6]); // wavelet_transform.rs:71-90
+
+// One K1/K3 workgroup: a group of cells whose pixel footprint is staged through LDS.
+struct Tile {
+    int32_t x_lo, y_lo;     // top-left pixel of the staged rectangle (already clipped to the image)
+    int32_t width_px, n_rows;
+    int32_t cell_begin, cell_count; // range in tile_cells
+};
+
+struct Geometry {
+    uint32_t width = 0, height = 0, channels = 0;
+    uint32_t n_bfs_cells = 0;
+    uint32_t n_interior = 0;
+    uint64_t n_some = 0;                // Some coefficients per channel
+    std::vector<Int2> centers;          // [F] canonical order (ascending im, then re)
+    std::vector<uint8_t> interior;      // [F] 1 = all 512 leaves inside the image
+    std::vector<uint32_t> valid_mask;   // [F][16]
+    std::vector<int32_t> nbr_cells;     // [F][kNbr]
+    // forward/inverse tiling
+    std::vector<Tile> tiles;
+    std::vector<int32_t> tile_cells;
+    int32_t lds_pitch = 0;   // bytes per staged row (multiple of 16)
+    int32_t lds_rows = 0;    // max rows per tile
+    int32_t band_rows = 0, cells_per_tile = 0;
+};
+
+// Returns "" on success, else an error string. band_rows / cells_per_tile = 0 picks defaults.
+std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, int band_rows, int cells_per_tile, Geometry &out);
+
+} // namespace fri

@@ -1,0 +1,52 @@
+// kernels.hpp -- launch interface between the C ABI (fri_hip.cpp) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "geometry.hpp"
+
+namespace fri {
+
+// Device-resident plan tables (all pointers are device pointers owned by the plan).
+struct DevicePlan {
+    const Tile *tiles = nullptr;
+    const int32_t *tile_cells = nullptr;
+    const Int2 *centers = nullptr;
+    const uint8_t *interior = nullptr;
+    const uint32_t *valid_mask = nullptr; // [F][16]
+    const int32_t *nbr_cells = nullptr;   // [F][kNbr]
+    const uint16_t *nbr_table = nullptr;  // [512][6]
+    uint32_t *hist_partial = nullptr;     // [hist_blocks][10*1024] scratch for the histogram reduction
+    unsigned long long *oob_partial = nullptr; // [hist_blocks]
+    uint32_t hist_blocks = 0;
+    uint32_t n_tiles = 0;
+    uint32_t F = 0;
+    int32_t width = 0, height = 0, channels = 0;
+    int32_t lds_pitch = 0, lds_rows = 0;
+};
+
+struct QMatrix {
+    int32_t q[32];
+};
+
+struct PredictParams {
+    float value[3][6];
+    float width[3][6];
+};
+
+// K1: address-map gather + 9-level residue transform + per-layer quantisation.
+hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, const uint8_t *pixels, size_t pixel_stride, int32_t *coefs,
+                                      size_t coef_stride, const QMatrix &q, hipStream_t stream);
+// K2: neighbour gather + bucket/prediction + LDS histogram, then the partial-histogram reduction.
+hipError_t launch_predict_histogram(const DevicePlan &p, const int32_t *coefs_channel, const PredictParams &pp, uint8_t *bucket,
+                                    int32_t *prediction, uint32_t *hist, unsigned long long *n_oob, hipStream_t stream);
+// K3: (reference-faithful) dequantisation + inverse transform + clamp.
+hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, const QMatrix &q, uint8_t *pixels, hipStream_t stream);
+
+size_t fwd_lds_bytes(const DevicePlan &p);
+// True iff the lane/leaf footprint hard-wired in the kernels equals the table derived from LITERALS.
+bool device_footprint_matches(const StaticTables &st);
+
+} // namespace fri

@@ -1,0 +1,152 @@
+/*
+ * fri_hip.h -- C ABI of libfri_hip.so: the MI355X (gfx950) implementation of libfri's
+ * transform + quantisation + prediction/histogram hot path (and its inverse).
+ *
+ * This is the drop-in boundary. The reference (pagmerek/frave, crate libfri) has no FFI of its
+ * own; every entry point below names the private Rust stage function whose body it replaces.
+ * Paths are relative to crates/libfri/src/ of the reference. INTEGRATION.md shows the Rust
+ * `extern "C"` block and the replacement stage bodies.
+ *
+ * Conventions
+ *   - Every call returns 0 on success or a negative FRI_HIP_ERR_* code; fri_hip_strerror() gives
+ *     text. Nothing panics or throws across the boundary.
+ *   - All buffers are caller-owned. "host" entry points take host pointers and are synchronous.
+ *     "_dev" entry points take device pointers, enqueue on `stream` (a hipStream_t passed as
+ *     void*, NULL = the null stream) and return without synchronising.
+ *   - One ctx per (host thread, GPU). Calls on one ctx/plan are not thread-safe; distinct ctxs are
+ *     independent. There is no global mutable state.
+ *   - There is NO CPU fallback: without a usable gfx950 device ctx_create fails and every compute
+ *     entry point returns FRI_HIP_ERR_NO_DEVICE.
+ *
+ * Data layout
+ *   pixels  : interleaved u8, index ((y*width + x)*channels + c)             (images.rs:94)
+ *   cells   : the F retained 512-pixel tiles ("Fractal", stages/wavelet_transform.rs:29-37) in
+ *             canonical order = ascending centre.im, then centre.re          (utils.rs:17-32)
+ *   coefs   : int32 [channels][F][512], heap order inside a cell: index 0 = DC, 1 = root,
+ *             2^l .. 2^(l+1)-1 = level l                (Fractal.coefficients, wavelet_transform.rs:32)
+ *             Option::None is encoded as FRI_HIP_NONE.
+ *   bucket  : u8  [F][512], prediction: int32 [F][512]   (Fractal.parameter_predictors, :33)
+ *   hist    : u32 [10][1024]                             (AnsContext.freqs, stages/entropy_coding.rs:34)
+ */
+#ifndef FRI_HIP_H
+#define FRI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRI_HIP_NONE INT32_MIN
+#define FRI_HIP_CELL_SIZE 512     /* 1 << BASE_FRAC_DEPTH, stages/wavelet_transform.rs:39 */
+#define FRI_HIP_CONTEXT_AMOUNT 10 /* stages/prediction.rs:15 */
+#define FRI_HIP_ALPHABET_SIZE 1024 /* stages/entropy_coding.rs:25 */
+
+#define FRI_HIP_OK 0
+#define FRI_HIP_ERR_INVALID_ARGUMENT (-1)
+#define FRI_HIP_ERR_HIP (-2)          /* a HIP runtime call failed; see fri_hip_last_hip_error() */
+#define FRI_HIP_ERR_NO_DEVICE (-3)    /* no gfx950 device / host-only plan used for compute */
+#define FRI_HIP_ERR_OUT_OF_MEMORY (-4)
+#define FRI_HIP_ERR_DIVIDE_BY_ZERO (-5) /* a used qmatrix entry is 0 (Rust: division panic, quantization.rs:17) */
+#define FRI_HIP_ERR_EMPTY_LATTICE (-6)  /* no retained cell (Rust: index panic, wavelet_transform.rs:664) */
+
+typedef struct fri_hip_ctx fri_hip_ctx;
+typedef struct fri_hip_plan fri_hip_plan;
+
+const char *fri_hip_strerror(int code);
+const char *fri_hip_version(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* Binds to HIP device `device`; fails with FRI_HIP_ERR_NO_DEVICE unless it is a gfx950 GPU. */
+int fri_hip_ctx_create(int device, fri_hip_ctx **out);
+int fri_hip_ctx_destroy(fri_hip_ctx *ctx);
+/* "hip:gfx950" for a live ctx. */
+const char *fri_hip_backend(const fri_hip_ctx *ctx);
+/* Text of the last failing HIP call on this ctx ("" if none). */
+const char *fri_hip_last_hip_error(const fri_hip_ctx *ctx);
+
+/* ---- plan: geometry of one (width, height, channels), cached and reusable ------------------ */
+/* Replaces WaveletImage::fractal_divide + Fractal::new + the retain() filter +
+ * get_global_position_map (stages/wavelet_transform.rs:42-69, 405-484): the cell lattice, the
+ * address map and the Some/None pattern depend on (width, height) only.
+ * channels is 1 or 3. With channels == 1 a cell is retained iff it has >= 1 in-image leaf (the
+ * reference's own Luma path drops every cell and panics).
+ * ctx may be NULL: the plan is then host-only (getters work, compute returns NO_DEVICE). */
+int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint32_t channels, fri_hip_plan **out);
+int fri_hip_plan_destroy(fri_hip_plan *plan);
+
+uint32_t fri_hip_plan_num_cells(const fri_hip_plan *plan);     /* F, after retain()        */
+uint32_t fri_hip_plan_num_bfs_cells(const fri_hip_plan *plan); /* size of fractal_divide() */
+uint32_t fri_hip_plan_num_interior_cells(const fri_hip_plan *plan);
+size_t fri_hip_plan_coef_count(const fri_hip_plan *plan);      /* channels * F * 512 */
+size_t fri_hip_plan_pixel_bytes(const fri_hip_plan *plan);     /* width * height * channels */
+/* centres[F][2] = (re, im) in canonical order. */
+int fri_hip_plan_centers(const fri_hip_plan *plan, int32_t *centers);
+/* mask[F][16]: bit (i & 31) of word (i >> 5) set <=> coefficient i of the cell is Some. Channel independent. */
+int fri_hip_plan_valid_mask(const fri_hip_plan *plan, uint32_t *mask);
+/* Number of Some coefficients per channel (= histogram total per channel). */
+uint64_t fri_hip_plan_num_some(const fri_hip_plan *plan);
+/* ids[F][8]: cell ids of {self, +V9[0..5]} neighbours (stages/wavelet_transform.rs:71-95), -1 = absent. */
+int fri_hip_plan_neighbour_cells(const fri_hip_plan *plan, int32_t *ids);
+/* table[512][6] u16: static neighbour map used by the gather kernel (context_modeling.rs:25-77):
+ * bits 0-8 heap index to read, bits 9-11 index into the neighbour-cell list, bit 15 = "always 0". */
+int fri_hip_plan_neighbour_table(const fri_hip_plan *plan, uint16_t *table);
+
+/* ---- forward: transform + quantisation ------------------------------------------------------ */
+/* Replaces wavelet_transform::encode (stages/wavelet_transform.rs:708-713: from_raster ->
+ * Fractal::extract_coefficients :179-225) followed by quantization::encode
+ * (stages/quantization.rs:7-25) with qmatrix = get_quantization_matrix() (:3-5, all ones today).
+ * qmatrix[layer], layer = floor(log2(i + 1)) for heap index i; truncating division. */
+int fri_hip_transform_quant(fri_hip_plan *plan, const uint8_t *pixels, const int32_t qmatrix[32], int32_t *coefs);
+int fri_hip_transform_quant_dev(fri_hip_plan *plan, const uint8_t *d_pixels, const int32_t qmatrix[32], int32_t *d_coefs,
+                                void *stream);
+/* n independent images of the plan's shape: image k at d_pixels + k*pixel_stride (bytes),
+ * coefficients at d_coefs + k*coef_stride (int32 elements). One launch. */
+int fri_hip_transform_quant_batch_dev(fri_hip_plan *plan, uint32_t n_images, const uint8_t *d_pixels, size_t pixel_stride,
+                                      const int32_t qmatrix[32], int32_t *d_coefs, size_t coef_stride, void *stream);
+/* Host batch: n images, pinned staging, H2D / kernel / D2H overlapped on internal streams. */
+int fri_hip_transform_quant_batch(fri_hip_plan *plan, uint32_t n_images, const uint8_t *const *pixels, const int32_t qmatrix[32],
+                                  int32_t *const *coefs);
+
+/* ---- prediction + context bucket + ANS symbol histogram -------------------------------------- */
+/* Replaces the loop body of prediction::encode (stages/prediction.rs:237-298) for one channel:
+ * get_lf_context_bucket (:86-149) for heap index 0 and 1, get_hf_context_bucket (:151-207) with
+ * ContextModeler::get_neighbour_values (context_modeling.rs:25-77) for levels 1..8, pack_signed
+ * (utils.rs:34-40) and AnsContext::bump_freq (stages/entropy_coding.rs:98-100).
+ * value_params / width_params are the [3][6] f32 sets the host fit produced (prediction.rs:232-235);
+ * group 0 = level 8, 1 = level 7, 2 = levels 1..6 (prediction.rs:165-179).
+ * coefs is the whole [channels][F][512] array (quantised); `channel` selects the plane.
+ * hist is overwritten. Symbols >= 1024 (Rust: index panic, entropy_coding.rs:99) are not
+ * histogrammed; their count is returned in *n_out_of_alphabet. bucket/prediction may be NULL. */
+int fri_hip_predict_histogram(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, const float value_params[3][6],
+                              const float width_params[3][6], uint8_t *bucket, int32_t *prediction, uint32_t *hist,
+                              uint64_t *n_out_of_alphabet);
+/* Device form: d_hist u32[10*1024] and d_n_out_of_alphabet u64[1] are overwritten. */
+int fri_hip_predict_histogram_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint32_t channel, const float value_params[3][6],
+                                  const float width_params[3][6], uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist,
+                                  uint64_t *d_n_out_of_alphabet, void *stream);
+
+/* ---- inverse: dequantisation + inverse transform (decode side) ------------------------------ */
+/* Replaces quantization::decode (stages/quantization.rs:27-45) + wavelet_transform::decode
+ * (stages/wavelet_transform.rs:715-717: RasterImage::from_wavelet :308-356, extract_values
+ * :358-381, set_pixel clamp images.rs:103-111). NOTE the reference's decode *divides* by
+ * qmatrix[layer] (quantization.rs:37) exactly like encode; this entry point reproduces that
+ * (bit-exact, and the identity for today's all-ones matrix). Pixels not covered by any Some
+ * coefficient are written 0 like the reference's zero-initialised raster. */
+int fri_hip_inverse_transform(fri_hip_plan *plan, const int32_t *coefs, const int32_t qmatrix[32], uint8_t *pixels);
+int fri_hip_inverse_transform_dev(fri_hip_plan *plan, const int32_t *d_coefs, const int32_t qmatrix[32], uint8_t *d_pixels,
+                                  void *stream);
+
+/* ---- timing helper ---------------------------------------------------------------------------- */
+/* Runs the forward kernel `iters` times on `stream` bracketed by HIP events recorded on that same
+ * stream and returns the mean kernel-to-kernel time per launch in microseconds (bench.py uses it
+ * for roofline.achieved). Buffers rotate over n_images image/coef slots of the batch layout. */
+int fri_hip_time_transform_quant_dev(fri_hip_plan *plan, uint32_t n_images, const uint8_t *d_pixels, size_t pixel_stride,
+                                     const int32_t qmatrix[32], int32_t *d_coefs, size_t coef_stride, uint32_t iters, void *stream,
+                                     double *mean_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

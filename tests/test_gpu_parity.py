@@ -1,0 +1,192 @@
+"""GPU parity: libfri_hip.so (through the C ABI) against the CPU oracle on the same inputs. Bit-exact."""
+import numpy as np
+import pytest
+
+from tests.common import KAT_VALUE_PARAMS, KAT_WIDTH_PARAMS, gen_image, kat_image, random_params
+
+pytestmark = pytest.mark.gpu
+
+ONES = np.ones(32, np.int32)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import frave_amd as fa
+
+    c = fa.Context(0)
+    assert c.backend == "hip:gfx950"
+    yield c
+    c.close()
+
+
+def _plan(ctx, w, h, c):
+    import frave_amd as fa
+
+    return fa.Plan(ctx, w, h, c)
+
+
+SHAPES = [(10, 10, 3), (64, 48, 3), (100, 37, 3), (1, 1, 1), (1, 700, 1), (700, 1, 3), (33, 17, 1), (512, 512, 3), (512, 512, 1), (777, 333, 1),
+          (777, 333, 3), (1000, 1000, 1), (1920, 1080, 1)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("kind", ["noise", "smooth"])
+def test_transform_matches_oracle(ctx, oracle, shape, kind):
+    w, h, c = shape
+    img = gen_image(kind, w, h, c, image_index=w + h)
+    P = _plan(ctx, w, h, c)
+    W = oracle.Wavelet(img, h, w, c)
+    assert P.num_cells == W.num_cells
+    assert np.array_equal(P.centers(), W.centers())
+    got = P.transform_quant(img)
+    want = W.coefficients()
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[0] != oracle.NONE, P.valid_bits())
+
+
+@pytest.mark.parametrize("shape", [(64, 48, 3), (300, 200, 1), (512, 512, 3)])
+def test_quantiser_matches_oracle(ctx, oracle, shape):
+    w, h, c = shape
+    img = gen_image("noise", w, h, c, 3)
+    q = np.ones(32, np.int32)
+    q[:10] = [1, 2, 3, 5, 7, -3, 16, 255, 256, 1000]
+    P = _plan(ctx, w, h, c)
+    W = oracle.Wavelet(img, h, w, c)
+    assert W.quantize(q) == 0
+    assert np.array_equal(P.transform_quant(img, q), W.coefficients())
+
+
+def test_quantiser_zero_divisor_is_an_error(ctx):
+    import frave_amd as fa
+
+    P = _plan(ctx, 64, 48, 3)
+    q = np.ones(32, np.int32)
+    q[4] = 0
+    with pytest.raises(fa.FriHipError) as e:
+        P.transform_quant(np.zeros((48, 64, 3), np.uint8), q)
+    assert e.value.code == -5
+
+
+def test_kat_hashes_through_the_abi(ctx, oracle):
+    """SURVEY.md section 8c hashes, computed from the GPU output."""
+    from tests.test_oracle_kat import KATS
+
+    for (w, h), (F, some, fnv_coef, buckets, fnv_hist) in KATS.items():
+        img = kat_image(w, h)
+        P = _plan(ctx, w, h, 3)
+        co = P.transform_quant(img)
+        assert P.num_cells == F and P.num_some == some
+        assert oracle.fnv1a64_np(co.transpose(1, 0, 2)) == fnv_coef
+        for ch in range(3):
+            _, _, hist, oob = P.predict_histogram(co, ch, KAT_VALUE_PARAMS, KAT_WIDTH_PARAMS)
+            assert oob == 0
+            if ch == 0:
+                assert hist.sum(1).tolist() == buckets
+            assert oracle.fnv1a64_np(hist) == fnv_hist[ch]
+
+
+@pytest.mark.parametrize("shape", [(10, 10, 3), (64, 48, 3), (100, 37, 3), (33, 17, 1), (512, 512, 3), (777, 333, 1), (1000, 700, 3)])
+@pytest.mark.parametrize("kind", ["noise", "smooth", "const"])
+def test_predict_histogram_matches_oracle(ctx, oracle, shape, kind):
+    w, h, c = shape
+    img = gen_image(kind, w, h, c, 11)
+    P = _plan(ctx, w, h, c)
+    W = oracle.Wavelet(img, h, w, c)
+    co = P.transform_quant(img)
+    W.quantize(ONES)
+    for ch in range(c):
+        for seed in (None, 7):
+            vp, wp = (KAT_VALUE_PARAMS, KAT_WIDTH_PARAMS) if seed is None else random_params(seed + ch)
+            b, p, hist, oob = P.predict_histogram(co, ch, vp, wp)
+            wb, wpred, whist, woob = W.predict(ch, vp, wp)
+            assert np.array_equal(b, wb)
+            assert np.array_equal(p, wpred)
+            assert np.array_equal(hist, whist)
+            assert oob == woob
+            assert int(hist.sum()) + oob == P.num_some
+
+
+def test_predict_out_of_alphabet_counted_not_clamped(ctx, oracle):
+    w, h, c = 200, 100, 1
+    img = gen_image("noise", w, h, c, 2)
+    P = _plan(ctx, w, h, c)
+    W = oracle.Wavelet(img, h, w, c)
+    co = P.transform_quant(img)
+    vp = np.full((3, 6), 40.0, np.float32)  # adversarial: predictions far off -> symbols >= 1024
+    wp = np.full((3, 6), 1e30, np.float32)
+    wp[0, :] = np.nan
+    b, p, hist, oob = P.predict_histogram(co, 0, vp, wp)
+    wb, wpred, whist, woob = W.predict(0, vp, wp)
+    assert oob == woob and oob > 0
+    assert np.array_equal(hist, whist) and np.array_equal(b, wb) and np.array_equal(p, wpred)
+
+
+@pytest.mark.parametrize("shape", [(10, 10, 3), (100, 37, 3), (512, 512, 1), (777, 333, 3), (1920, 1080, 1)])
+def test_inverse_roundtrip_and_oracle(ctx, oracle, shape):
+    w, h, c = shape
+    img = gen_image("noise", w, h, c, 5)
+    P = _plan(ctx, w, h, c)
+    co = P.transform_quant(img)
+    back = P.inverse_transform(co)
+    assert np.array_equal(back, img.reshape(-1))  # lossless identity (bench.rs:97-101)
+    # arbitrary coefficients (clamp path, images.rs:109) against the oracle's inverse
+    rng = np.random.default_rng(1)
+    W = oracle.Wavelet(img, h, w, c)
+    valid = co != oracle.NONE
+    rnd = rng.integers(-300, 300, co.shape, dtype=np.int32)
+    rnd[~valid] = oracle.NONE
+    W.set_coefficients(rnd)
+    assert np.array_equal(P.inverse_transform(rnd), W.to_raster())
+
+
+def test_batch_entry_points(ctx, oracle):
+    w, h, c = 320, 200, 3
+    imgs = [gen_image("noise", w, h, c, i) for i in range(7)]
+    P = _plan(ctx, w, h, c)
+    outs = P.transform_quant_batch(imgs)
+    for img, got in zip(imgs, outs):
+        assert np.array_equal(got, oracle.Wavelet(img, h, w, c).coefficients())
+
+
+def test_device_pointer_entry_points_with_torch(ctx, oracle):
+    import torch
+
+    w, h, c = 640, 360, 1
+    n = 5
+    P = _plan(ctx, w, h, c)
+    imgs = np.stack([gen_image("smooth", w, h, c, i) for i in range(n)])
+    d_px = torch.from_numpy(imgs.reshape(n, -1)).cuda()
+    d_co = torch.empty((n, P.coef_count), dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    P.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=s, n_images=n, pixel_stride=P.pixel_bytes, coef_stride=P.coef_count)
+    torch.cuda.synchronize()
+    got = d_co.cpu().numpy().reshape(n, c, P.num_cells, 512)
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.Wavelet(imgs[i], h, w, c).coefficients())
+
+
+@pytest.mark.parametrize("c", [1, 3])
+def test_full_size_4096_properties(ctx, c):
+    """BASELINE config 2 at full size through size-independent properties: Some/None pattern = plan mask,
+    lossless forward->inverse identity, value ranges, DC = cell mean bound, histogram total."""
+    w = h = 4096
+    img = gen_image("noise", w, h, c, 0)
+    P = _plan(ctx, w, h, c)
+    assert (P.num_cells, P.num_bfs_cells, P.num_interior_cells) == (33289, 33559, 32249)  # SURVEY.md section 8 size table
+    co = P.transform_quant(img)
+    valid = P.valid_bits()
+    for ch in range(c):
+        assert np.array_equal(co[ch] != -(2 ** 31), valid)
+    v = co[:, valid]
+    assert v.min() >= -255 and v.max() <= 255
+    assert co[:, :, 0].min() >= 0 and co[:, :, 0].max() <= 255
+    assert np.array_equal(P.inverse_transform(co), img.reshape(-1))
+    _, _, hist, oob = P.predict_histogram(co, 0, KAT_VALUE_PARAMS, KAT_WIDTH_PARAMS)
+    assert int(hist.sum()) + oob == P.num_some
+    # linearity of the residue transform on interior cells for even offsets: T(img) - T(img - 2k) has zero differences
+    img2 = (img.astype(np.int32) // 4 * 2).astype(np.uint8)
+    img3 = img2 + 20
+    a, b = P.transform_quant(img2), P.transform_quant(img3)
+    assert np.array_equal(a[:, :, 1:], b[:, :, 1:])
+    inter = valid.all(axis=1)
+    assert np.array_equal(a[:, inter, 0] + 20, b[:, inter, 0])
