@@ -15,7 +15,7 @@ SYMBOLS = [
     "fri_hip_last_hip_error", "fri_hip_plan_create", "fri_hip_plan_destroy", "fri_hip_plan_num_cells",
     "fri_hip_plan_num_bfs_cells", "fri_hip_plan_num_interior_cells", "fri_hip_plan_coef_count", "fri_hip_plan_pixel_bytes",
     "fri_hip_plan_centers", "fri_hip_plan_valid_mask", "fri_hip_plan_num_some", "fri_hip_plan_neighbour_cells",
-    "fri_hip_plan_neighbour_table", "fri_hip_transform_quant", "fri_hip_transform_quant_dev",
+    "fri_hip_plan_neighbour_table", "fri_hip_plan_tiling", "fri_hip_transform_quant", "fri_hip_transform_quant_dev",
     "fri_hip_transform_quant_batch_dev", "fri_hip_transform_quant_batch", "fri_hip_predict_histogram",
     "fri_hip_predict_histogram_dev", "fri_hip_inverse_transform", "fri_hip_inverse_transform_dev",
     "fri_hip_time_transform_quant_dev",
@@ -53,6 +53,14 @@ def load_library():
     if not os.path.exists(_SO):
         raise FileNotFoundError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                                 "frave_amd has no CPU fallback.")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's). If this
+    # library were loaded first the dynamic linker would bind torch to /opt/rocm's copy later and torch then finds no
+    # GPU; importing torch first makes both share torch's copy. Without torch (C++ callers) /opt/rocm's is used.
+    if os.environ.get("FRI_HIP_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(_SO)
     vp, u32, i32, sz = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t
     L.fri_hip_strerror.restype = C.c_char_p
@@ -74,7 +82,7 @@ def load_library():
         f.restype, f.argtypes = sz, [vp]
     L.fri_hip_plan_num_some.restype = C.c_uint64
     L.fri_hip_plan_num_some.argtypes = [vp]
-    for n in ("centers", "valid_mask", "neighbour_cells", "neighbour_table"):
+    for n in ("centers", "valid_mask", "neighbour_cells", "neighbour_table", "tiling"):
         getattr(L, "fri_hip_plan_" + n).argtypes = [vp, vp]
     L.fri_hip_transform_quant.argtypes = [vp, vp, vp, vp]
     L.fri_hip_transform_quant_dev.argtypes = [vp, vp, vp, vp, vp]
@@ -182,6 +190,11 @@ class Plan:
         out = np.empty((self.num_cells, 8), np.int32)
         _check(load_library().fri_hip_plan_neighbour_cells(self._h, _p(out)), "fri_hip_plan_neighbour_cells")
         return out
+
+    def tiling(self):
+        out = np.empty(8, np.int32)
+        _check(load_library().fri_hip_plan_tiling(self._h, _p(out)), "fri_hip_plan_tiling")
+        return dict(zip(("n_wg", "n_tiles", "lds_pitch", "lds_rows", "max_tile_cells", "band_rows", "cells_per_tile", "cells_per_wg"), (int(v) for v in out)))
 
     def neighbour_table(self):
         out = np.empty((512, 6), np.uint16)

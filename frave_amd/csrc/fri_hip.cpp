@@ -19,6 +19,7 @@ using namespace fri;
 struct fri_hip_ctx {
     int device = -1;
     std::string arch;
+    int cu_count = 256;
     std::string last_error;
 };
 
@@ -159,6 +160,7 @@ int fri_hip_ctx_create(int device, fri_hip_ctx **out) {
     if (!c) return FRI_HIP_ERR_OUT_OF_MEMORY;
     c->device = device;
     c->arch = prop.gcnArchName;
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out = c;
     return FRI_HIP_OK;
 }
@@ -179,11 +181,38 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
     fri_hip_plan *p = new (std::nothrow) fri_hip_plan;
     if (!p) return FRI_HIP_ERR_OUT_OF_MEMORY;
     p->ctx = ctx;
-    std::string err = build_geometry(width, height, channels, env_int("FRI_HIP_BAND_ROWS"), env_int("FRI_HIP_CELLS_PER_TILE"), p->geo);
-    if (!err.empty()) {
-        int rc = err == "empty lattice" ? FRI_HIP_ERR_EMPTY_LATTICE : FRI_HIP_ERR_INVALID_ARGUMENT;
-        delete p;
-        return rc;
+    TilingParams tp;
+    tp.band_rows = env_int("FRI_HIP_BAND_ROWS");
+    tp.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
+    tp.cells_per_wg = env_int("FRI_HIP_CELLS_PER_WG");
+    tp.target_wgs = env_int("FRI_HIP_TARGET_WGS");
+    if (tp.target_wgs <= 0 && ctx) tp.target_wgs = ctx->cu_count * 4; // 4 resident workgroups per CU (register budget of K1)
+    // Shrink the tiles until they fit the forward kernel's static register / LDS budget (irregular centre spacing
+    // makes a few tiles wider than the average; RGB triples the bytes per pixel).
+    for (;;) {
+        std::string err = build_geometry(width, height, channels, tp, p->geo);
+        if (!err.empty()) {
+            int rc = err == "empty lattice" ? FRI_HIP_ERR_EMPTY_LATTICE : FRI_HIP_ERR_INVALID_ARGUMENT;
+            delete p;
+            return rc;
+        }
+        DevicePlan probe;
+        probe.channels = (int32_t)channels;
+        probe.lds_pitch = p->geo.lds_pitch;
+        probe.lds_rows = p->geo.lds_rows;
+        probe.max_tile_cells = p->geo.max_tile_cells;
+        probe.max_wg_tiles = p->geo.max_wg_tiles;
+        if (fwd_plan_fits(probe)) break;
+        tp.band_rows = p->geo.band_rows;
+        tp.cells_per_tile = p->geo.cells_per_tile - 1;
+        if (tp.cells_per_tile < 1) {
+            tp.cells_per_tile = 1;
+            tp.band_rows = p->geo.band_rows / 2;
+            if (tp.band_rows < 1) {
+                delete p;
+                return FRI_HIP_ERR_INVALID_ARGUMENT;
+            }
+        }
     }
     if (ctx) {
         if (hipSetDevice(ctx->device) != hipSuccess) {
@@ -194,7 +223,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         DevicePlan &d = p->dev;
         int rc = FRI_HIP_OK;
         std::vector<uint16_t> tab(&st.nbr_table[0][0], &st.nbr_table[0][0] + kCell * 6);
-        if ((rc = upload(p, g.tiles, d.tiles)) || (rc = upload(p, g.tile_cells, d.tile_cells)) || (rc = upload(p, g.centers, d.centers)) ||
+        if ((rc = upload(p, g.tiles, d.tiles)) || (rc = upload(p, g.tile_cells, d.tile_cells)) || (rc = upload(p, g.tile_meta, d.tile_meta)) || (rc = upload(p, g.wg_tiles, d.wg_tiles)) || (rc = upload(p, g.centers, d.centers)) ||
             (rc = upload(p, g.interior, d.interior)) || (rc = upload(p, g.valid_mask, d.valid_mask)) ||
             (rc = upload(p, g.nbr_cells, d.nbr_cells)) || (rc = upload(p, tab, d.nbr_table))) {
             fri_hip_plan_destroy(p);
@@ -207,8 +236,13 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.channels = (int32_t)g.channels;
         d.lds_pitch = g.lds_pitch;
         d.lds_rows = g.lds_rows;
+        d.cells_per_tile = g.cells_per_tile;
+        d.max_tile_cells = g.max_tile_cells;
+        d.max_wg_tiles = g.max_wg_tiles;
+        d.n_wg = (uint32_t)g.wg_tiles.size() - 1;
         hipDeviceProp_t prop;
         d.hist_blocks = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? (uint32_t)prop.multiProcessorCount : 256u;
+        d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
         int hb = env_int("FRI_HIP_HIST_BLOCKS");
         if (hb > 0) d.hist_blocks = (uint32_t)hb;
     }
@@ -255,6 +289,13 @@ int fri_hip_plan_valid_mask(const fri_hip_plan *p, uint32_t *mask) {
 int fri_hip_plan_neighbour_cells(const fri_hip_plan *p, int32_t *ids) {
     if (!p || !ids) return FRI_HIP_ERR_INVALID_ARGUMENT;
     std::memcpy(ids, p->geo.nbr_cells.data(), p->geo.nbr_cells.size() * sizeof(int32_t));
+    return FRI_HIP_OK;
+}
+int fri_hip_plan_tiling(const fri_hip_plan *p, int32_t out[8]) {
+    if (!p || !out) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    const Geometry &g = p->geo;
+    const int32_t v[8] = {(int32_t)g.wg_tiles.size() - 1, (int32_t)g.tiles.size(), g.lds_pitch, g.lds_rows, g.max_tile_cells, g.band_rows, g.cells_per_tile, g.cells_per_wg};
+    std::memcpy(out, v, sizeof(v));
     return FRI_HIP_OK;
 }
 int fri_hip_plan_neighbour_table(const fri_hip_plan *p, uint16_t *table) {

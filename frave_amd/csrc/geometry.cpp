@@ -191,7 +191,7 @@ const StaticTables &static_tables() {
     return t;
 }
 
-std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, int band_rows, int cells_per_tile, Geometry &g) {
+std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, const TilingParams &tp, Geometry &g) {
     const StaticTables &st = static_tables();
     if (!st.error.empty()) return st.error;
     if (!width || !height || (channels != 1 && channels != 3)) return "width/height must be > 0 and channels 1 or 3";
@@ -304,14 +304,21 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, i
         }
     }
 
-    // Tiling for the LDS-staged forward/inverse kernels: bands of `band_rows` centre rows, cut into
-    // runs of `cells_per_tile` cells sorted by x. Every 512-pixel-wide window holds exactly one centre
-    // per row (centres satisfy x + 181*y = const mod 512), so a run spans about
-    // 512 * cells_per_tile / band_rows pixels in x.
-    if (band_rows <= 0) band_rows = channels == 1 ? 64 : 32;
-    if (cells_per_tile <= 0) cells_per_tile = channels == 1 ? 32 : 12;
+    // Work decomposition for the LDS-staged forward kernel (see geometry.hpp). Every 512-pixel-wide window holds
+    // exactly one centre per row (centres satisfy x + 181*y = const mod 512), so a tile of n cells of a band spans
+    // about 512 * n / band_rows pixels in x (+45 for the cell footprint) and band_rows + 20 rows.
+    int band_rows = tp.band_rows > 0 ? tp.band_rows : (channels == 1 ? 32 : 16);
+    int cells_per_tile = tp.cells_per_tile > 0 ? tp.cells_per_tile : (channels == 1 ? 8 : 5);
+    if (cells_per_tile * (int)channels > 16) cells_per_tile = 16 / (int)channels; // 4 waves x at most 2 pairs of (cell, channel) items each
+    // Workgroup shares: as many as the device keeps resident at once (so the launch is a single round with no tail),
+    // each with the same number of cells (+-1), but never less than one tile's worth.
+    const int target_wgs = tp.target_wgs > 0 ? tp.target_wgs : 1024;
+    size_t n_wg = std::min<size_t>((size_t)target_wgs, (F + cells_per_tile - 1) / cells_per_tile);
+    if (tp.cells_per_wg > 0) n_wg = (F + tp.cells_per_wg - 1) / tp.cells_per_wg;
+    if (n_wg < 1) n_wg = 1;
     g.band_rows = band_rows;
     g.cells_per_tile = cells_per_tile;
+    g.cells_per_wg = (int32_t)((F + n_wg - 1) / n_wg);
     const int cy_min = g.centers.front().y;
     std::vector<int32_t> order(F);
     for (size_t k = 0; k < F; k++) order[k] = (int32_t)k;
@@ -323,19 +330,17 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, i
         return g.centers[l].y < g.centers[r].y;
     });
     g.tile_cells.assign(order.begin(), order.end());
-    size_t i = 0;
+    g.tile_meta.resize(F);
+    for (size_t k = 0; k < F; k++) g.tile_meta[k] = TileCell{g.centers[order[k]].x, g.centers[order[k]].y, order[k], g.interior[order[k]]};
     int max_w = 0, max_r = 0;
-    while (i < F) {
-        size_t j = i;
-        int b = band(order[i]);
+    auto emit_tile = [&](size_t i, size_t j) {
         int x0 = INT_MAX, x1 = INT_MIN, y0 = INT_MAX, y1 = INT_MIN;
-        while (j < F && (int)(j - i) < cells_per_tile && band(order[j]) == b) {
-            Int2 c = g.centers[order[j]];
+        for (size_t k = i; k < j; k++) {
+            Int2 c = g.centers[order[k]];
             x0 = std::min(x0, c.x - 15);
             x1 = std::max(x1, c.x + 30);
             y0 = std::min(y0, c.y - 8);
             y1 = std::max(y1, c.y + 12);
-            j++;
         }
         x0 = std::max(x0, 0);
         y0 = std::max(y0, 0);
@@ -344,11 +349,30 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, i
         Tile t{x0, y0, x1 - x0 + 1, y1 - y0 + 1, (int32_t)i, (int32_t)(j - i)};
         max_w = std::max(max_w, t.width_px);
         max_r = std::max(max_r, t.n_rows);
+        g.max_tile_cells = std::max(g.max_tile_cells, t.cell_count);
         g.tiles.push_back(t);
-        i = j;
+    };
+    g.wg_tiles.push_back(0);
+    for (size_t sh = 0; sh < n_wg; sh++) {
+        const size_t s0 = F * sh / n_wg, s1 = F * (sh + 1) / n_wg;
+        size_t i = s0;
+        while (i < s1) { // maximal run inside one band, cut evenly into tiles of <= cells_per_tile cells
+            size_t j = i;
+            const int b = band(order[i]);
+            while (j < s1 && band(order[j]) == b) j++;
+            const size_t m = j - i, n_t = (m + cells_per_tile - 1) / cells_per_tile;
+            for (size_t t = 0; t < n_t; t++) emit_tile(i + m * t / n_t, i + m * (t + 1) / n_t);
+            i = j;
+        }
+        g.max_wg_tiles = std::max(g.max_wg_tiles, (int32_t)g.tiles.size() - g.wg_tiles.back());
+        g.wg_tiles.push_back((int32_t)g.tiles.size());
     }
     // A staged row starts at the 16-byte boundary at or below its first byte: up to 15 bytes of lead-in.
-    g.lds_pitch = ((max_w * (int)channels + 15 + 15) / 16) * 16;
+    // The pitch (in dwords) is kept = 8 or 24 mod 32: with the cell footprint that gives the fewest LDS bank
+    // conflicts for the byte gather (2-way instead of 4-way at a multiple of 64 bytes).
+    int pitch = ((max_w * (int)channels + 15 + 15) / 16) * 16;
+    while (((pitch / 4) % 32) != 8 && ((pitch / 4) % 32) != 24) pitch += 16;
+    g.lds_pitch = pitch;
     g.lds_rows = max_r;
     return "";
 }

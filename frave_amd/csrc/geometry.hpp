@@ -42,6 +42,11 @@ struct Tile {
     int32_t cell_begin, cell_count; // range in tile_cells
 };
 
+// One cell of a tile as the forward/inverse kernels see it (16 bytes, staged into LDS per workgroup).
+struct TileCell {
+    int32_t cx, cy, cell, interior;
+};
+
 struct Geometry {
     uint32_t width = 0, height = 0, channels = 0;
     uint32_t n_bfs_cells = 0;
@@ -52,14 +57,27 @@ struct Geometry {
     std::vector<uint32_t> valid_mask;   // [F][16]
     std::vector<int32_t> nbr_cells;     // [F][kNbr]
     // forward/inverse tiling
+    // Work decomposition: the cells of a band (band_rows rows of centres), sorted by x, are split evenly into
+    // workgroup shares of about cells_per_wg cells; a share is split evenly into tiles of <= cells_per_tile cells
+    // that the workgroup stages through LDS one after the other (double buffered).
     std::vector<Tile> tiles;
     std::vector<int32_t> tile_cells;
+    std::vector<TileCell> tile_meta;    // same order as tile_cells
+    std::vector<int32_t> wg_tiles;      // [n_wg + 1] tile range of each workgroup share
     int32_t lds_pitch = 0;   // bytes per staged row (multiple of 16)
     int32_t lds_rows = 0;    // max rows per tile
-    int32_t band_rows = 0, cells_per_tile = 0;
+    int32_t band_rows = 0, cells_per_tile = 0, cells_per_wg = 0;
+    int32_t max_tile_cells = 0; // largest cell_count over all tiles (<= cells_per_tile)
+    int32_t max_wg_tiles = 0;   // most tiles in one workgroup share
 };
 
-// Returns "" on success, else an error string. band_rows / cells_per_tile = 0 picks defaults.
-std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, int band_rows, int cells_per_tile, Geometry &out);
+struct TilingParams {
+    int band_rows = 0, cells_per_tile = 0; // 0 = default
+    int target_wgs = 0;   // workgroup shares to aim for (resident workgroups of the device); 0 = 1024
+    int cells_per_wg = 0; // if > 0 overrides target_wgs
+};
+
+// Returns "" on success, else an error string.
+std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, const TilingParams &tp, Geometry &out);
 
 } // namespace fri

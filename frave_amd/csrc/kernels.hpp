@@ -13,6 +13,11 @@ namespace fri {
 struct DevicePlan {
     const Tile *tiles = nullptr;
     const int32_t *tile_cells = nullptr;
+    const TileCell *tile_meta = nullptr;  // [F] in tile order
+    const int32_t *wg_tiles = nullptr;    // [n_wg + 1] tile range per workgroup share
+    uint32_t n_wg = 0;
+    int32_t max_tile_cells = 0;
+    int32_t max_wg_tiles = 0;
     const Int2 *centers = nullptr;
     const uint8_t *interior = nullptr;
     const uint32_t *valid_mask = nullptr; // [F][16]
@@ -24,7 +29,8 @@ struct DevicePlan {
     uint32_t n_tiles = 0;
     uint32_t F = 0;
     int32_t width = 0, height = 0, channels = 0;
-    int32_t lds_pitch = 0, lds_rows = 0;
+    int32_t lds_pitch = 0, lds_rows = 0, cells_per_tile = 0;
+    int32_t k1_ablate = 0; // timing-only ablation flags, see FwdArgs::ablate
 };
 
 struct QMatrix {
@@ -48,5 +54,7 @@ hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, c
 size_t fwd_lds_bytes(const DevicePlan &p);
 // True iff the lane/leaf footprint hard-wired in the kernels equals the table derived from LITERALS.
 bool device_footprint_matches(const StaticTables &st);
+// True iff the plan's tiles fit the forward kernel's static register/LDS budget.
+bool fwd_plan_fits(const DevicePlan &p);
 
 } // namespace fri

@@ -93,6 +93,11 @@ int fri_hip_plan_neighbour_cells(const fri_hip_plan *plan, int32_t *ids);
  * bits 0-8 heap index to read, bits 9-11 index into the neighbour-cell list, bit 15 = "always 0". */
 int fri_hip_plan_neighbour_table(const fri_hip_plan *plan, uint16_t *table);
 
+/* out[8] = {workgroup shares, tiles, LDS row pitch (bytes), LDS rows, max cells per tile, band rows, cells per tile,
+ * cells per workgroup}: how the forward kernel decomposes the image (diagnostics / tuning; FRI_HIP_BAND_ROWS,
+ * FRI_HIP_CELLS_PER_TILE, FRI_HIP_CELLS_PER_WG override the defaults at plan creation). */
+int fri_hip_plan_tiling(const fri_hip_plan *plan, int32_t out[8]);
+
 /* ---- forward: transform + quantisation ------------------------------------------------------ */
 /* Replaces wavelet_transform::encode (stages/wavelet_transform.rs:708-713: from_raster ->
  * Fractal::extract_coefficients :179-225) followed by quantization::encode

@@ -1,0 +1,19 @@
+"""Minimal K1 driver for rocprofv3: N event-timed launches over rotating slots."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import frave_amd
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+C = int(os.environ.get("SWEEP_C", "1"))
+ctx = frave_amd.Context(0)
+plan = frave_amd.Plan(ctx, 4096, 4096, C)
+slots = 8
+d_px = torch.randint(0, 256, (slots, plan.pixel_bytes), dtype=torch.uint8, device="cuda")
+d_co = torch.empty((slots, plan.coef_count), dtype=torch.int32, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+us = plan.time_transform_quant_dev(slots, d_px.data_ptr(), plan.pixel_bytes, d_co.data_ptr(), plan.coef_count, n, stream=s)
+print(f"K1 {us:.2f} us/launch over {n} launches")
