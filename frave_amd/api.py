@@ -15,7 +15,7 @@ SYMBOLS = [
     "fri_hip_last_hip_error", "fri_hip_plan_create", "fri_hip_plan_destroy", "fri_hip_plan_num_cells",
     "fri_hip_plan_num_bfs_cells", "fri_hip_plan_num_interior_cells", "fri_hip_plan_coef_count", "fri_hip_plan_pixel_bytes",
     "fri_hip_plan_centers", "fri_hip_plan_valid_mask", "fri_hip_plan_num_some", "fri_hip_plan_neighbour_cells",
-    "fri_hip_plan_neighbour_table", "fri_hip_plan_tiling", "fri_hip_transform_quant", "fri_hip_transform_quant_dev",
+    "fri_hip_plan_neighbour_table", "fri_hip_plan_tiling", "fri_hip_plan_tile_table", "fri_hip_transform_quant", "fri_hip_transform_quant_dev",
     "fri_hip_transform_quant_batch_dev", "fri_hip_transform_quant_batch", "fri_hip_predict_histogram",
     "fri_hip_predict_histogram_dev", "fri_hip_inverse_transform", "fri_hip_inverse_transform_dev",
     "fri_hip_time_transform_quant_dev",
@@ -84,6 +84,7 @@ def load_library():
     L.fri_hip_plan_num_some.argtypes = [vp]
     for n in ("centers", "valid_mask", "neighbour_cells", "neighbour_table", "tiling"):
         getattr(L, "fri_hip_plan_" + n).argtypes = [vp, vp]
+    L.fri_hip_plan_tile_table.argtypes = [vp, vp, vp, vp]
     L.fri_hip_transform_quant.argtypes = [vp, vp, vp, vp]
     L.fri_hip_transform_quant_dev.argtypes = [vp, vp, vp, vp, vp]
     L.fri_hip_transform_quant_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, vp]
@@ -195,6 +196,14 @@ class Plan:
         out = np.empty(8, np.int32)
         _check(load_library().fri_hip_plan_tiling(self._h, _p(out)), "fri_hip_plan_tiling")
         return dict(zip(("n_wg", "n_tiles", "lds_pitch", "lds_rows", "max_tile_cells", "band_rows", "cells_per_tile", "cells_per_wg"), (int(v) for v in out)))
+
+    def tile_table(self):
+        t = self.tiling()
+        tiles = np.empty((t["n_tiles"], 6), np.int32)
+        cells = np.empty(self.num_cells, np.int32)
+        wg = np.empty(t["n_wg"] + 1, np.int32)
+        _check(load_library().fri_hip_plan_tile_table(self._h, _p(tiles), _p(cells), _p(wg)), "fri_hip_plan_tile_table")
+        return tiles, cells, wg
 
     def neighbour_table(self):
         out = np.empty((512, 6), np.uint16)

@@ -298,6 +298,15 @@ int fri_hip_plan_tiling(const fri_hip_plan *p, int32_t out[8]) {
     std::memcpy(out, v, sizeof(v));
     return FRI_HIP_OK;
 }
+int fri_hip_plan_tile_table(const fri_hip_plan *p, int32_t *tiles, int32_t *tile_cells, int32_t *wg_tiles) {
+    if (!p) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    const Geometry &g = p->geo;
+    static_assert(sizeof(Tile) == 6 * sizeof(int32_t), "Tile layout");
+    if (tiles) std::memcpy(tiles, g.tiles.data(), g.tiles.size() * sizeof(Tile));
+    if (tile_cells) std::memcpy(tile_cells, g.tile_cells.data(), g.tile_cells.size() * sizeof(int32_t));
+    if (wg_tiles) std::memcpy(wg_tiles, g.wg_tiles.data(), g.wg_tiles.size() * sizeof(int32_t));
+    return FRI_HIP_OK;
+}
 int fri_hip_plan_neighbour_table(const fri_hip_plan *p, uint16_t *table) {
     if (!p || !table) return FRI_HIP_ERR_INVALID_ARGUMENT;
     std::memcpy(table, &static_tables().nbr_table[0][0], sizeof(uint16_t) * kCell * 6);

@@ -1,0 +1,94 @@
+// fri_driver.cpp -- command-line driver over the C++ mirror / C ABI (the counterpart of fri-cli's encode/decode/bench
+// for this path; crates/fri-cli/src/commands/*.rs). Synthetic inputs only (SURVEY.md section 8d generators).
+//   fri_driver roundtrip <width> <height> <channels>         encode -> predict -> decode, checks the lossless identity
+//   fri_driver batch <width> <height> <channels> <n_images>  BASELINE config 3: host batch with H2D / kernel / D2H overlap
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "libfri.hpp"
+
+static uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static std::vector<uint8_t> noise_image(uint32_t w, uint32_t h, uint32_t c, uint64_t index) {
+    std::vector<uint8_t> v((size_t)w * h * c);
+    const uint64_t seed = 0xF7A5E000ull + index;
+    for (size_t i = 0; i < v.size(); i++) v[i] = (uint8_t)(splitmix64(seed + i * 0x9E3779B97F4A7C15ull) & 0xFF);
+    return v;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 5) {
+        std::fprintf(stderr, "usage: %s roundtrip|batch <width> <height> <channels> [n_images]\n", argv[0]);
+        return 2;
+    }
+    const std::string cmd = argv[1];
+    const uint32_t w = (uint32_t)std::atoi(argv[2]), h = (uint32_t)std::atoi(argv[3]), c = (uint32_t)std::atoi(argv[4]);
+    const libfri::ColorSpace cs = c == 1 ? libfri::ColorSpace::Luma : libfri::ColorSpace::RGB;
+    libfri::EncoderOpts opts;
+    for (int ch = 0; ch < 3; ch++)
+        for (int g = 0; g < 3; g++) {
+            opts.value_prediction_params[ch][g] = {0.25f, 0.25f, 0.25f, 0.125f, 0.0625f, 0.0625f};
+            opts.width_prediction_params[ch][g] = {1.0f, 0.5f, 0.25f, 0.25f, 0.125f, 0.125f};
+        }
+    if (cmd == "roundtrip") {
+        std::vector<uint8_t> img = noise_image(w, h, c, 0);
+        auto enc = libfri::FRIEncoder(opts).encode(img, h, w, cs);
+        if (!enc.ok) {
+            std::fprintf(stderr, "%s\n", enc.error.c_str());
+            return 1;
+        }
+        uint64_t total = 0;
+        for (auto &ctx : enc.value.contexts[0])
+            for (uint32_t f : ctx.freqs) total += f;
+        auto dec = libfri::FRIDecoder().decode(enc.value.image, opts);
+        if (!dec.ok) {
+            std::fprintf(stderr, "%s\n", dec.error.c_str());
+            return 1;
+        }
+        const bool same = dec.value.data == img;
+        std::printf("cells=%u hist_total_ch0=%llu lossless=%s\n", enc.value.image.num_cells, (unsigned long long)total, same ? "yes" : "NO");
+        return same ? 0 : 1;
+    }
+    if (cmd == "batch") {
+        const uint32_t n = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 16;
+        libfri::Device dev(0);
+        std::string err;
+        fri_hip_plan *plan = dev.plan(w, h, c, err);
+        if (!plan) {
+            std::fprintf(stderr, "%s\n", err.c_str());
+            return 1;
+        }
+        const uint32_t distinct = n < 8 ? n : 8; // a few distinct inputs, every image gets its own output
+        std::vector<std::vector<uint8_t>> in(distinct);
+        for (uint32_t i = 0; i < distinct; i++) in[i] = noise_image(w, h, c, i);
+        std::vector<std::vector<int32_t>> out(n, std::vector<int32_t>(fri_hip_plan_coef_count(plan)));
+        std::vector<const uint8_t *> pin(n);
+        std::vector<int32_t *> pout(n);
+        for (uint32_t i = 0; i < n; i++) {
+            pin[i] = in[i % distinct].data();
+            pout[i] = out[i].data();
+        }
+        std::vector<int32_t> q(32, 1);
+        int rc = fri_hip_transform_quant_batch(plan, n < 3 ? n : 3, pin.data(), q.data(), pout.data()); // warm-up (allocates pinned staging)
+        auto t0 = std::chrono::steady_clock::now();
+        if (rc == FRI_HIP_OK) rc = fri_hip_transform_quant_batch(plan, n, pin.data(), q.data(), pout.data());
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rc != FRI_HIP_OK) {
+            std::fprintf(stderr, "%s\n", dev.describe(rc).c_str());
+            return 1;
+        }
+        std::printf("batch %u x %ux%ux%u: %.3f s, %.1f Mpixels/s host-to-host (PCIe inclusive)\n", n, w, h, c, s, (double)n * w * h / s / 1e6);
+        return 0;
+    }
+    std::fprintf(stderr, "unknown command %s\n", cmd.c_str());
+    return 2;
+}

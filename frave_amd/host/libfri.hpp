@@ -1,0 +1,124 @@
+// libfri.hpp -- C++ mirror of the part of libfri's interface that sits on the hot path, implemented on top of the C ABI
+// (include/fri_hip.h). Same names, argument order and error behaviour as the Rust (paths relative to
+// /root/reference/crates/libfri/src/):
+//   FRIEncoder::new(opts).encode(data, height, width, colorspace)   encoder.rs:82-109   (note: height before width)
+//   FRIDecoder{}.decode(..)                                         decoder.rs:47-59
+//   stages::wavelet_transform::{encode,decode}                      stages/wavelet_transform.rs:708-717
+//   stages::quantization::{encode,decode}                           stages/quantization.rs:7-45
+//   stages::prediction::encode                                      stages/prediction.rs:224-323 (scan loops only)
+// The host-only stages (context-model fit, rANS, frif container) are out of scope: `encode` stops at
+// the state the reference calls EncoderStage::EntropyEncoding(WaveletImage, contexts) (encoder.rs:38).
+// Errors come back as Result<T>{ok,error} with the reference's "Failed to decode: " prefix (sic, encoder.rs:106).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "fri_hip.h"
+
+namespace libfri {
+
+enum class ColorSpace { Luma, YCbCr, RGB }; // images.rs:8-21
+inline uint32_t num_channels(ColorSpace c) { return c == ColorSpace::Luma ? 1u : 3u; }
+
+struct ImageMetadata { // images.rs:68-79
+    uint32_t height = 0, width = 0;
+    ColorSpace colorspace = ColorSpace::RGB;
+};
+struct RasterImage { // images.rs:82-85
+    ImageMetadata metadata;
+    std::vector<uint8_t> data;
+};
+
+constexpr int CONTEXT_AMOUNT = FRI_HIP_CONTEXT_AMOUNT; // prediction.rs:15
+constexpr int ALPHABET_SIZE = FRI_HIP_ALPHABET_SIZE;   // entropy_coding.rs:25
+struct AnsContext {                                     // entropy_coding.rs:32-40, the part the device fills
+    std::array<uint32_t, ALPHABET_SIZE> freqs{};
+};
+
+using PredictionParams = std::array<std::array<float, 6>, 3>; // Vec<[f32; 6]> with 3 layer groups (prediction.rs:165-179)
+
+struct EncoderOpts { // encoder.rs:58-64
+    bool emit_coefficients = false;
+    bool verbose = false;
+    std::array<PredictionParams, 3> value_prediction_params{}; // per channel; an INPUT here (the SVD fit stays on the host)
+    std::array<PredictionParams, 3> width_prediction_params{};
+    std::array<int32_t, 32> quantization_matrix;               // get_quantization_matrix(), quantization.rs:3-5
+    int device = 0;
+    EncoderOpts() { quantization_matrix.fill(1); }
+};
+
+// WaveletImage (wavelet_transform.rs:384-389) as dense arrays in the plan's canonical cell order.
+struct WaveletImage {
+    ImageMetadata metadata;
+    uint32_t num_cells = 0;
+    std::vector<int32_t> centers;      // [F][2] (re, im)
+    std::vector<int32_t> coefficients; // [C][F][512], FRI_HIP_NONE = None          (Fractal.coefficients)
+    std::array<std::vector<uint8_t>, 3> bucket;     // [F][512] per channel         (Fractal.parameter_predictors.0)
+    std::array<std::vector<int32_t>, 3> prediction; // [F][512] per channel         (Fractal.parameter_predictors.1)
+    bool quantized = false;
+};
+
+template <typename T>
+struct Result {
+    bool ok = false;
+    T value{};
+    std::string error;
+};
+
+// Owns the fri_hip_ctx and a cache of plans keyed by (width, height, channels).
+class Device {
+  public:
+    explicit Device(int device);
+    ~Device();
+    Device(const Device &) = delete;
+    Device &operator=(const Device &) = delete;
+    bool ok() const { return ctx_ != nullptr; }
+    const std::string &error() const { return error_; }
+    fri_hip_plan *plan(uint32_t width, uint32_t height, uint32_t channels, std::string &err);
+    std::string describe(int code) const;
+
+  private:
+    fri_hip_ctx *ctx_ = nullptr;
+    std::string error_;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, fri_hip_plan *> plans_;
+};
+
+namespace stages {
+namespace wavelet_transform {
+Result<WaveletImage> encode(const RasterImage &raster, const EncoderOpts &opts, Device &dev); // + fused quantiser, see quantization::encode
+Result<RasterImage> decode(const WaveletImage &image, const EncoderOpts &opts, Device &dev);
+} // namespace wavelet_transform
+namespace quantization {
+// The device applies the matrix inside the transform kernel; encode() only checks that this happened.
+Result<WaveletImage> encode(WaveletImage image);
+} // namespace quantization
+namespace prediction {
+Result<std::array<std::vector<AnsContext>, 3>> encode(WaveletImage &image, const EncoderOpts &opts, Device &dev);
+} // namespace prediction
+} // namespace stages
+
+struct EncodedStages { // EncoderStage::EntropyEncoding(WaveletImage, [Vec<AnsContext>; 3]), encoder.rs:12
+    WaveletImage image;
+    std::array<std::vector<AnsContext>, 3> contexts;
+};
+
+class FRIEncoder { // encoder.rs:66-109
+  public:
+    explicit FRIEncoder(EncoderOpts opts) : opts_(std::move(opts)) {}
+    Result<EncodedStages> encode(std::vector<uint8_t> data, uint32_t height, uint32_t width, ColorSpace colorspace);
+
+  private:
+    EncoderOpts opts_;
+};
+
+class FRIDecoder { // decoder.rs:44-59, from the WaveletTransform stage on
+  public:
+    Result<RasterImage> decode(const WaveletImage &image, const EncoderOpts &opts = EncoderOpts());
+};
+
+} // namespace libfri

@@ -97,6 +97,9 @@ int fri_hip_plan_neighbour_table(const fri_hip_plan *plan, uint16_t *table);
  * cells per workgroup}: how the forward kernel decomposes the image (diagnostics / tuning; FRI_HIP_BAND_ROWS,
  * FRI_HIP_CELLS_PER_TILE, FRI_HIP_CELLS_PER_WG override the defaults at plan creation). */
 int fri_hip_plan_tiling(const fri_hip_plan *plan, int32_t out[8]);
+/* The decomposition itself (any pointer may be NULL): tiles[n_tiles][6] = {x_lo, y_lo, width_px, n_rows, cell_begin,
+ * cell_count}; tile_cells[F] = cell ids in tile order; wg_tiles[n_wg + 1] = tile range of each workgroup share. */
+int fri_hip_plan_tile_table(const fri_hip_plan *plan, int32_t *tiles, int32_t *tile_cells, int32_t *wg_tiles);
 
 /* ---- forward: transform + quantisation ------------------------------------------------------ */
 /* Replaces wavelet_transform::encode (stages/wavelet_transform.rs:708-713: from_raster ->

@@ -1,0 +1,72 @@
+"""The C ABI library loads on a machine without a GPU and exports every symbol include/fri_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fri_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fri_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    import frave_amd.api as api
+
+    assert declared_symbols() == sorted(api.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    import frave_amd
+
+    lib = frave_amd.load_library()
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+        assert ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
+
+
+def test_strerror_and_version():
+    import frave_amd
+
+    lib = frave_amd.load_library()
+    assert b"gfx950" in lib.fri_hip_version()
+    assert lib.fri_hip_strerror(0) == b"ok"
+    for code in range(-6, 0):
+        assert lib.fri_hip_strerror(code) not in (b"", b"unknown error")
+    assert lib.fri_hip_strerror(-99) == b"unknown error"
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the context cannot be created and a host-only plan refuses to compute: nothing silently runs on the CPU."""
+    import numpy as np
+    import torch
+
+    import frave_amd
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: this check is about the CPU-only container")
+    with pytest.raises(frave_amd.FriHipError) as e:
+        frave_amd.Context(0)
+    assert e.value.code == -3
+    plan = frave_amd.Plan(None, 64, 48, 3)
+    with pytest.raises(frave_amd.FriHipError) as e:
+        plan.transform_quant(np.zeros((48, 64, 3), np.uint8))
+    assert e.value.code == -3
+    with pytest.raises(frave_amd.FriHipError) as e:
+        plan.inverse_transform(np.zeros((3, plan.num_cells, 512), np.int32))
+    assert e.value.code == -3
+
+
+def test_plan_argument_errors():
+    import frave_amd
+
+    for w, h, c in [(0, 10, 3), (10, 0, 1), (10, 10, 2), (10, 10, 4)]:
+        with pytest.raises(frave_amd.FriHipError) as e:
+            frave_amd.Plan(None, w, h, c)
+        assert e.value.code == -1
+    with pytest.raises(frave_amd.FriHipError):  # larger than the reference's u32 pixel index (images.rs:94)
+        frave_amd.Plan(None, 65536, 65536, 3)
