@@ -225,10 +225,11 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         std::vector<uint16_t> tab(&st.nbr_table[0][0], &st.nbr_table[0][0] + kCell * 6);
         if ((rc = upload(p, g.tiles, d.tiles)) || (rc = upload(p, g.tile_cells, d.tile_cells)) || (rc = upload(p, g.tile_meta, d.tile_meta)) || (rc = upload(p, g.wg_tiles, d.wg_tiles)) || (rc = upload(p, g.centers, d.centers)) ||
             (rc = upload(p, g.interior, d.interior)) || (rc = upload(p, g.valid_mask, d.valid_mask)) ||
-            (rc = upload(p, g.nbr_cells, d.nbr_cells)) || (rc = upload(p, tab, d.nbr_table))) {
+            (rc = upload(p, g.nbr_cells, d.nbr_cells)) || (rc = upload(p, g.pred_slots, d.pred_slots)) || (rc = upload(p, tab, d.nbr_table))) {
             fri_hip_plan_destroy(p);
             return rc;
         }
+        d.n_pred_tiles = g.n_pred_tiles;
         d.n_tiles = (uint32_t)g.tiles.size();
         d.F = (uint32_t)g.centers.size();
         d.width = (int32_t)g.width;
@@ -240,8 +241,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.max_tile_cells = g.max_tile_cells;
         d.max_wg_tiles = g.max_wg_tiles;
         d.n_wg = (uint32_t)g.wg_tiles.size() - 1;
-        hipDeviceProp_t prop;
-        d.hist_blocks = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? (uint32_t)prop.multiProcessorCount : 256u;
+        d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
         int hb = env_int("FRI_HIP_HIST_BLOCKS");
         if (hb > 0) d.hist_blocks = (uint32_t)hb;

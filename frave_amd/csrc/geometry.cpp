@@ -304,6 +304,29 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         }
     }
 
+    // Gather-kernel tiles: kPredBlock x kPredBlock blocks in lattice coordinates (a, b) with a halo ring of one cell, so
+    // that all 7 neighbour cells of every block cell are among the tile's slots.
+    {
+        const int na = (amax - amin) / kPredBlock + 1, nb = (bmax - bmin) / kPredBlock + 1;
+        std::vector<int32_t> tile_of((size_t)na * nb, -1);
+        for (size_t k = 0; k < F; k++) {
+            const int ta = (kept[k].ab.a - amin) / kPredBlock, tb = (kept[k].ab.b - bmin) / kPredBlock;
+            int32_t &t = tile_of[(size_t)ta * nb + tb];
+            if (t < 0) {
+                t = (int32_t)g.n_pred_tiles++;
+                g.pred_slots.resize((size_t)g.n_pred_tiles * kPredSlots, -1);
+                const int a0 = amin + ta * kPredBlock - 1, b0 = bmin + tb * kPredBlock - 1;
+                for (int i = 0; i < kPredSide; i++)
+                    for (int j = 0; j < kPredSide; j++) {
+                        const int a = a0 + i, b = b0 + j;
+                        int32_t id = -1;
+                        if (a >= amin && a <= amax && b >= bmin && b <= bmax) id = at(a, b);
+                        g.pred_slots[(size_t)t * kPredSlots + i * kPredSide + j] = id >= 0 ? id : -1;
+                    }
+            }
+        }
+    }
+
     // Work decomposition for the LDS-staged forward kernel (see geometry.hpp). Every 512-pixel-wide window holds
     // exactly one centre per row (centres satisfy x + 181*y = const mod 512), so a tile of n cells of a band spans
     // about 512 * n / band_rows pixels in x (+45 for the cell footprint) and band_rows + 20 rows.

@@ -25,7 +25,7 @@ struct StaticTables {
     Int2 leaf_off[kCell];       // leaf suffix s -> pixel offset from the cell centre
     uint16_t residue_lut[kCell]; // ((dx + 181*dy) mod 512) -> leaf suffix s
     Int2 v9[6];                 // get_nearby_vectors(9): cell lattice neighbours
-    Int2 nbr_delta[kNbr];       // lattice-coordinate deltas (da, db) of the neighbour-cell list
+    Int2 nbr_delta[kNbr];       // lattice-coordinate deltas (da, db) of the neighbour-cell list (slot delta = da * kPredSide + db)
     // Neighbour map for the gather (context_modeling.rs:25-77 + wavelet_transform.rs:97-177):
     // entry [p][k], k = left, up_left, up_right, right, down_left, down_right.
     // bits 0-8 heap index, bits 9-11 neighbour-cell slot, bit 15 = position is not a node of that level.
@@ -69,7 +69,15 @@ struct Geometry {
     int32_t band_rows = 0, cells_per_tile = 0, cells_per_wg = 0;
     int32_t max_tile_cells = 0; // largest cell_count over all tiles (<= cells_per_tile)
     int32_t max_wg_tiles = 0;   // most tiles in one workgroup share
+    // Gather kernel (K2): blocks of kPredBlock x kPredBlock cells in lattice coordinates plus a one-cell halo ring.
+    // pred_slots[t][(kPredBlock+2)^2] = cell id held by each LDS slot of tile t (-1 = no retained cell there).
+    std::vector<int32_t> pred_slots;
+    uint32_t n_pred_tiles = 0;
 };
+
+constexpr int kPredBlock = 4;                              // cells per block edge
+constexpr int kPredSide = kPredBlock + 2;                  // with halo
+constexpr int kPredSlots = kPredSide * kPredSide;          // 36
 
 struct TilingParams {
     int band_rows = 0, cells_per_tile = 0; // 0 = default

@@ -514,115 +514,194 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
 // ------------------------------------------------------------------------------------------------
 // K2: prediction + bucket + histogram for one channel plane.
 // ------------------------------------------------------------------------------------------------
-constexpr int kPredThreads = 1024;
+constexpr int kPredThreads = 512; // 8 waves
+constexpr int kPredWaves = kPredThreads / 64;
 constexpr int kHistBins = 10 * 1024;
+constexpr int kSlotStride = 1040; // bytes per staged cell: 512 int16 + 8 zero halfwords (what "never a node" entries read); 16-byte multiple
 
-// Rust `f32 as u32` / `f32 as i32`: saturating, NaN -> 0.
+// Rust `f32 as u32` / `f32 as i32` (prediction.rs:56, :206): truncation toward zero, saturating, NaN -> 0. That is exactly
+// what gfx950's v_cvt_u32_f32 / v_cvt_i32_f32 do in hardware; a C++ cast would be undefined out of range, so the
+// instructions are named explicitly (pure VALU, no memory, no wait states to manage).
 __device__ __forceinline__ uint32_t f32_as_u32(float x) {
-    if (!(x == x) || x <= 0.0f) return 0u;
-    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
-    return (uint32_t)x;
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 __device__ __forceinline__ int f32_as_i32(float x) {
-    if (!(x == x)) return 0;
-    if (x >= 2147483648.0f) return INT32_MAX;
-    if (x <= -2147483648.0f) return INT32_MIN;
-    return (int)x;
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
-// assign_bucket, prediction.rs:55-68
-__device__ __forceinline__ uint32_t assign_bucket(float width) {
-    const uint32_t w = f32_as_u32(width);
+// assign_bucket, prediction.rs:55-68: 0..3->0, 3..5->1, 5..6->2, 6..8->3, 8..12->4, 12..16->5, 16..20->6, 20..25->7, 25..30->8, 30..->9
+// as four 32-entry bit planes indexed by min(width as u32, 31).
+__host__ __device__ constexpr uint32_t bucket_of(uint32_t w) {
     return w < 3 ? 0 : w < 5 ? 1 : w < 6 ? 2 : w < 8 ? 3 : w < 12 ? 4 : w < 16 ? 5 : w < 20 ? 6 : w < 25 ? 7 : w < 30 ? 8 : 9;
+}
+__host__ __device__ constexpr uint32_t bucket_plane(int bit) {
+    uint32_t m = 0;
+    for (uint32_t w = 0; w < 32; w++) m |= ((bucket_of(w) >> bit) & 1u) << w;
+    return m;
+}
+__device__ __forceinline__ uint32_t assign_bucket(float width) {
+    const uint32_t w = min(f32_as_u32(width), 31u);
+    constexpr uint32_t P0 = bucket_plane(0), P1 = bucket_plane(1), P2 = bucket_plane(2), P3 = bucket_plane(3);
+    return ((P0 >> w) & 1u) | (((P1 >> w) & 1u) << 1) | (((P2 >> w) & 1u) << 2) | (((P3 >> w) & 1u) << 3);
 }
 __device__ __forceinline__ int iabs_w(int a) { return a < 0 ? (int)(0u - (unsigned)a) : a; }
 __device__ __forceinline__ int sub_w(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 __device__ __forceinline__ int add_w(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
-// pack_signed, utils.rs:34-40 (wrapping arithmetic like a release build)
-__device__ __forceinline__ uint32_t pack_signed(int k) { return k >= 0 ? 2u * (uint32_t)k : (uint32_t)(-2ll * (long long)k - 1); }
+// pack_signed, utils.rs:34-40 (k >= 0 -> 2k, k < 0 -> -2k - 1; wrapping arithmetic like a release build) = zig-zag
+__device__ __forceinline__ uint32_t pack_signed(int k) { return ((uint32_t)k << 1) ^ (uint32_t)(k >> 31); }
 
 struct PredArgs {
-    const int32_t *coefs; // one channel plane [F][512]
-    const int32_t *nbr_cells;
-    const uint16_t *nbr_table;
+    const int32_t *coefs;      // one channel plane [F][512]
+    const int32_t *pred_slots; // [n_tiles][kPredSlots]
+    const uint16_t *nbr_table; // [512][6]
+    const uint8_t *interior;   // [F]
+    const uint32_t *valid_mask; // [F][16]
     uint8_t *bucket;
     int32_t *prediction;
     uint32_t *hist;
     unsigned long long *n_oob;
-    uint32_t F;
+    uint32_t n_tiles;
     PredictParams pp;
 };
 
-__global__ void __launch_bounds__(kPredThreads) predict_histogram_kernel(const PredArgs a) {
+// K2. Persistent workgroups (2 per CU), each walks tiles = 4 x 4 blocks of cells in lattice coordinates. Per tile the 36
+// cells of the block plus its halo ring are staged into LDS as int16 (every coefficient fits; None and missing cells are
+// stored as 0, which is what the reference's unwrap_or(0) yields), so the 6-neighbour gather of
+// ContextModeler::get_neighbour_values (context_modeling.rs:25-77) is an LDS gather: the neighbour of node p sits at
+// (own slot + slot delta) * kSlotStride + 2 * heap, and both are image independent -- each lane keeps the 48 byte offsets
+// of its 8 nodes in registers for the whole kernel. Lane L owns nodes 8L..8L+7 of a cell (wide loads and stores); its
+// level, hence its parameter group (prediction.rs:165-179), is a per-lane constant.
+__global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(const PredArgs a) {
     __shared__ uint32_t s_hist[kHistBins];
-    __shared__ uint16_t s_tab[kCell * 6];
-    __shared__ int32_t s_nbr[kPredThreads / 64][kNbr];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
+    __shared__ int32_t s_slot_cell[kPredSlots];
     __shared__ unsigned int s_oob;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < kHistBins; i += kPredThreads) s_hist[i] = 0;
-    for (int i = tid; i < kCell * 6; i += kPredThreads) s_tab[i] = a.nbr_table[i];
     if (tid == 0) s_oob = 0;
-    __syncthreads();
 
-    const uint32_t waves_total = gridDim.x * (kPredThreads / 64);
-    for (uint32_t cell = blockIdx.x * (kPredThreads / 64) + wave; cell < a.F; cell += waves_total) {
-        if (lane < kNbr) s_nbr[wave][lane] = a.nbr_cells[(size_t)cell * kNbr + lane];
-        __builtin_amdgcn_wave_barrier();
-        const int32_t *own = a.coefs + (size_t)cell * kCell;
-#pragma unroll 2
-        for (int i = 0; i < kCell / 64; i++) {
-            const int p = i * 64 + lane;
-            const int value = own[p];
-            uint32_t bucket = 0;
-            int prediction = 0;
-            if (value != kNone) {
+    // neighbour byte offsets relative to the own slot, loop invariant
+    int off[8][6];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int p = 8 * lane + i;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const uint32_t e = a.nbr_table[p * 6 + k];
+            const int slot = (e >> 9) & 7; // index into {self, +V9[0..5]} = lattice deltas (0,0),(1,0),(1,-1),(0,-1),(-1,0),(-1,1),(0,1)
+            const int da = slot == 1 || slot == 2 ? 1 : slot == 4 || slot == 5 ? -1 : 0;
+            const int db = slot == 2 || slot == 3 ? -1 : slot == 5 || slot == 6 ? 1 : 0;
+            off[i][k] = (e & 0x8000u) ? 1024 : (da * kPredSide + db) * kSlotStride + 2 * (int)(e & 511u);
+        }
+    }
+    // parameter group of this lane's nodes: level 8 (lanes 32..63) -> 0, level 7 (16..31) -> 1, levels 1..6 -> 2
+    const int g = lane >= 32 ? 0 : lane >= 16 ? 1 : 2;
+    float wp[6], vp[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        wp[k] = a.pp.width[g][k];
+        vp[k] = a.pp.value[g][k];
+    }
+
+    // Tile walk: blocks are dealt round-robin over the 8 XCDs; XCD x gets the contiguous eighth [x n/8, (x+1) n/8) of the
+    // tiles and its workgroups stride through it together, so concurrently staged tiles are neighbours in the image and
+    // their shared halo cells hit in that XCD's L2 (placement only affects speed).
+    const uint32_t groups = gridDim.x < 8u ? gridDim.x : 8u; // a grid smaller than 8 blocks: every block is its own group
+    const uint32_t xcd = blockIdx.x % groups, wg_in_xcd = blockIdx.x / groups, wgs_per_xcd = (gridDim.x - xcd + groups - 1u) / groups;
+    const uint32_t t_begin = (uint32_t)((uint64_t)a.n_tiles * xcd / groups), t_end = (uint32_t)((uint64_t)a.n_tiles * (xcd + 1u) / groups);
+    for (uint32_t tile = t_begin + wg_in_xcd; tile < t_end; tile += wgs_per_xcd) {
+        __syncthreads(); // everyone is done with the previous tile's LDS image (and the histogram is zeroed on the first pass)
+        if (tid < kPredSlots) s_slot_cell[tid] = a.pred_slots[(size_t)tile * kPredSlots + tid];
+        __syncthreads();
+        for (int slot = wave; slot < kPredSlots; slot += kPredWaves) { // stage: 64 lanes x 8 coefficients per cell
+            const int cell = s_slot_cell[slot];
+            int4 lo = make_int4(0, 0, 0, 0), hi = lo;
+            if (cell >= 0) {
+                const int4 *src = reinterpret_cast<const int4 *>(a.coefs + (size_t)cell * kCell + 8 * lane);
+                lo = src[0];
+                hi = src[1];
+            }
+            auto h = [](int v) -> uint32_t { return v == kNone ? 0u : ((uint32_t)v & 0xFFFFu); }; // .unwrap_or(0)
+            uint4 packed;
+            packed.x = h(lo.x) | (h(lo.y) << 16);
+            packed.y = h(lo.z) | (h(lo.w) << 16);
+            packed.z = h(hi.x) | (h(hi.y) << 16);
+            packed.w = h(hi.z) | (h(hi.w) << 16);
+            uint8_t *dst = s_cells + slot * kSlotStride;
+            *reinterpret_cast<uint4 *>(dst + 16 * lane) = packed;
+            if (lane == 0) *reinterpret_cast<uint4 *>(dst + 1024) = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+
+        for (int r = wave; r < kPredBlock * kPredBlock; r += kPredWaves) { // two block cells per wave
+            const int slot = (1 + r / kPredBlock) * kPredSide + 1 + (r % kPredBlock);
+            const int cell = s_slot_cell[slot];
+            if (cell < 0) continue;
+            const uint8_t *own = s_cells + slot * kSlotStride;
+            const uint4 mine = *reinterpret_cast<const uint4 *>(own + 16 * lane); // this lane's 8 coefficients
+            const uint32_t mw[4] = {mine.x, mine.y, mine.z, mine.w};
+            uint32_t some = 0xFFu; // bit i: node 8*lane + i is Some
+            if (!a.interior[cell]) some = (a.valid_mask[(size_t)cell * 16 + (lane >> 2)] >> (8 * (lane & 3))) & 0xFFu;
+            uint32_t bk[8];
+            int pr[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int value = (int)(short)((mw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
                 int v[6];
 #pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    const uint32_t e = s_tab[p * 6 + k];
-                    int x = 0;
-                    if (!(e & 0x8000u)) {
-                        const int nb = s_nbr[wave][(e >> 9) & 7];
-                        if (nb >= 0) {
-                            x = a.coefs[(size_t)nb * kCell + (e & 511u)];
-                            if (x == kNone) x = 0; // .unwrap_or(0)
-                        }
-                    }
-                    v[k] = x;
-                }
-                if (p < 2) { // get_lf_context_bucket, prediction.rs:134-144
-                    const uint32_t width = (uint32_t)iabs_w(sub_w(v[0], v[2]));
-                    bucket = assign_bucket((float)width);
+                for (int k = 0; k < 6; k++) v[k] = *reinterpret_cast<const short *>(own + off[i][k]);
+                // get_hf_context_bucket, prediction.rs:165-206: f32, left to right, one rounding per op. The reference
+                // takes |a - b| on i32 and converts; for these magnitudes |f32(a) - f32(b)| is the same exact value, and
+                // the absolute value then rides on the multiply as a source modifier.
+                float f[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) f[k] = (float)v[k];
+                float width = wp[0];
+                width = __fadd_rn(width, __fmul_rn(wp[1], fabsf(__fsub_rn(f[0], f[3]))));
+                width = __fadd_rn(width, __fmul_rn(wp[2], fabsf(__fsub_rn(f[1], f[2]))));
+                width = __fadd_rn(width, __fmul_rn(wp[3], fabsf(__fsub_rn(f[4], f[5]))));
+                width = __fadd_rn(width, __fmul_rn(wp[4], fabsf(__fsub_rn(f[1], f[5]))));
+                width = __fadd_rn(width, __fmul_rn(wp[5], fabsf(__fsub_rn(f[2], f[4]))));
+                uint32_t bucket = assign_bucket(width);
+                float pf = __fmul_rn(f[0], vp[0]);
+                pf = __fadd_rn(pf, __fmul_rn(f[1], vp[1]));
+                pf = __fadd_rn(pf, __fmul_rn(f[2], vp[2]));
+                pf = __fadd_rn(pf, __fmul_rn(f[3], vp[3]));
+                pf = __fadd_rn(pf, __fmul_rn(f[4], vp[4]));
+                pf = __fadd_rn(pf, __fmul_rn(f[5], vp[5]));
+                int prediction = f32_as_i32(pf);
+                if (i < 2 && lane == 0) { // heap index 0 (DC) and 1 (root): get_lf_context_bucket, prediction.rs:134-144
+                    const uint32_t w = (uint32_t)iabs_w(sub_w(v[0], v[2]));
+                    bucket = bucket_of(w);
                     const int mx = max(v[0], v[2]), mn = min(v[0], v[2]);
                     prediction = v[1] >= mx ? mx : v[1] <= mn ? mn : sub_w(add_w(v[0], v[2]), v[1]);
-                } else { // get_hf_context_bucket, prediction.rs:165-206: f32, left to right, one rounding per op
-                    const int level = 31 - __clz(p);
-                    const int g = level < 7 ? 2 : level == 7 ? 1 : 0;
-                    const float *wp = a.pp.width[g], *vp = a.pp.value[g];
-                    float width = wp[0];
-                    width = __fadd_rn(width, __fmul_rn(wp[1], (float)iabs_w(sub_w(v[0], v[3]))));
-                    width = __fadd_rn(width, __fmul_rn(wp[2], (float)iabs_w(sub_w(v[1], v[2]))));
-                    width = __fadd_rn(width, __fmul_rn(wp[3], (float)iabs_w(sub_w(v[4], v[5]))));
-                    width = __fadd_rn(width, __fmul_rn(wp[4], (float)iabs_w(sub_w(v[1], v[5]))));
-                    width = __fadd_rn(width, __fmul_rn(wp[5], (float)iabs_w(sub_w(v[2], v[4]))));
-                    bucket = assign_bucket(width);
-                    float pr = __fmul_rn((float)v[0], vp[0]);
-                    pr = __fadd_rn(pr, __fmul_rn((float)v[1], vp[1]));
-                    pr = __fadd_rn(pr, __fmul_rn((float)v[2], vp[2]));
-                    pr = __fadd_rn(pr, __fmul_rn((float)v[3], vp[3]));
-                    pr = __fadd_rn(pr, __fmul_rn((float)v[4], vp[4]));
-                    pr = __fadd_rn(pr, __fmul_rn((float)v[5], vp[5]));
-                    prediction = f32_as_i32(pr);
                 }
-                const uint32_t sym = pack_signed(sub_w(value, prediction));
-                if (sym < 1024u)
-                    atomicAdd(&s_hist[bucket * 1024u + sym], 1u); // bump_freq, entropy_coding.rs:98-100
-                else
-                    atomicAdd(&s_oob, 1u); // the reference would panic (index out of bounds)
+                if ((some >> i) & 1u) {
+                    const uint32_t sym = pack_signed(sub_w(value, prediction));
+                    if (sym < 1024u)
+                        atomicAdd(&s_hist[bucket * 1024u + sym], 1u); // bump_freq, entropy_coding.rs:98-100
+                    else
+                        atomicAdd(&s_oob, 1u); // the reference would panic (index out of bounds)
+                } else { // never written by the reference: stays (0, 0) (wavelet_transform.rs:60-64)
+                    bucket = 0;
+                    prediction = 0;
+                }
+                bk[i] = bucket;
+                pr[i] = prediction;
             }
-            if (a.bucket) a.bucket[(size_t)cell * kCell + p] = (uint8_t)bucket;
-            if (a.prediction) a.prediction[(size_t)cell * kCell + p] = prediction;
+            const size_t base = (size_t)cell * kCell + 8 * lane;
+            if (a.bucket)
+                *reinterpret_cast<uint2 *>(a.bucket + base) =
+                    make_uint2(bk[0] | (bk[1] << 8) | (bk[2] << 16) | (bk[3] << 24), bk[4] | (bk[5] << 8) | (bk[6] << 16) | (bk[7] << 24));
+            if (a.prediction) {
+                int4 *dst = reinterpret_cast<int4 *>(a.prediction + base);
+                dst[0] = make_int4(pr[0], pr[1], pr[2], pr[3]);
+                dst[1] = make_int4(pr[4], pr[5], pr[6], pr[7]);
+            }
         }
-        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     for (int i = tid; i < kHistBins; i += kPredThreads) {
@@ -782,17 +861,18 @@ hipError_t launch_predict_histogram(const DevicePlan &p, const int32_t *coefs_ch
     if (e != hipSuccess) return e;
     PredArgs a{};
     a.coefs = coefs_channel;
-    a.nbr_cells = p.nbr_cells;
+    a.pred_slots = p.pred_slots;
     a.nbr_table = p.nbr_table;
+    a.interior = p.interior;
+    a.valid_mask = p.valid_mask;
     a.bucket = bucket;
     a.prediction = prediction;
     a.hist = hist;
     a.n_oob = n_oob;
-    a.F = p.F;
+    a.n_tiles = p.n_pred_tiles;
     a.pp = pp;
-    const uint32_t per_block = kPredThreads / 64;
-    uint32_t blocks = (p.F + per_block - 1) / per_block;
-    if (blocks > p.hist_blocks) blocks = p.hist_blocks;
+    uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
+    if (!blocks) blocks = 1;
     hipLaunchKernelGGL(predict_histogram_kernel, dim3(blocks), dim3(kPredThreads), 0, stream, a);
     return hipGetLastError();
 }

@@ -23,6 +23,8 @@ struct DevicePlan {
     const uint32_t *valid_mask = nullptr; // [F][16]
     const int32_t *nbr_cells = nullptr;   // [F][kNbr]
     const uint16_t *nbr_table = nullptr;  // [512][6]
+    const int32_t *pred_slots = nullptr;  // [n_pred_tiles][kPredSlots]
+    uint32_t n_pred_tiles = 0;
     uint32_t *hist_partial = nullptr;     // [hist_blocks][10*1024] scratch for the histogram reduction
     unsigned long long *oob_partial = nullptr; // [hist_blocks]
     uint32_t hist_blocks = 0;

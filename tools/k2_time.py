@@ -1,0 +1,48 @@
+"""Time K2 (predict + histogram) and K3 (inverse) at 4096x4096. GPU only."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import frave_amd
+
+C = int(os.environ.get("SWEEP_C", "1"))
+kind = os.environ.get("K2_DATA", "noise")
+ctx = frave_amd.Context(0)
+plan = frave_amd.Plan(ctx, 4096, 4096, C)
+F = plan.num_cells
+if kind == "noise":
+    d_px = torch.randint(0, 256, (plan.pixel_bytes,), dtype=torch.uint8, device="cuda")
+else:  # smooth: hot histogram bins
+    y, x = torch.meshgrid(torch.arange(4096, device="cuda"), torch.arange(4096, device="cuda"), indexing="ij")
+    d_px = (((x + 2 * y) >> 3) + torch.randint(0, 8, (4096, 4096), device="cuda")).to(torch.uint8).reshape(-1).repeat_interleave(C)
+d_co = torch.empty(plan.coef_count, dtype=torch.int32, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+plan.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=s)
+vp = np.tile(np.array([0.25, 0.25, 0.25, 0.125, 0.0625, 0.0625], np.float32), (3, 1))
+wp = np.tile(np.array([1.0, 0.5, 0.25, 0.25, 0.125, 0.125], np.float32), (3, 1))
+d_b = torch.empty(F * 512, dtype=torch.uint8, device="cuda")
+d_p = torch.empty(F * 512, dtype=torch.int32, device="cuda")
+d_h = torch.empty(10 * 1024, dtype=torch.int32, device="cuda")
+d_o = torch.empty(1, dtype=torch.int64, device="cuda")
+d_back = torch.empty(plan.pixel_bytes, dtype=torch.uint8, device="cuda")
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
+def timed(fn, reps=20):
+    fn()
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps * 1e3
+
+
+k2 = timed(lambda: plan.predict_histogram_dev(d_co.data_ptr(), 0, vp, wp, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=s))
+k3 = timed(lambda: plan.inverse_transform_dev(d_co.data_ptr(), d_back.data_ptr(), stream=s))
+ok = bool(torch.equal(d_back, d_px))
+print(f"data={kind} hist_blocks={os.environ.get('FRI_HIP_HIST_BLOCKS', 'default')}  K2 {k2:8.2f} us  K3 {k3:8.2f} us  roundtrip={ok}  hist_total={int(d_h.sum())} (expect {plan.num_some})")
