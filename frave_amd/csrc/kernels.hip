@@ -542,11 +542,13 @@ __host__ __device__ constexpr uint32_t bucket_plane(int bit) {
     for (uint32_t w = 0; w < 32; w++) m |= ((bucket_of(w) >> bit) & 1u) << w;
     return m;
 }
-__device__ __forceinline__ uint32_t assign_bucket(float width) {
-    const uint32_t w = min(f32_as_u32(width), 31u);
+__device__ __forceinline__ uint32_t bucket_of_rt(uint32_t width_u32) {
+    const uint32_t w = min(width_u32, 31u);
     constexpr uint32_t P0 = bucket_plane(0), P1 = bucket_plane(1), P2 = bucket_plane(2), P3 = bucket_plane(3);
-    return ((P0 >> w) & 1u) | (((P1 >> w) & 1u) << 1) | (((P2 >> w) & 1u) << 2) | (((P3 >> w) & 1u) << 3);
+    return __builtin_amdgcn_ubfe(P0, w, 1) | (__builtin_amdgcn_ubfe(P1, w, 1) << 1) | (__builtin_amdgcn_ubfe(P2, w, 1) << 2) |
+           (__builtin_amdgcn_ubfe(P3, w, 1) << 3);
 }
+__device__ __forceinline__ uint32_t assign_bucket(float width) { return bucket_of_rt(f32_as_u32(width)); }
 __device__ __forceinline__ int iabs_w(int a) { return a < 0 ? (int)(0u - (unsigned)a) : a; }
 __device__ __forceinline__ int sub_w(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 __device__ __forceinline__ int add_w(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
@@ -567,43 +569,88 @@ struct PredArgs {
     PredictParams pp;
 };
 
+// One node of the gather/predict/histogram loop. P_HI = p >> 6 is compile time, so the parameter group
+// (prediction.rs:165-179: level 8 -> 0, level 7 -> 1, levels 1..6 -> 2) is too and the parameters stay in SGPRs.
+template <int I>
+__device__ __forceinline__ void predict_node(const uint8_t *own, int lane, uint32_t o01, uint32_t o23, uint32_t o45, bool some, const PredictParams &pp,
+                                             uint32_t *s_hist, uint32_t &bucket_out, int &pred_out) {
+    constexpr int g = I >= 4 ? 0 : I >= 2 ? 1 : 2;
+    const float *wp = pp.width[g], *vp = pp.value[g];
+    const int value = *reinterpret_cast<const short *>(own + 2 * (lane + 64 * I));
+    // neighbour halfword offsets relative to the own slot, two per register
+    const int o[6] = {(int)(short)(o01 & 0xFFFFu), (int)o01 >> 16, (int)(short)(o23 & 0xFFFFu), (int)o23 >> 16, (int)(short)(o45 & 0xFFFFu), (int)o45 >> 16};
+    float f[6];
+    int v[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        v[k] = *reinterpret_cast<const short *>(own + 2 * o[k]);
+        f[k] = (float)v[k];
+    }
+    // get_hf_context_bucket, prediction.rs:165-206: f32, left to right, one rounding per op. The reference takes |a - b|
+    // on i32 and converts; for these magnitudes |f32(a) - f32(b)| is the same exact value, and the absolute value rides
+    // on the multiply as a source modifier.
+    float width = wp[0];
+    width = __fadd_rn(width, __fmul_rn(wp[1], fabsf(__fsub_rn(f[0], f[3]))));
+    width = __fadd_rn(width, __fmul_rn(wp[2], fabsf(__fsub_rn(f[1], f[2]))));
+    width = __fadd_rn(width, __fmul_rn(wp[3], fabsf(__fsub_rn(f[4], f[5]))));
+    width = __fadd_rn(width, __fmul_rn(wp[4], fabsf(__fsub_rn(f[1], f[5]))));
+    width = __fadd_rn(width, __fmul_rn(wp[5], fabsf(__fsub_rn(f[2], f[4]))));
+    uint32_t bucket = assign_bucket(width);
+    float pf = __fmul_rn(f[0], vp[0]);
+    pf = __fadd_rn(pf, __fmul_rn(f[1], vp[1]));
+    pf = __fadd_rn(pf, __fmul_rn(f[2], vp[2]));
+    pf = __fadd_rn(pf, __fmul_rn(f[3], vp[3]));
+    pf = __fadd_rn(pf, __fmul_rn(f[4], vp[4]));
+    pf = __fadd_rn(pf, __fmul_rn(f[5], vp[5]));
+    int prediction = f32_as_i32(pf);
+    if (I == 0) { // heap index 0 (DC) and 1 (root) live in lanes 0, 1: get_lf_context_bucket, prediction.rs:134-144
+        const uint32_t w = (uint32_t)iabs_w(sub_w(v[0], v[2]));
+        const int mx = max(v[0], v[2]), mn = min(v[0], v[2]);
+        const int lf_pred = v[1] >= mx ? mx : v[1] <= mn ? mn : sub_w(add_w(v[0], v[2]), v[1]);
+        const bool lf = lane < 2;
+        bucket = lf ? bucket_of_rt(w) : bucket;
+        prediction = lf ? lf_pred : prediction;
+    }
+    // histogram update without a branch: a None node goes to the trash bin, an out-of-alphabet symbol (the reference
+    // would panic, entropy_coding.rs:99) to the counter bin behind the 10 x 1024 table
+    const uint32_t sym = pack_signed(sub_w(value, prediction));
+    const uint32_t bin = !some ? (uint32_t)kHistBins + 1u : sym < 1024u ? bucket * 1024u + sym : (uint32_t)kHistBins;
+    atomicAdd(&s_hist[bin], 1u); // bump_freq, entropy_coding.rs:98-100
+    bucket_out = some ? bucket : 0u; // never written by the reference: stays (0, 0) (wavelet_transform.rs:60-64)
+    pred_out = some ? prediction : 0;
+}
+
 // K2. Persistent workgroups (2 per CU), each walks tiles = 4 x 4 blocks of cells in lattice coordinates. Per tile the 36
 // cells of the block plus its halo ring are staged into LDS as int16 (every coefficient fits; None and missing cells are
 // stored as 0, which is what the reference's unwrap_or(0) yields), so the 6-neighbour gather of
 // ContextModeler::get_neighbour_values (context_modeling.rs:25-77) is an LDS gather: the neighbour of node p sits at
-// (own slot + slot delta) * kSlotStride + 2 * heap, and both are image independent -- each lane keeps the 48 byte offsets
-// of its 8 nodes in registers for the whole kernel. Lane L owns nodes 8L..8L+7 of a cell (wide loads and stores); its
-// level, hence its parameter group (prediction.rs:165-179), is a per-lane constant.
+// (own slot + slot delta) * kSlotStride + 2 * heap, and both are image independent -- each lane keeps the 48 offsets of
+// its 8 nodes in registers (two per VGPR) for the whole kernel. Lane L owns nodes L, L + 64, ..., L + 448 of a cell:
+// neighbouring lanes touch neighbouring halfwords (no structural bank conflict).
 __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(const PredArgs a) {
-    __shared__ uint32_t s_hist[kHistBins];
+    __shared__ uint32_t s_hist[kHistBins + 2]; // + out-of-alphabet counter + trash bin
     __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
     __shared__ int32_t s_slot_cell[kPredSlots];
-    __shared__ unsigned int s_oob;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < kHistBins; i += kPredThreads) s_hist[i] = 0;
-    if (tid == 0) s_oob = 0;
+    for (int i = tid; i < kHistBins + 2; i += kPredThreads) s_hist[i] = 0;
 
-    // neighbour byte offsets relative to the own slot, loop invariant
-    int off[8][6];
+    uint32_t off[8][3]; // neighbour halfword offsets relative to the own slot, loop invariant
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const int p = 8 * lane + i;
+        const int p = lane + 64 * i;
+        uint32_t h[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             const uint32_t e = a.nbr_table[p * 6 + k];
             const int slot = (e >> 9) & 7; // index into {self, +V9[0..5]} = lattice deltas (0,0),(1,0),(1,-1),(0,-1),(-1,0),(-1,1),(0,1)
             const int da = slot == 1 || slot == 2 ? 1 : slot == 4 || slot == 5 ? -1 : 0;
             const int db = slot == 2 || slot == 3 ? -1 : slot == 5 || slot == 6 ? 1 : 0;
-            off[i][k] = (e & 0x8000u) ? 1024 : (da * kPredSide + db) * kSlotStride + 2 * (int)(e & 511u);
+            const int o = (e & 0x8000u) ? 512 : (da * kPredSide + db) * (kSlotStride / 2) + (int)(e & 511u); // 512 = the slot's zero pad
+            h[k] = (uint32_t)o & 0xFFFFu;
         }
-    }
-    // parameter group of this lane's nodes: level 8 (lanes 32..63) -> 0, level 7 (16..31) -> 1, levels 1..6 -> 2
-    const int g = lane >= 32 ? 0 : lane >= 16 ? 1 : 2;
-    float wp[6], vp[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        wp[k] = a.pp.width[g][k];
-        vp[k] = a.pp.value[g][k];
+        off[i][0] = h[0] | (h[1] << 16);
+        off[i][1] = h[2] | (h[3] << 16);
+        off[i][2] = h[4] | (h[5] << 16);
     }
 
     // Tile walk: blocks are dealt round-robin over the 8 XCDs; XCD x gets the contiguous eighth [x n/8, (x+1) n/8) of the
@@ -641,65 +688,28 @@ __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(cons
             const int cell = s_slot_cell[slot];
             if (cell < 0) continue;
             const uint8_t *own = s_cells + slot * kSlotStride;
-            const uint4 mine = *reinterpret_cast<const uint4 *>(own + 16 * lane); // this lane's 8 coefficients
-            const uint32_t mw[4] = {mine.x, mine.y, mine.z, mine.w};
-            uint32_t some = 0xFFu; // bit i: node 8*lane + i is Some
-            if (!a.interior[cell]) some = (a.valid_mask[(size_t)cell * 16 + (lane >> 2)] >> (8 * (lane & 3))) & 0xFFu;
+            // Some/None of this lane's 8 nodes: node lane + 64 i is bit (lane & 31) of mask word 2 i + (lane >> 5)
+            uint32_t some_bits = 0xFFu;
+            if (__builtin_amdgcn_readfirstlane((int)a.interior[cell]) == 0) { // wave-uniform: boundary cell
+                some_bits = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) some_bits |= ((a.valid_mask[(size_t)cell * 16 + 2 * i + (lane >> 5)] >> (lane & 31)) & 1u) << i;
+            }
             uint32_t bk[8];
             int pr[8];
+            predict_node<0>(own, lane, off[0][0], off[0][1], off[0][2], some_bits & 1u, a.pp, s_hist, bk[0], pr[0]);
+            predict_node<1>(own, lane, off[1][0], off[1][1], off[1][2], some_bits & 2u, a.pp, s_hist, bk[1], pr[1]);
+            predict_node<2>(own, lane, off[2][0], off[2][1], off[2][2], some_bits & 4u, a.pp, s_hist, bk[2], pr[2]);
+            predict_node<3>(own, lane, off[3][0], off[3][1], off[3][2], some_bits & 8u, a.pp, s_hist, bk[3], pr[3]);
+            predict_node<4>(own, lane, off[4][0], off[4][1], off[4][2], some_bits & 16u, a.pp, s_hist, bk[4], pr[4]);
+            predict_node<5>(own, lane, off[5][0], off[5][1], off[5][2], some_bits & 32u, a.pp, s_hist, bk[5], pr[5]);
+            predict_node<6>(own, lane, off[6][0], off[6][1], off[6][2], some_bits & 64u, a.pp, s_hist, bk[6], pr[6]);
+            predict_node<7>(own, lane, off[7][0], off[7][1], off[7][2], some_bits & 128u, a.pp, s_hist, bk[7], pr[7]);
+            const size_t base = (size_t)cell * kCell + lane;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const int value = (int)(short)((mw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
-                int v[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) v[k] = *reinterpret_cast<const short *>(own + off[i][k]);
-                // get_hf_context_bucket, prediction.rs:165-206: f32, left to right, one rounding per op. The reference
-                // takes |a - b| on i32 and converts; for these magnitudes |f32(a) - f32(b)| is the same exact value, and
-                // the absolute value then rides on the multiply as a source modifier.
-                float f[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) f[k] = (float)v[k];
-                float width = wp[0];
-                width = __fadd_rn(width, __fmul_rn(wp[1], fabsf(__fsub_rn(f[0], f[3]))));
-                width = __fadd_rn(width, __fmul_rn(wp[2], fabsf(__fsub_rn(f[1], f[2]))));
-                width = __fadd_rn(width, __fmul_rn(wp[3], fabsf(__fsub_rn(f[4], f[5]))));
-                width = __fadd_rn(width, __fmul_rn(wp[4], fabsf(__fsub_rn(f[1], f[5]))));
-                width = __fadd_rn(width, __fmul_rn(wp[5], fabsf(__fsub_rn(f[2], f[4]))));
-                uint32_t bucket = assign_bucket(width);
-                float pf = __fmul_rn(f[0], vp[0]);
-                pf = __fadd_rn(pf, __fmul_rn(f[1], vp[1]));
-                pf = __fadd_rn(pf, __fmul_rn(f[2], vp[2]));
-                pf = __fadd_rn(pf, __fmul_rn(f[3], vp[3]));
-                pf = __fadd_rn(pf, __fmul_rn(f[4], vp[4]));
-                pf = __fadd_rn(pf, __fmul_rn(f[5], vp[5]));
-                int prediction = f32_as_i32(pf);
-                if (i < 2 && lane == 0) { // heap index 0 (DC) and 1 (root): get_lf_context_bucket, prediction.rs:134-144
-                    const uint32_t w = (uint32_t)iabs_w(sub_w(v[0], v[2]));
-                    bucket = bucket_of(w);
-                    const int mx = max(v[0], v[2]), mn = min(v[0], v[2]);
-                    prediction = v[1] >= mx ? mx : v[1] <= mn ? mn : sub_w(add_w(v[0], v[2]), v[1]);
-                }
-                if ((some >> i) & 1u) {
-                    const uint32_t sym = pack_signed(sub_w(value, prediction));
-                    if (sym < 1024u)
-                        atomicAdd(&s_hist[bucket * 1024u + sym], 1u); // bump_freq, entropy_coding.rs:98-100
-                    else
-                        atomicAdd(&s_oob, 1u); // the reference would panic (index out of bounds)
-                } else { // never written by the reference: stays (0, 0) (wavelet_transform.rs:60-64)
-                    bucket = 0;
-                    prediction = 0;
-                }
-                bk[i] = bucket;
-                pr[i] = prediction;
-            }
-            const size_t base = (size_t)cell * kCell + 8 * lane;
-            if (a.bucket)
-                *reinterpret_cast<uint2 *>(a.bucket + base) =
-                    make_uint2(bk[0] | (bk[1] << 8) | (bk[2] << 16) | (bk[3] << 24), bk[4] | (bk[5] << 8) | (bk[6] << 16) | (bk[7] << 24));
-            if (a.prediction) {
-                int4 *dst = reinterpret_cast<int4 *>(a.prediction + base);
-                dst[0] = make_int4(pr[0], pr[1], pr[2], pr[3]);
-                dst[1] = make_int4(pr[4], pr[5], pr[6], pr[7]);
+                if (a.bucket) a.bucket[base + 64 * i] = (uint8_t)bk[i];
+                if (a.prediction) a.prediction[base + 64 * i] = pr[i];
             }
         }
     }
@@ -708,7 +718,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(cons
         const uint32_t c = s_hist[i];
         if (c) atomicAdd(&a.hist[i], c);
     }
-    if (tid == 0 && s_oob) atomicAdd(a.n_oob, (unsigned long long)s_oob);
+    if (tid == 0 && s_hist[kHistBins]) atomicAdd(a.n_oob, (unsigned long long)s_hist[kHistBins]);
 }
 
 // ------------------------------------------------------------------------------------------------
