@@ -573,7 +573,7 @@ struct PredArgs {
 // (prediction.rs:165-179: level 8 -> 0, level 7 -> 1, levels 1..6 -> 2) is too and the parameters stay in SGPRs.
 template <int I>
 __device__ __forceinline__ void predict_node(const uint8_t *own, int lane, uint32_t o01, uint32_t o23, uint32_t o45, bool some, const PredictParams &pp,
-                                             uint32_t *s_hist, uint32_t &bucket_out, int &pred_out) {
+                                             uint32_t *s_hist, uint8_t *bucket_dst, int32_t *pred_dst) {
     constexpr int g = I >= 4 ? 0 : I >= 2 ? 1 : 2;
     const float *wp = pp.width[g], *vp = pp.value[g];
     const int value = *reinterpret_cast<const short *>(own + 2 * (lane + 64 * I));
@@ -616,8 +616,9 @@ __device__ __forceinline__ void predict_node(const uint8_t *own, int lane, uint3
     const uint32_t sym = pack_signed(sub_w(value, prediction));
     const uint32_t bin = !some ? (uint32_t)kHistBins + 1u : sym < 1024u ? bucket * 1024u + sym : (uint32_t)kHistBins;
     atomicAdd(&s_hist[bin], 1u); // bump_freq, entropy_coding.rs:98-100
-    bucket_out = some ? bucket : 0u; // never written by the reference: stays (0, 0) (wavelet_transform.rs:60-64)
-    pred_out = some ? prediction : 0;
+    // a None node is never written by the reference and stays (0, 0) (wavelet_transform.rs:60-64)
+    if (bucket_dst) bucket_dst[64 * I] = (uint8_t)(some ? bucket : 0u);
+    if (pred_dst) pred_dst[64 * I] = some ? prediction : 0;
 }
 
 // K2. Persistent workgroups (2 per CU), each walks tiles = 4 x 4 blocks of cells in lattice coordinates. Per tile the 36
@@ -671,12 +672,14 @@ __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(cons
                 lo = src[0];
                 hi = src[1];
             }
-            auto h = [](int v) -> uint32_t { return v == kNone ? 0u : ((uint32_t)v & 0xFFFFu); }; // .unwrap_or(0)
+            // int32 -> int16 by truncation: every Some coefficient fits, and None (INT32_MIN = 0x80000000) truncates to 0,
+            // which is what the reference's .unwrap_or(0) reads. One v_perm_b32 packs two low halves.
+            auto pk = [](int lo16, int hi16) -> uint32_t { return __builtin_amdgcn_perm((uint32_t)hi16, (uint32_t)lo16, 0x05040100u); };
             uint4 packed;
-            packed.x = h(lo.x) | (h(lo.y) << 16);
-            packed.y = h(lo.z) | (h(lo.w) << 16);
-            packed.z = h(hi.x) | (h(hi.y) << 16);
-            packed.w = h(hi.z) | (h(hi.w) << 16);
+            packed.x = pk(lo.x, lo.y);
+            packed.y = pk(lo.z, lo.w);
+            packed.z = pk(hi.x, hi.y);
+            packed.w = pk(hi.z, hi.w);
             uint8_t *dst = s_cells + slot * kSlotStride;
             *reinterpret_cast<uint4 *>(dst + 16 * lane) = packed;
             if (lane == 0) *reinterpret_cast<uint4 *>(dst + 1024) = make_uint4(0, 0, 0, 0);
@@ -695,22 +698,17 @@ __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(cons
 #pragma unroll
                 for (int i = 0; i < 8; i++) some_bits |= ((a.valid_mask[(size_t)cell * 16 + 2 * i + (lane >> 5)] >> (lane & 31)) & 1u) << i;
             }
-            uint32_t bk[8];
-            int pr[8];
-            predict_node<0>(own, lane, off[0][0], off[0][1], off[0][2], some_bits & 1u, a.pp, s_hist, bk[0], pr[0]);
-            predict_node<1>(own, lane, off[1][0], off[1][1], off[1][2], some_bits & 2u, a.pp, s_hist, bk[1], pr[1]);
-            predict_node<2>(own, lane, off[2][0], off[2][1], off[2][2], some_bits & 4u, a.pp, s_hist, bk[2], pr[2]);
-            predict_node<3>(own, lane, off[3][0], off[3][1], off[3][2], some_bits & 8u, a.pp, s_hist, bk[3], pr[3]);
-            predict_node<4>(own, lane, off[4][0], off[4][1], off[4][2], some_bits & 16u, a.pp, s_hist, bk[4], pr[4]);
-            predict_node<5>(own, lane, off[5][0], off[5][1], off[5][2], some_bits & 32u, a.pp, s_hist, bk[5], pr[5]);
-            predict_node<6>(own, lane, off[6][0], off[6][1], off[6][2], some_bits & 64u, a.pp, s_hist, bk[6], pr[6]);
-            predict_node<7>(own, lane, off[7][0], off[7][1], off[7][2], some_bits & 128u, a.pp, s_hist, bk[7], pr[7]);
             const size_t base = (size_t)cell * kCell + lane;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (a.bucket) a.bucket[base + 64 * i] = (uint8_t)bk[i];
-                if (a.prediction) a.prediction[base + 64 * i] = pr[i];
-            }
+            uint8_t *bd = a.bucket ? a.bucket + base : nullptr;
+            int32_t *pd = a.prediction ? a.prediction + base : nullptr;
+            predict_node<0>(own, lane, off[0][0], off[0][1], off[0][2], some_bits & 1u, a.pp, s_hist, bd, pd);
+            predict_node<1>(own, lane, off[1][0], off[1][1], off[1][2], some_bits & 2u, a.pp, s_hist, bd, pd);
+            predict_node<2>(own, lane, off[2][0], off[2][1], off[2][2], some_bits & 4u, a.pp, s_hist, bd, pd);
+            predict_node<3>(own, lane, off[3][0], off[3][1], off[3][2], some_bits & 8u, a.pp, s_hist, bd, pd);
+            predict_node<4>(own, lane, off[4][0], off[4][1], off[4][2], some_bits & 16u, a.pp, s_hist, bd, pd);
+            predict_node<5>(own, lane, off[5][0], off[5][1], off[5][2], some_bits & 32u, a.pp, s_hist, bd, pd);
+            predict_node<6>(own, lane, off[6][0], off[6][1], off[6][2], some_bits & 64u, a.pp, s_hist, bd, pd);
+            predict_node<7>(own, lane, off[7][0], off[7][1], off[7][2], some_bits & 128u, a.pp, s_hist, bd, pd);
         }
     }
     __syncthreads();
