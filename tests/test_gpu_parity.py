@@ -192,3 +192,62 @@ def test_full_size_4096_properties(ctx, c):
     assert 0 < int(inter.sum()) <= P.num_interior_cells
     assert np.array_equal(a[:, inter, 1:], b[:, inter, 1:])  # differences ignore a constant offset (no None operands)
     assert np.array_equal(a[:, inter, 0] + 20, b[:, inter, 0])  # the DC carries it
+
+
+def test_config3_batch_of_1080p_frames(ctx, oracle):
+    """BASELINE config 3: 256 x 1920x1080 frames through ONE plan. All 256 go through the device batch entry point (one
+    launch, grid.y = images); a sample is checked against the oracle, every frame by the lossless round trip; a handful
+    also go through the host batch entry point (pinned staging + stream overlap)."""
+    import torch
+
+    w, h, c, n = 1920, 1080, 1, 256
+    P = _plan(ctx, w, h, c)
+    assert (P.num_bfs_cells, P.num_cells) == (4317, 4221)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    d_px = torch.randint(0, 256, (n, P.pixel_bytes), dtype=torch.uint8, device="cuda", generator=gen)
+    d_co = torch.empty((n, P.coef_count), dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    P.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=s, n_images=n, pixel_stride=P.pixel_bytes, coef_stride=P.coef_count)
+    d_back = torch.empty(P.pixel_bytes, dtype=torch.uint8, device="cuda")
+    for k in range(n):
+        P.inverse_transform_dev(d_co[k].data_ptr(), d_back.data_ptr(), stream=s)
+        assert torch.equal(d_back, d_px[k]), k
+    for k in (0, 131, 255):
+        want = oracle.Wavelet(d_px[k].cpu().numpy(), h, w, c).coefficients()
+        assert np.array_equal(d_co[k].cpu().numpy().reshape(want.shape), want)
+    imgs = [d_px[k].cpu().numpy() for k in range(5)]
+    for k, got in enumerate(P.transform_quant_batch(imgs)):
+        assert np.array_equal(got.reshape(-1), d_co[k].cpu().numpy())
+
+
+def test_config5_16384_square(ctx):
+    """BASELINE config 5 at full size: 526 369 cells, 269.5 M coefficient slots (1.08 GB of int32: 64-bit offsets),
+    histogram on the device. Checked through size-independent properties."""
+    import torch
+
+    w = h = 16384
+    P = _plan(ctx, w, h, 1)
+    assert (P.num_bfs_cells, P.num_cells, P.num_interior_cells) == (527431, 526369, 522209)  # SURVEY.md section 8 size table
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    d_px = torch.randint(0, 256, (P.pixel_bytes,), dtype=torch.uint8, device="cuda", generator=gen)
+    d_co = torch.empty(P.coef_count, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    P.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=s)
+    co = d_co.view(P.num_cells, 512)
+    valid = torch.from_numpy(P.valid_bits()).cuda()
+    assert torch.equal(co != -(2 ** 31), valid)
+    assert int(co[valid].min()) >= -255 and int(co[valid].max()) <= 255
+    assert int(co[:, 0].min()) >= 0 and int(co[:, 0].max()) <= 255
+    d_back = torch.empty(P.pixel_bytes, dtype=torch.uint8, device="cuda")
+    P.inverse_transform_dev(d_co.data_ptr(), d_back.data_ptr(), stream=s)
+    assert torch.equal(d_back, d_px)  # lossless identity
+    d_b = torch.empty(P.num_cells * 512, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(P.num_cells * 512, dtype=torch.int32, device="cuda")
+    d_h = torch.empty(10 * 1024, dtype=torch.int32, device="cuda")
+    d_o = torch.empty(1, dtype=torch.int64, device="cuda")
+    P.predict_histogram_dev(d_co.data_ptr(), 0, KAT_VALUE_PARAMS, KAT_WIDTH_PARAMS, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    assert int(d_h.sum()) + int(d_o.item()) == P.num_some  # every Some coefficient is counted exactly once
+    assert int(d_b.max()) <= 9
+    # the predictor outputs of None nodes stay (0, 0)
+    assert int(d_b.view(P.num_cells, 512)[~valid].max()) == 0 and int(d_p.view(P.num_cells, 512)[~valid].abs().max()) == 0
