@@ -187,11 +187,15 @@ def main():
         k2_us = timed(lambda: plan.predict_histogram_dev(co0, 0, vp, wp, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=stream))
         k3_us = timed(lambda: plan.inverse_transform_dev(co0, d_back.data_ptr(), stream=stream))
         assert torch.equal(d_back, d_px[0]), "K3(K1(x)) != x"
+        k2_bytes = F * 512 * (4 + 1 + 4) + 10 * 1024 * 4  # coefficient read + bucket + prediction write + histogram
         out["extras"] = {
             "k2_predict_histogram_us": round(k2_us, 2),
             "k2_Mpixels_per_s": round(W * H / k2_us, 1),
+            "k2_algorithmic_GBps": round(k2_bytes / k2_us / 1e3, 1),
             "k3_inverse_us": round(k3_us, 2),
             "k3_Mpixels_per_s": round(W * H / k3_us, 1),
+            "k3_algorithmic_GBps": round(alg_bytes / k3_us / 1e3, 1),
+            "note": "per channel plane; K2 = 6-neighbour gather + bucket/prediction + histogram, K3 = dequant + inverse transform",
         }
 
     if rank == 0:
