@@ -86,7 +86,7 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("FRI_BENCH_FORCE_DIST") == "1":  # the env knob exercises the RCCL path with a single rank
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
