@@ -17,7 +17,8 @@ SYMBOLS = [
     "fri_hip_plan_centers", "fri_hip_plan_valid_mask", "fri_hip_plan_num_some", "fri_hip_plan_neighbour_cells",
     "fri_hip_plan_neighbour_table", "fri_hip_plan_tiling", "fri_hip_plan_tile_table", "fri_hip_transform_quant", "fri_hip_transform_quant_dev",
     "fri_hip_transform_quant_batch_dev", "fri_hip_transform_quant_batch", "fri_hip_predict_histogram",
-    "fri_hip_predict_histogram_dev", "fri_hip_inverse_transform", "fri_hip_inverse_transform_dev",
+    "fri_hip_predict_histogram_dev", "fri_hip_fit_value_sums", "fri_hip_fit_value_sums_dev", "fri_hip_fit_width_sums",
+    "fri_hip_fit_width_sums_dev", "fri_hip_inverse_transform", "fri_hip_inverse_transform_dev",
     "fri_hip_time_transform_quant_dev",
 ]
 
@@ -91,6 +92,10 @@ def load_library():
     L.fri_hip_transform_quant_batch.argtypes = [vp, u32, vp, vp, vp]
     L.fri_hip_predict_histogram.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp]
     L.fri_hip_predict_histogram_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
+    L.fri_hip_fit_value_sums.argtypes = [vp, vp, u32, vp]
+    L.fri_hip_fit_value_sums_dev.argtypes = [vp, vp, u32, vp, vp]
+    L.fri_hip_fit_width_sums.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+    L.fri_hip_fit_width_sums_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     L.fri_hip_inverse_transform.argtypes = [vp, vp, vp, vp]
     L.fri_hip_inverse_transform_dev.argtypes = [vp, vp, vp, vp, vp]
     L.fri_hip_time_transform_quant_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, u32, vp, C.POINTER(C.c_double)]
@@ -106,6 +111,27 @@ def _q(q):
     q = np.ones(32, np.int32) if q is None else np.ascontiguousarray(q, np.int32)
     assert q.size == 32
     return q
+
+
+def _untriangle(tri, n):
+    """[g][n(n+1)/2] upper triangle (row major) -> [g][n][n] symmetric."""
+    out = np.zeros((tri.shape[0], n, n), tri.dtype)
+    iu = np.triu_indices(n)
+    for g in range(tri.shape[0]):
+        out[g][iu] = tri[g]
+        out[g] = out[g] + out[g].T - np.diag(np.diag(out[g]))
+    return out
+
+
+def solve_normal_equations(ata, atb, eps=1e-12):
+    """Minimum-norm least-squares solution from normal equations (what lstsq's SVD returns, up to rounding):
+    x = pinv(A^T A) A^T b via the symmetric eigen-decomposition; eigenvalues <= eps * max are treated as zero."""
+    ata = np.asarray(ata, np.float64)
+    atb = np.asarray(atb, np.float64)
+    lam, vec = np.linalg.eigh(ata)
+    keep = lam > eps * max(lam.max(), 0.0)
+    inv = np.where(keep, 1.0 / np.where(keep, lam, 1.0), 0.0)
+    return (vec * inv) @ (vec.T @ atb)
 
 
 def _check(rc, where, ctx=None):
@@ -241,6 +267,25 @@ class Plan:
         _check(load_library().fri_hip_predict_histogram(self._h, _p(co), channel, _p(vp), _p(wp), _p(bucket), _p(pred), _p(hist), C.addressof(oob)),
                "fri_hip_predict_histogram", self.ctx)
         return bucket, pred, hist, oob.value
+
+    def fit_value_sums(self, coefs, channel):
+        """gram[3][7][7] (full symmetric int64) of u = [v0..v5, value] per layer group."""
+        co = np.ascontiguousarray(coefs, np.int32)
+        assert co.size == self.coef_count
+        tri = np.empty((3, 28), np.int64)
+        _check(load_library().fri_hip_fit_value_sums(self._h, _p(co), channel, _p(tri)), "fri_hip_fit_value_sums", self.ctx)
+        return _untriangle(tri, 7)
+
+    def fit_width_sums(self, coefs, channel, value_params):
+        """(wtw[3][6][6] int64 over the Some rows, wtr[3][6] float64, rows[3])."""
+        co = np.ascontiguousarray(coefs, np.int32)
+        assert co.size == self.coef_count
+        vp = np.ascontiguousarray(value_params, np.float32).reshape(3, 6)
+        tri = np.empty((3, 21), np.int64)
+        wtr = np.empty((3, 6), np.float64)
+        rows = np.empty(3, np.uint64)
+        _check(load_library().fri_hip_fit_width_sums(self._h, _p(co), channel, _p(vp), _p(tri), _p(wtr), _p(rows)), "fri_hip_fit_width_sums", self.ctx)
+        return _untriangle(tri, 6), wtr, rows
 
     def inverse_transform(self, coefs, qmatrix=None):
         co = np.ascontiguousarray(coefs, np.int32)

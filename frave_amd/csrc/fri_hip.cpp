@@ -50,6 +50,8 @@ struct fri_hip_plan {
     int32_t *d_prediction = nullptr;
     uint32_t *d_hist = nullptr;
     unsigned long long *d_oob = nullptr;
+    unsigned long long *d_fit_int = nullptr; // [3][28]
+    double *d_fit_dbl = nullptr;             // [3][6]
     Slot slots[kBatchSlots];
     bool slots_ready = false;
 };
@@ -109,6 +111,8 @@ int ensure_staging(fri_hip_plan *p) {
     if (!p->d_prediction) HIP_TRY(c, hipMalloc((void **)&p->d_prediction, F * kCell * sizeof(int32_t)));
     if (!p->d_hist) HIP_TRY(c, hipMalloc((void **)&p->d_hist, 10 * 1024 * sizeof(uint32_t)));
     if (!p->d_oob) HIP_TRY(c, hipMalloc((void **)&p->d_oob, sizeof(unsigned long long)));
+    if (!p->d_fit_int) HIP_TRY(c, hipMalloc((void **)&p->d_fit_int, 3 * 28 * sizeof(unsigned long long)));
+    if (!p->d_fit_dbl) HIP_TRY(c, hipMalloc((void **)&p->d_fit_dbl, 18 * sizeof(double)));
     return FRI_HIP_OK;
 }
 
@@ -255,7 +259,7 @@ int fri_hip_plan_destroy(fri_hip_plan *p) {
     if (p->ctx) {
         (void)hipSetDevice(p->ctx->device);
         for (void *d : p->owned) (void)hipFree(d);
-        for (void *d : {(void *)p->d_pixels, (void *)p->d_coefs, (void *)p->d_bucket, (void *)p->d_prediction, (void *)p->d_hist, (void *)p->d_oob})
+        for (void *d : {(void *)p->d_pixels, (void *)p->d_coefs, (void *)p->d_bucket, (void *)p->d_prediction, (void *)p->d_hist, (void *)p->d_oob, (void *)p->d_fit_int, (void *)p->d_fit_dbl})
             if (d) (void)hipFree(d);
         for (Slot &s : p->slots) {
             if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -406,6 +410,57 @@ int fri_hip_predict_histogram(fri_hip_plan *p, const int32_t *coefs, uint32_t ch
     unsigned long long oob = 0;
     HIP_TRY(p->ctx, hipMemcpy(&oob, p->d_oob, sizeof(oob), hipMemcpyDeviceToHost));
     if (n_out_of_alphabet) *n_out_of_alphabet = oob;
+    return FRI_HIP_OK;
+}
+
+/* ---- context-model fit sums ----------------------------------------------------------------------- */
+int fri_hip_fit_value_sums_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t channel, int64_t *d_gram, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_coefs || !d_gram || channel >= p->geo.channels) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    PredictParams pp{};
+    const int32_t *plane = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
+    HIP_TRY(p->ctx, launch_fit_accumulate(p->dev, 0, plane, pp, (unsigned long long *)d_gram, nullptr, (hipStream_t)stream));
+    return FRI_HIP_OK;
+}
+
+int fri_hip_fit_width_sums_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t channel, const float value_params[3][6], int64_t *d_wtw, double *d_wtr,
+                               void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_coefs || !value_params || !d_wtw || !d_wtr || channel >= p->geo.channels) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    PredictParams pp{};
+    std::memcpy(pp.value, value_params, sizeof(pp.value));
+    const int32_t *plane = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
+    HIP_TRY(p->ctx, launch_fit_accumulate(p->dev, 1, plane, pp, (unsigned long long *)d_wtw, d_wtr, (hipStream_t)stream));
+    return FRI_HIP_OK;
+}
+
+int fri_hip_fit_value_sums(fri_hip_plan *p, const int32_t *coefs, uint32_t channel, int64_t gram[3][28]) {
+    if (int rc = need_device(p)) return rc;
+    if (!coefs || !gram || channel >= p->geo.channels) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    if (int rc = ensure_staging(p)) return rc;
+    HIP_TRY(p->ctx, hipMemcpy(p->d_coefs, coefs, fri_hip_plan_coef_count(p) * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (int rc = fri_hip_fit_value_sums_dev(p, p->d_coefs, channel, (int64_t *)p->d_fit_int, nullptr)) return rc;
+    HIP_TRY(p->ctx, hipMemcpy(gram, p->d_fit_int, 3 * 28 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return FRI_HIP_OK;
+}
+
+int fri_hip_fit_width_sums(fri_hip_plan *p, const int32_t *coefs, uint32_t channel, const float value_params[3][6], int64_t wtw[3][21], double wtr[3][6],
+                           uint64_t rows[3]) {
+    if (int rc = need_device(p)) return rc;
+    if (!coefs || !value_params || !wtw || !wtr || channel >= p->geo.channels) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    if (int rc = ensure_staging(p)) return rc;
+    HIP_TRY(p->ctx, hipMemcpy(p->d_coefs, coefs, fri_hip_plan_coef_count(p) * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (int rc = fri_hip_fit_width_sums_dev(p, p->d_coefs, channel, value_params, (int64_t *)p->d_fit_int, p->d_fit_dbl, nullptr)) return rc;
+    HIP_TRY(p->ctx, hipMemcpy(wtw, p->d_fit_int, 3 * 21 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(p->ctx, hipMemcpy(wtr, p->d_fit_dbl, 18 * sizeof(double), hipMemcpyDeviceToHost));
+    if (rows) { // num_ctx_last_layer / num_ctx_middle_layer, context_modeling.rs:84-85
+        const uint64_t F = p->geo.centers.size();
+        rows[0] = F * 256;
+        rows[1] = F * 128;
+        rows[2] = F * 128;
+    }
     return FRI_HIP_OK;
 }
 

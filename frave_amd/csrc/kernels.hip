@@ -569,6 +569,68 @@ struct PredArgs {
     PredictParams pp;
 };
 
+// ---- shared by the gather kernels (K2 and the fit accumulators) -----------------------------------------------------
+// Neighbour halfword offsets of node p relative to the own LDS slot, two per register: out[0] = {k0, k1}, out[1] = {k2, k3},
+// out[2] = {k4, k5} (k = left, up_left, up_right, right, down_left, down_right; context_modeling.rs:37-71).
+__device__ __forceinline__ void pred_node_offsets(const uint16_t *nbr_table, int p, uint32_t (&out)[3]) {
+    uint32_t h[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint32_t e = nbr_table[p * 6 + k];
+        const int slot = (e >> 9) & 7; // index into {self, +V9[0..5]} = lattice deltas (0,0),(1,0),(1,-1),(0,-1),(-1,0),(-1,1),(0,1)
+        const int da = slot == 1 || slot == 2 ? 1 : slot == 4 || slot == 5 ? -1 : 0;
+        const int db = slot == 2 || slot == 3 ? -1 : slot == 5 || slot == 6 ? 1 : 0;
+        const int o = (e & 0x8000u) ? 512 : (da * kPredSide + db) * (kSlotStride / 2) + (int)(e & 511u); // 512 = the slot's zero pad
+        h[k] = (uint32_t)o & 0xFFFFu;
+    }
+    out[0] = h[0] | (h[1] << 16);
+    out[1] = h[2] | (h[3] << 16);
+    out[2] = h[4] | (h[5] << 16);
+}
+__device__ __forceinline__ void pred_gather(const uint8_t *own, const uint32_t (&o)[3], int (&v)[6]) {
+    const int h[6] = {(int)(short)(o[0] & 0xFFFFu), (int)o[0] >> 16, (int)(short)(o[1] & 0xFFFFu), (int)o[1] >> 16, (int)(short)(o[2] & 0xFFFFu), (int)o[2] >> 16};
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = *reinterpret_cast<const short *>(own + 2 * h[k]);
+}
+
+// Tile walk: blocks are dealt round-robin over the 8 XCDs; XCD x gets the contiguous eighth [x n/8, (x+1) n/8) of the
+// tiles and its workgroups stride through it together, so concurrently staged tiles are neighbours in the image and
+// their shared halo cells hit in that XCD's L2 (placement only affects speed).
+struct PredTileWalk {
+    uint32_t first, end, step;
+    __device__ explicit PredTileWalk(uint32_t n_tiles) {
+        const uint32_t groups = gridDim.x < 8u ? gridDim.x : 8u; // a grid smaller than 8 blocks: every block is its own group
+        const uint32_t xcd = blockIdx.x % groups, wg_in_xcd = blockIdx.x / groups;
+        step = (gridDim.x - xcd + groups - 1u) / groups;
+        first = (uint32_t)((uint64_t)n_tiles * xcd / groups) + wg_in_xcd;
+        end = (uint32_t)((uint64_t)n_tiles * (xcd + 1u) / groups);
+    }
+};
+
+// Stages the 36 cells of a tile: 64 lanes x 8 coefficients per cell, int32 -> int16 by truncation. Every Some coefficient
+// fits, and None (INT32_MIN = 0x80000000) truncates to 0, which is what the reference's .unwrap_or(0) reads; a slot without
+// a retained cell is all zeros. One v_perm_b32 packs two low halves.
+__device__ __forceinline__ void pred_stage_tile(const int32_t *__restrict__ coefs, const int32_t *s_slot_cell, uint8_t *s_cells, int lane, int wave) {
+    for (int slot = wave; slot < kPredSlots; slot += kPredWaves) {
+        const int cell = s_slot_cell[slot];
+        int4 lo = make_int4(0, 0, 0, 0), hi = lo;
+        if (cell >= 0) {
+            const int4 *src = reinterpret_cast<const int4 *>(coefs + (size_t)cell * kCell + 8 * lane);
+            lo = src[0];
+            hi = src[1];
+        }
+        auto pk = [](int lo16, int hi16) -> uint32_t { return __builtin_amdgcn_perm((uint32_t)hi16, (uint32_t)lo16, 0x05040100u); };
+        uint4 packed;
+        packed.x = pk(lo.x, lo.y);
+        packed.y = pk(lo.z, lo.w);
+        packed.z = pk(hi.x, hi.y);
+        packed.w = pk(hi.z, hi.w);
+        uint8_t *dst = s_cells + slot * kSlotStride;
+        *reinterpret_cast<uint4 *>(dst + 16 * lane) = packed;
+        if (lane == 0) *reinterpret_cast<uint4 *>(dst + 1024) = make_uint4(0, 0, 0, 0);
+    }
+}
+
 // One node of the gather/predict/histogram loop. P_HI = p >> 6 is compile time, so the parameter group
 // (prediction.rs:165-179: level 8 -> 0, level 7 -> 1, levels 1..6 -> 2) is too and the parameters stay in SGPRs.
 template <int I>
@@ -637,53 +699,14 @@ __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(cons
 
     uint32_t off[8][3]; // neighbour halfword offsets relative to the own slot, loop invariant
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int p = lane + 64 * i;
-        uint32_t h[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const uint32_t e = a.nbr_table[p * 6 + k];
-            const int slot = (e >> 9) & 7; // index into {self, +V9[0..5]} = lattice deltas (0,0),(1,0),(1,-1),(0,-1),(-1,0),(-1,1),(0,1)
-            const int da = slot == 1 || slot == 2 ? 1 : slot == 4 || slot == 5 ? -1 : 0;
-            const int db = slot == 2 || slot == 3 ? -1 : slot == 5 || slot == 6 ? 1 : 0;
-            const int o = (e & 0x8000u) ? 512 : (da * kPredSide + db) * (kSlotStride / 2) + (int)(e & 511u); // 512 = the slot's zero pad
-            h[k] = (uint32_t)o & 0xFFFFu;
-        }
-        off[i][0] = h[0] | (h[1] << 16);
-        off[i][1] = h[2] | (h[3] << 16);
-        off[i][2] = h[4] | (h[5] << 16);
-    }
+    for (int i = 0; i < 8; i++) pred_node_offsets(a.nbr_table, lane + 64 * i, off[i]);
 
-    // Tile walk: blocks are dealt round-robin over the 8 XCDs; XCD x gets the contiguous eighth [x n/8, (x+1) n/8) of the
-    // tiles and its workgroups stride through it together, so concurrently staged tiles are neighbours in the image and
-    // their shared halo cells hit in that XCD's L2 (placement only affects speed).
-    const uint32_t groups = gridDim.x < 8u ? gridDim.x : 8u; // a grid smaller than 8 blocks: every block is its own group
-    const uint32_t xcd = blockIdx.x % groups, wg_in_xcd = blockIdx.x / groups, wgs_per_xcd = (gridDim.x - xcd + groups - 1u) / groups;
-    const uint32_t t_begin = (uint32_t)((uint64_t)a.n_tiles * xcd / groups), t_end = (uint32_t)((uint64_t)a.n_tiles * (xcd + 1u) / groups);
-    for (uint32_t tile = t_begin + wg_in_xcd; tile < t_end; tile += wgs_per_xcd) {
+    const PredTileWalk walk(a.n_tiles);
+    for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step) {
         __syncthreads(); // everyone is done with the previous tile's LDS image (and the histogram is zeroed on the first pass)
         if (tid < kPredSlots) s_slot_cell[tid] = a.pred_slots[(size_t)tile * kPredSlots + tid];
         __syncthreads();
-        for (int slot = wave; slot < kPredSlots; slot += kPredWaves) { // stage: 64 lanes x 8 coefficients per cell
-            const int cell = s_slot_cell[slot];
-            int4 lo = make_int4(0, 0, 0, 0), hi = lo;
-            if (cell >= 0) {
-                const int4 *src = reinterpret_cast<const int4 *>(a.coefs + (size_t)cell * kCell + 8 * lane);
-                lo = src[0];
-                hi = src[1];
-            }
-            // int32 -> int16 by truncation: every Some coefficient fits, and None (INT32_MIN = 0x80000000) truncates to 0,
-            // which is what the reference's .unwrap_or(0) reads. One v_perm_b32 packs two low halves.
-            auto pk = [](int lo16, int hi16) -> uint32_t { return __builtin_amdgcn_perm((uint32_t)hi16, (uint32_t)lo16, 0x05040100u); };
-            uint4 packed;
-            packed.x = pk(lo.x, lo.y);
-            packed.y = pk(lo.z, lo.w);
-            packed.z = pk(hi.x, hi.y);
-            packed.w = pk(hi.z, hi.w);
-            uint8_t *dst = s_cells + slot * kSlotStride;
-            *reinterpret_cast<uint4 *>(dst + 16 * lane) = packed;
-            if (lane == 0) *reinterpret_cast<uint4 *>(dst + 1024) = make_uint4(0, 0, 0, 0);
-        }
+        pred_stage_tile(a.coefs, s_slot_cell, s_cells, lane, wave);
         __syncthreads();
 
         for (int r = wave; r < kPredBlock * kPredBlock; r += kPredWaves) { // two block cells per wave
@@ -717,6 +740,133 @@ __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(cons
         if (c) atomicAdd(&a.hist[i], c);
     }
     if (tid == 0 && s_hist[kHistBins]) atomicAdd(a.n_oob, (unsigned long long)s_hist[kHistBins]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fit accumulators: the sums behind ContextModeler::optimize_parameters
+// (context_modeling.rs:79-213), so that the host solves two 6 x 6 systems per layer group instead of running an SVD over
+// n x 6 f32 matrices (n = 8.5 M rows at 4096^2). Same tiles, staging and LDS gather as K2.
+//   MODE 0 (value fit, :175-202): per layer group g, the Gram matrix of u = [v0..v5, value] over the Some nodes of levels
+//           1..8: gram[g][28] (upper triangle, row major) -- A^T A, A^T b and b^T b in exact integers.
+//   MODE 1 (width fit, :144-173): with the value parameters x: r = |f32(value) - f32 prediction| (the same left-to-right f32
+//           evaluation as K2 / nalgebra's gemv), w = [1, |v0-v3|, |v1-v2|, |v4-v5|, |v1-v5|, |v2-v4|]:
+//           wtw[g][21] = sum w w^T (exact integers), wtr[g][6] = sum w r (f64).
+// Lanes are bound to layer groups so that a lane needs one set of accumulators: lanes 0..31 take the level-8 nodes
+// (group 0), 32..47 level 7 (group 1), 48..63 levels 0..6 (group 2; heap index 0, 1 are not part of the fit).
+// ------------------------------------------------------------------------------------------------
+struct FitArgs {
+    const int32_t *coefs;
+    const int32_t *pred_slots;
+    const uint16_t *nbr_table;
+    const uint8_t *interior;
+    const uint32_t *valid_mask;
+    uint32_t n_tiles;
+    PredictParams pp;
+    unsigned long long *gram; // [3][28]   (MODE 0)
+    unsigned long long *wtw;  // [3][21]   (MODE 1)
+    double *wtr;              // [3][6]    (MODE 1)
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const FitArgs a) {
+    constexpr int NI = MODE == 0 ? 28 : 21;
+    __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
+    __shared__ int32_t s_slot_cell[kPredSlots];
+    __shared__ unsigned long long s_int[3][28];
+    __shared__ double s_dbl[3][6];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 3 * 28) (&s_int[0][0])[tid] = 0;
+    if (tid < 18) (&s_dbl[0][0])[tid] = 0.0;
+
+    const int g = lane < 32 ? 0 : lane < 48 ? 1 : 2;
+    const int p0 = lane < 32 ? 256 + lane : lane < 48 ? 128 + (lane - 32) : lane - 48;
+    const int pstep = lane < 32 ? 32 : 16;
+    uint32_t off[8][3];
+#pragma unroll
+    for (int i = 0; i < 8; i++) pred_node_offsets(a.nbr_table, p0 + pstep * i, off[i]);
+    float vp[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) vp[k] = a.pp.value[g][k];
+
+    int acc[NI];
+    double dacc[6];
+#pragma unroll
+    for (int k = 0; k < NI; k++) acc[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) dacc[k] = 0.0;
+    int cells_since_flush = 0;
+    auto flush = [&]() { // per-lane int32 sums -> workgroup int64 sums (sign-extended two's complement adds)
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            atomicAdd(&s_int[g][k], (unsigned long long)(long long)acc[k]);
+            acc[k] = 0;
+        }
+        cells_since_flush = 0;
+    };
+
+    const PredTileWalk walk(a.n_tiles);
+    for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step) {
+        __syncthreads();
+        if (tid < kPredSlots) s_slot_cell[tid] = a.pred_slots[(size_t)tile * kPredSlots + tid];
+        __syncthreads();
+        pred_stage_tile(a.coefs, s_slot_cell, s_cells, lane, wave);
+        __syncthreads();
+        for (int r = wave; r < kPredBlock * kPredBlock; r += kPredWaves) {
+            const int slot = (1 + r / kPredBlock) * kPredSide + 1 + (r % kPredBlock);
+            const int cell = s_slot_cell[slot];
+            if (cell < 0) continue;
+            const uint8_t *own = s_cells + slot * kSlotStride;
+            const bool boundary = __builtin_amdgcn_readfirstlane((int)a.interior[cell]) == 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int p = p0 + pstep * i;
+                bool use = p >= 2; // heap index 0 and 1 are coded by the LF predictor and are not rows of the fit
+                if (boundary) use = use && ((a.valid_mask[(size_t)cell * 16 + (p >> 5)] >> (p & 31)) & 1u);
+                int u[7];
+                int v[6];
+                pred_gather(own, off[i], v);
+                const int value = *reinterpret_cast<const short *>(own + 2 * p);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) u[k] = use ? v[k] : 0; // a None row is all zeros in the reference (:109-134)
+                    u[6] = use ? value : 0;
+                    int n = 0;
+#pragma unroll
+                    for (int r0 = 0; r0 < 7; r0++)
+#pragma unroll
+                        for (int c0 = r0; c0 < 7; c0++) acc[n++] += __mul24(u[r0], u[c0]);
+                } else {
+                    float pf = __fmul_rn((float)v[0], vp[0]);
+#pragma unroll
+                    for (int k = 1; k < 6; k++) pf = __fadd_rn(pf, __fmul_rn((float)v[k], vp[k]));
+                    const float res = fabsf(__fsub_rn((float)value, pf));
+                    int w[6] = {1, iabs_w(v[0] - v[3]), iabs_w(v[1] - v[2]), iabs_w(v[4] - v[5]), iabs_w(v[1] - v[5]), iabs_w(v[2] - v[4])};
+#pragma unroll
+                    for (int k = 0; k < 6; k++) w[k] = use ? w[k] : 0;
+                    int n = 0;
+#pragma unroll
+                    for (int r0 = 0; r0 < 6; r0++)
+#pragma unroll
+                        for (int c0 = r0; c0 < 6; c0++) acc[n++] += __mul24(w[r0], w[c0]);
+                    const double rd = (double)res;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) dacc[k] += (double)w[k] * rd;
+                }
+            }
+            if (++cells_since_flush >= 1024) flush(); // 8 nodes x 255^2 x 1024 cells < 2^31
+        }
+    }
+    flush();
+    if (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) atomicAdd(&s_dbl[g][k], dacc[k]);
+    }
+    __syncthreads();
+    if (tid < 3 * NI) {
+        const int gg = tid / NI, k = tid % NI;
+        atomicAdd((MODE == 0 ? a.gram : a.wtw) + tid, s_int[gg][k]);
+    }
+    if (MODE == 1 && tid < 18) atomicAdd(a.wtr + tid, (&s_dbl[0][0])[tid]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -882,6 +1032,34 @@ hipError_t launch_predict_histogram(const DevicePlan &p, const int32_t *coefs_ch
     uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
     if (!blocks) blocks = 1;
     hipLaunchKernelGGL(predict_histogram_kernel, dim3(blocks), dim3(kPredThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fit_accumulate(const DevicePlan &p, int mode, const int32_t *coefs_channel, const PredictParams &pp, unsigned long long *sums_int,
+                                 double *sums_dbl, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(sums_int, 0, (size_t)3 * (mode == 0 ? 28 : 21) * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    if (mode == 1) {
+        e = hipMemsetAsync(sums_dbl, 0, 18 * sizeof(double), stream);
+        if (e != hipSuccess) return e;
+    }
+    FitArgs a{};
+    a.coefs = coefs_channel;
+    a.pred_slots = p.pred_slots;
+    a.nbr_table = p.nbr_table;
+    a.interior = p.interior;
+    a.valid_mask = p.valid_mask;
+    a.n_tiles = p.n_pred_tiles;
+    a.pp = pp;
+    a.gram = sums_int;
+    a.wtw = sums_int;
+    a.wtr = sums_dbl;
+    uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
+    if (!blocks) blocks = 1;
+    if (mode == 0)
+        hipLaunchKernelGGL(fit_accumulate_kernel<0>, dim3(blocks), dim3(kPredThreads), 0, stream, a);
+    else
+        hipLaunchKernelGGL(fit_accumulate_kernel<1>, dim3(blocks), dim3(kPredThreads), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -50,6 +50,9 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
 // K2: neighbour gather + bucket/prediction + LDS histogram, then the partial-histogram reduction.
 hipError_t launch_predict_histogram(const DevicePlan &p, const int32_t *coefs_channel, const PredictParams &pp, uint8_t *bucket,
                                     int32_t *prediction, uint32_t *hist, unsigned long long *n_oob, hipStream_t stream);
+// Fit accumulators: mode 0 = value fit (sums_int[3][28]), mode 1 = width fit (sums_int[3][21], sums_dbl[3][6]).
+hipError_t launch_fit_accumulate(const DevicePlan &p, int mode, const int32_t *coefs_channel, const PredictParams &pp, unsigned long long *sums_int,
+                                 double *sums_dbl, hipStream_t stream);
 // K3: (reference-faithful) dequantisation + inverse transform + clamp.
 hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, const QMatrix &q, uint8_t *pixels, hipStream_t stream);
 

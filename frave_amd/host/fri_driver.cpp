@@ -55,7 +55,8 @@ int main(int argc, char **argv) {
             return 1;
         }
         const bool same = dec.value.data == img;
-        std::printf("cells=%u hist_total_ch0=%llu lossless=%s\n", enc.value.image.num_cells, (unsigned long long)total, same ? "yes" : "NO");
+        std::printf("cells=%u hist_total_ch0=%llu lossless=%s (parameters fitted on the device sums)\n", enc.value.image.num_cells, (unsigned long long)total,
+                    same ? "yes" : "NO");
         return same ? 0 : 1;
     }
     if (cmd == "batch") {

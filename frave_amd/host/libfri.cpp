@@ -1,6 +1,7 @@
 // libfri.cpp -- see libfri.hpp. Host glue over the C ABI; no compute here.
 #include "libfri.hpp"
 
+#include <cmath>
 #include <utility>
 
 namespace libfri {
@@ -37,6 +38,101 @@ fri_hip_plan *Device::plan(uint32_t width, uint32_t height, uint32_t channels, s
     }
     plans_[key] = p;
     return p;
+}
+
+std::array<double, 6> ContextModeler::solve_normal_equations(const double (&m)[6][6], const double (&y)[6]) {
+    // cyclic Jacobi: a = V diag(lam) V^T
+    double a[6][6], v[6][6];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            a[i][j] = m[i][j];
+            v[i][j] = i == j ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i + 1; j < 6; j++) off += a[i][j] * a[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 6; p++)
+            for (int q = p + 1; q < 6; q++) {
+                if (std::fabs(a[p][q]) < 1e-300) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 6; k++) {
+                    const double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - s * akq;
+                    a[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 6; k++) {
+                    const double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - s * aqk;
+                    a[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 6; k++) {
+                    const double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = c * vkp - s * vkq;
+                    v[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    double lmax = 0.0;
+    for (int i = 0; i < 6; i++) lmax = std::fmax(lmax, a[i][i]);
+    std::array<double, 6> x{};
+    for (int i = 0; i < 6; i++) {
+        if (!(a[i][i] > 1e-12 * lmax)) continue; // rank-deficient direction: minimum-norm solution leaves it at 0
+        double proj = 0.0;
+        for (int k = 0; k < 6; k++) proj += v[k][i] * y[k];
+        for (int k = 0; k < 6; k++) x[k] += v[k][i] * proj / a[i][i];
+    }
+    return x;
+}
+
+Result<bool> ContextModeler::optimize_parameters(const WaveletImage &image, uint32_t channel, Device &dev) {
+    Result<bool> r;
+    const uint32_t c = num_channels(image.metadata.colorspace);
+    fri_hip_plan *plan = dev.plan(image.metadata.width, image.metadata.height, c, r.error);
+    if (!plan) return r;
+    auto at = [](int i, int j, int n) { // index into the upper triangle (row major)
+        if (i > j) std::swap(i, j);
+        return i * n - i * (i - 1) / 2 + (j - i);
+    };
+    int64_t gram[3][28];
+    int rc = fri_hip_fit_value_sums(plan, image.coefficients.data(), channel, gram);
+    if (rc != FRI_HIP_OK) {
+        r.error = dev.describe(rc);
+        return r;
+    }
+    float vp[3][6];
+    for (int g = 0; g < 3; g++) { // optimize_value_prediction, context_modeling.rs:175-202
+        double m[6][6], y[6];
+        for (int i = 0; i < 6; i++) {
+            y[i] = (double)gram[g][at(i, 6, 7)];
+            for (int j = 0; j < 6; j++) m[i][j] = (double)gram[g][at(i, j, 7)];
+        }
+        const auto x = solve_normal_equations(m, y);
+        for (int k = 0; k < 6; k++) value_predictors[channel][g][k] = vp[g][k] = (float)x[k];
+    }
+    int64_t wtw[3][21];
+    double wtr[3][6];
+    uint64_t rows[3];
+    rc = fri_hip_fit_width_sums(plan, image.coefficients.data(), channel, vp, wtw, wtr, rows);
+    if (rc != FRI_HIP_OK) {
+        r.error = dev.describe(rc);
+        return r;
+    }
+    for (int g = 0; g < 3; g++) { // optimize_width_prediction, context_modeling.rs:144-173
+        double m[6][6], y[6];
+        for (int i = 0; i < 6; i++) {
+            y[i] = wtr[g][i];
+            for (int j = 0; j < 6; j++) m[i][j] = (double)wtw[g][at(i, j, 6)];
+        }
+        m[0][0] += (double)rows[g] - (double)wtw[g][0]; // the reference's all-zero rows: constant feature 1, residual 0
+        const auto x = solve_normal_equations(m, y);
+        for (int k = 0; k < 6; k++) width_predictors[channel][g][k] = (float)x[k];
+    }
+    r.ok = r.value = true;
+    return r;
 }
 
 namespace stages {
@@ -103,14 +199,24 @@ Result<WaveletImage> encode(WaveletImage image) {
 } // namespace quantization
 
 namespace prediction {
-Result<std::array<std::vector<AnsContext>, 3>> encode(WaveletImage &image, const EncoderOpts &opts, Device &dev) {
+Result<std::array<std::vector<AnsContext>, 3>> encode(WaveletImage &image, EncoderOpts &opts, Device &dev) {
     Result<std::array<std::vector<AnsContext>, 3>> r;
+    ContextModeler ctx_mod;
     const uint32_t c = num_channels(image.metadata.colorspace);
     fri_hip_plan *plan = dev.plan(image.metadata.width, image.metadata.height, c, r.error);
     if (!plan) return r;
     const size_t n = (size_t)image.num_cells * FRI_HIP_CELL_SIZE;
     std::vector<uint32_t> hist((size_t)CONTEXT_AMOUNT * ALPHABET_SIZE);
     for (uint32_t ch = 0; ch < c; ch++) {
+        if (opts.fit_parameters) { // prediction.rs:232-235
+            auto fit = ctx_mod.optimize_parameters(image, ch, dev);
+            if (!fit.ok) {
+                r.error = fit.error;
+                return r;
+            }
+            opts.value_prediction_params[ch] = ctx_mod.value_predictors[ch];
+            opts.width_prediction_params[ch] = ctx_mod.width_predictors[ch];
+        }
         image.bucket[ch].resize(n);
         image.prediction[ch].resize(n);
         uint64_t oob = 0;

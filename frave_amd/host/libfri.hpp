@@ -48,6 +48,7 @@ struct EncoderOpts { // encoder.rs:58-64
     std::array<PredictionParams, 3> value_prediction_params{}; // per channel; an INPUT here (the SVD fit stays on the host)
     std::array<PredictionParams, 3> width_prediction_params{};
     std::array<int32_t, 32> quantization_matrix;               // get_quantization_matrix(), quantization.rs:3-5
+    bool fit_parameters = true; // like the reference (prediction.rs:232-235); false = use the parameters given above
     int device = 0;
     EncoderOpts() { quantization_matrix.fill(1); }
 };
@@ -88,6 +89,18 @@ class Device {
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, fri_hip_plan *> plans_;
 };
 
+// ContextModeler (context_modeling.rs:13-213): the least-squares fit of the value / width predictors. The device
+// accumulates the normal-equation sums (fri_hip_fit_value_sums / fri_hip_fit_width_sums); this class solves the 6 x 6
+// systems (minimum-norm solution via a Jacobi eigen-decomposition, the counterpart of lstsq's SVD with its 1e-14 cut-off).
+struct ContextModeler {
+    std::array<PredictionParams, 3> value_predictors{};
+    std::array<PredictionParams, 3> width_predictors{};
+    // optimize_parameters(&wavelet_image, channel), context_modeling.rs:204-213
+    Result<bool> optimize_parameters(const WaveletImage &image, uint32_t channel, Device &dev);
+    // x = pinv(M) y for a symmetric positive semi-definite 6 x 6 matrix
+    static std::array<double, 6> solve_normal_equations(const double (&m)[6][6], const double (&y)[6]);
+};
+
 namespace stages {
 namespace wavelet_transform {
 Result<WaveletImage> encode(const RasterImage &raster, const EncoderOpts &opts, Device &dev); // + fused quantiser, see quantization::encode
@@ -98,7 +111,7 @@ namespace quantization {
 Result<WaveletImage> encode(WaveletImage image);
 } // namespace quantization
 namespace prediction {
-Result<std::array<std::vector<AnsContext>, 3>> encode(WaveletImage &image, const EncoderOpts &opts, Device &dev);
+Result<std::array<std::vector<AnsContext>, 3>> encode(WaveletImage &image, EncoderOpts &opts, Device &dev); // fits opts.*_prediction_params first
 } // namespace prediction
 } // namespace stages
 

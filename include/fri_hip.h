@@ -135,6 +135,28 @@ int fri_hip_predict_histogram_dev(fri_hip_plan *plan, const int32_t *d_coefs, ui
                                   const float width_params[3][6], uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist,
                                   uint64_t *d_n_out_of_alphabet, void *stream);
 
+/* ---- context-model fit: normal-equation sums ------------------ */
+/* The reference fits the 3 x 6 value and 3 x 6 width parameters of a channel by building n x 6 f32 design matrices
+ * (ContextModeler::get_image_neighbour_matrices, context_modeling.rs:79-142) and running an SVD least squares on them
+ * (lstsq, :168, :185). These entry points return the sums from which the same least-squares problems are solved as 6 x 6
+ * systems on the host; the fitted parameters are transmitted in the file, so any solution gives a decodable stream
+ * (the SVD's exact f32 output is third-party arithmetic: parity unpinned).
+ * Layer groups g: 0 = level 8, 1 = level 7, 2 = levels 1..6 (matrices[0..2], :87-96). Rows exist for Some coefficients of
+ * heap index >= 2 only; None rows are all zero in the reference (:109-134).
+ * gram[g][28] = upper triangle (row major) of sum u u^T with u = [v0..v5, value], v = get_neighbour_values:
+ *              A^T A = rows/columns 0..5, A^T b = column 6, b^T b = entry (6,6). Exact integers. */
+int fri_hip_fit_value_sums(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, int64_t gram[3][28]);
+int fri_hip_fit_value_sums_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint32_t channel, int64_t *d_gram, void *stream);
+/* Width fit (optimize_width_prediction, :144-173) for given value parameters x: residual r = |f32(value) - A x| in f32
+ * (left to right like nalgebra's gemv), features w = [1, |v0-v3|, |v1-v2|, |v4-v5|, |v1-v5|, |v2-v4|].
+ * wtw[g][21] = upper triangle of sum w w^T over the Some rows (exact), wtr[g][6] = sum w r (f64; summation order is not
+ * fixed, so the last bits may vary between runs). rows[g] = height of the reference's matrix (F*256, F*128, F*128): its
+ * all-zero rows still carry the constant feature 1 with residual 0, so add rows[g] - wtw[g][0] to entry (0,0). */
+int fri_hip_fit_width_sums(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, const float value_params[3][6], int64_t wtw[3][21],
+                           double wtr[3][6], uint64_t rows[3]);
+int fri_hip_fit_width_sums_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint32_t channel, const float value_params[3][6], int64_t *d_wtw,
+                               double *d_wtr, void *stream);
+
 /* ---- inverse: dequantisation + inverse transform (decode side) ------------------------------ */
 /* Replaces quantization::decode (stages/quantization.rs:27-45) + wavelet_transform::decode
  * (stages/wavelet_transform.rs:715-717: RasterImage::from_wavelet :308-356, extract_values

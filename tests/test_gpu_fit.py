@@ -1,0 +1,115 @@
+"""Fit accumulators against sums computed on the CPU from the oracle's restatement of
+ContextModeler::get_neighbour_values (context_modeling.rs:25-77). Integer sums are bit-exact; the f64 residual sums are
+compared with a tolerance (summation order is not fixed on the device)."""
+import numpy as np
+import pytest
+
+from tests.common import gen_image, random_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import frave_amd
+
+    c = frave_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _groups():
+    p = np.arange(512)
+    level = np.floor(np.log2(np.maximum(p, 1))).astype(int)
+    g = np.where(level == 8, 0, np.where(level == 7, 1, 2))
+    return g, p >= 2
+
+
+def _cpu_sums(oracle, W, ch, value_params):
+    co = W.coefficients()[ch].astype(np.int64)  # [F][512]
+    some = co != oracle.NONE
+    nv = W.neighbour_values(ch).astype(np.int64)  # [F][512][6]
+    g, fit_row = _groups()
+    use = some & fit_row[None, :]
+    gram = np.zeros((3, 7, 7), np.int64)
+    wtw = np.zeros((3, 6, 6), np.int64)
+    wtr = np.zeros((3, 6), np.float64)
+    vp = np.asarray(value_params, np.float32)
+    for grp in range(3):
+        m = use & (g == grp)[None, :]
+        v = nv[m]  # [n][6]
+        val = co[m]
+        u = np.concatenate([v, val[:, None]], axis=1)
+        gram[grp] = u.T @ u
+        # f32 prediction, left to right, one rounding per op (prediction.rs:199-204 / nalgebra gemv)
+        vf = v.astype(np.float32)
+        pf = vf[:, 0] * vp[grp, 0]
+        for k in range(1, 6):
+            pf = (pf + vf[:, k] * vp[grp, k]).astype(np.float32)
+        res = np.abs(val.astype(np.float32) - pf).astype(np.float32)
+        w = np.stack([np.ones(len(v), np.int64), np.abs(v[:, 0] - v[:, 3]), np.abs(v[:, 1] - v[:, 2]), np.abs(v[:, 4] - v[:, 5]), np.abs(v[:, 1] - v[:, 5]),
+                      np.abs(v[:, 2] - v[:, 4])], axis=1)
+        wtw[grp] = w.T @ w
+        wtr[grp] = (w.astype(np.float64) * res.astype(np.float64)[:, None]).sum(0)
+    return gram, wtw, wtr
+
+
+@pytest.mark.parametrize("shape", [(10, 10, 3), (100, 37, 3), (300, 200, 1), (512, 512, 3)])
+@pytest.mark.parametrize("kind", ["noise", "smooth"])
+def test_fit_sums_match_cpu(ctx, oracle, shape, kind):
+    import frave_amd
+
+    w, h, c = shape
+    img = gen_image(kind, w, h, c, 21)
+    P = frave_amd.Plan(ctx, w, h, c)
+    W = oracle.Wavelet(img, h, w, c)
+    co = P.transform_quant(img)
+    for ch in range(c):
+        vp, _ = random_params(3 + ch, scale=0.2)
+        want_gram, want_wtw, want_wtr = _cpu_sums(oracle, W, ch, vp)
+        gram = P.fit_value_sums(co, ch)
+        assert np.array_equal(gram, want_gram)
+        wtw, wtr, rows = P.fit_width_sums(co, ch, vp)
+        assert np.array_equal(wtw, want_wtw)
+        assert np.allclose(wtr, want_wtr, rtol=1e-10, atol=1e-6)
+        assert rows.tolist() == [P.num_cells * 256, P.num_cells * 128, P.num_cells * 128]
+
+
+def test_fitted_parameters_reduce_the_residual(ctx, oracle):
+    """Solve the two 6 x 6 systems on the host and use the result: it must be the least-squares optimum (no worse than
+    numpy's lstsq on the explicit design matrix), and K2 must run with it."""
+    import frave_amd
+    from frave_amd.api import solve_normal_equations
+
+    w, h, c = 640, 360, 1
+    img = gen_image("smooth", w, h, c, 8)
+    P = frave_amd.Plan(ctx, w, h, c)
+    W = oracle.Wavelet(img, h, w, c)
+    co = P.transform_quant(img)
+    gram = P.fit_value_sums(co, 0)
+    vp = np.stack([solve_normal_equations(gram[g][:6, :6], gram[g][:6, 6]) for g in range(3)]).astype(np.float32)
+    # reference route: explicit design matrix + lstsq (float64)
+    cov = W.coefficients()[0].astype(np.float64)
+    some = cov != oracle.NONE
+    nv = W.neighbour_values(0).astype(np.float64)
+    g, fit_row = _groups()
+    for grp in range(3):
+        m = some & (fit_row & (g == grp))[None, :]
+        A, b = nv[m], cov[m]
+        x_ref = np.linalg.lstsq(A, b, rcond=None)[0]
+        r_ref = np.linalg.norm(A @ x_ref - b)
+        r_got = np.linalg.norm(A @ vp[grp].astype(np.float64) - b)
+        assert r_got <= r_ref * (1 + 1e-5)
+        assert np.allclose(vp[grp], x_ref, rtol=1e-3, atol=1e-4)
+    wtw, wtr, rows = P.fit_width_sums(co, 0, vp)
+    wp = []
+    for grp in range(3):
+        H = wtw[grp].astype(np.float64)
+        H[0, 0] += float(rows[grp]) - float(wtw[grp][0, 0])  # the reference's all-zero rows: feature 1, residual 0
+        wp.append(solve_normal_equations(H, wtr[grp]))
+    wp = np.stack(wp).astype(np.float32)
+    assert np.isfinite(wp).all()
+    b_, p_, hist, oob = P.predict_histogram(co, 0, vp, wp)
+    W.quantize(np.ones(32, np.int32))
+    wb, wpred, whist, woob = W.predict(0, vp, wp)
+    assert np.array_equal(hist, whist) and np.array_equal(b_, wb) and np.array_equal(p_, wpred) and oob == woob
