@@ -307,6 +307,13 @@ class Plan:
         _check(load_library().fri_hip_predict_histogram_dev(self._h, d_coefs, channel, _p(vp), _p(wp), d_bucket, d_prediction, d_hist, d_oob, stream),
                "fri_hip_predict_histogram_dev", self.ctx)
 
+    def fit_value_sums_dev(self, d_coefs, channel, d_gram, stream=0):
+        _check(load_library().fri_hip_fit_value_sums_dev(self._h, d_coefs, channel, d_gram, stream), "fri_hip_fit_value_sums_dev", self.ctx)
+
+    def fit_width_sums_dev(self, d_coefs, channel, value_params, d_wtw, d_wtr, stream=0):
+        vp = np.ascontiguousarray(value_params, np.float32).reshape(3, 6)
+        _check(load_library().fri_hip_fit_width_sums_dev(self._h, d_coefs, channel, _p(vp), d_wtw, d_wtr, stream), "fri_hip_fit_width_sums_dev", self.ctx)
+
     def inverse_transform_dev(self, d_coefs, d_pixels, qmatrix=None, stream=0):
         q = _q(qmatrix)
         _check(load_library().fri_hip_inverse_transform_dev(self._h, d_coefs, _p(q), d_pixels, stream), "fri_hip_inverse_transform_dev", self.ctx)

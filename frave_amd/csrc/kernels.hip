@@ -781,9 +781,18 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
     const int g = lane < 32 ? 0 : lane < 48 ? 1 : 2;
     const int p0 = lane < 32 ? 256 + lane : lane < 48 ? 128 + (lane - 32) : lane - 48;
     const int pstep = lane < 32 ? 32 : 16;
-    uint32_t off[8][3];
-#pragma unroll
-    for (int i = 0; i < 8; i++) pred_node_offsets(a.nbr_table, p0 + pstep * i, off[i]);
+    // The neighbour offsets of a lane's 8 nodes live in LDS here (not in registers as in K2): together with 21-28 accumulators
+    // they would not fit 128 VGPRs, and this kernel is not on the critical path. The map is per lane, identical in all waves.
+    __shared__ uint32_t s_off[8][64][3];
+    if (wave == 0) {
+        for (int i = 0; i < 8; i++) {
+            uint32_t o[3];
+            pred_node_offsets(a.nbr_table, p0 + pstep * i, o);
+            s_off[i][lane][0] = o[0];
+            s_off[i][lane][1] = o[1];
+            s_off[i][lane][2] = o[2];
+        }
+    }
     float vp[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) vp[k] = a.pp.value[g][k];
@@ -817,14 +826,15 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
             if (cell < 0) continue;
             const uint8_t *own = s_cells + slot * kSlotStride;
             const bool boundary = __builtin_amdgcn_readfirstlane((int)a.interior[cell]) == 0;
-#pragma unroll
+#pragma unroll 1
             for (int i = 0; i < 8; i++) {
                 const int p = p0 + pstep * i;
                 bool use = p >= 2; // heap index 0 and 1 are coded by the LF predictor and are not rows of the fit
                 if (boundary) use = use && ((a.valid_mask[(size_t)cell * 16 + (p >> 5)] >> (p & 31)) & 1u);
                 int u[7];
                 int v[6];
-                pred_gather(own, off[i], v);
+                const uint32_t off_i[3] = {s_off[i][lane][0], s_off[i][lane][1], s_off[i][lane][2]};
+                pred_gather(own, off_i, v);
                 const int value = *reinterpret_cast<const short *>(own + 2 * p);
                 if (MODE == 0) {
 #pragma unroll
