@@ -82,11 +82,15 @@ class Wavelet:
             raise ValueError("fri_oracle_from_raster failed")
 
     def close(self):
-        if self._h:
-            lib().fri_oracle_free(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.fri_oracle_free(self._h)
+        self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
     @property
     def num_cells(self):

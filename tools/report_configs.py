@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Runs the five BASELINE.json configs on one MI355X and prints a report: kernel-only Mpixels/s and
+algorithmic GB/s per kernel, fraction of the 8 TB/s HBM roofline, CPU-oracle Mpixels/s where it is run, parity verdicts.
+    python tools/report_configs.py [--quick]
+"""
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import frave_amd
+from oracle import fri_oracle as O
+from tests.common import KAT_VALUE_PARAMS, KAT_WIDTH_PARAMS, gen_image
+
+QUICK = "--quick" in sys.argv
+PEAK = 8000.0
+ctx = frave_amd.Context(0)
+s = torch.cuda.current_stream().cuda_stream
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps * 1e3  # us
+
+
+def line(name, us, pixels, nbytes):
+    gbs = nbytes / us / 1e3
+    print(f"    {name:34s} {us:10.2f} us  {pixels / us:12.1f} Mpix/s  {gbs:8.1f} GB/s algorithmic  {gbs / PEAK * 100:5.1f} % of 8 TB/s")
+
+
+def kernels(w, h, c, slots, label):
+    P = frave_amd.Plan(ctx, w, h, c)
+    F = P.num_cells
+    print(f"  {label}: {w}x{h}x{c}, F={F} cells, tiling {P.tiling()}")
+    d_px = torch.randint(0, 256, (slots, P.pixel_bytes), dtype=torch.uint8, device="cuda")
+    d_co = torch.empty((slots, P.coef_count), dtype=torch.int32, device="cuda")
+    k1 = P.time_transform_quant_dev(slots, d_px.data_ptr(), P.pixel_bytes, d_co.data_ptr(), P.coef_count, 20, stream=s)
+    k1 = P.time_transform_quant_dev(slots, d_px.data_ptr(), P.pixel_bytes, d_co.data_ptr(), P.coef_count, 100 if w * h < 1e8 else 20, stream=s)
+    alg1 = P.pixel_bytes + P.coef_count * 4
+    line("K1 transform+quant (all channels)", k1, w * h, alg1)
+    d_b = torch.empty(F * 512, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(F * 512, dtype=torch.int32, device="cuda")
+    d_h = torch.empty(10 * 1024, dtype=torch.int32, device="cuda")
+    d_o = torch.empty(1, dtype=torch.int64, device="cuda")
+    d_back = torch.empty(P.pixel_bytes, dtype=torch.uint8, device="cuda")
+    k2 = timed(lambda: P.predict_histogram_dev(d_co[0].data_ptr(), 0, KAT_VALUE_PARAMS, KAT_WIDTH_PARAMS, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=s), 10)
+    line("K2 predict+histogram (per channel)", k2, w * h, F * 512 * 9 + 40960)
+    k3 = timed(lambda: P.inverse_transform_dev(d_co[0].data_ptr(), d_back.data_ptr(), stream=s), 10)
+    line("K3 inverse (all channels)", k3, w * h, alg1)
+    ok = bool(torch.equal(d_back, d_px[0]))
+    tot = int(d_h.sum()) + int(d_o.item())
+    print(f"    lossless K3(K1(x)) == x: {ok};  histogram total {tot} == Some coefficients {P.num_some}: {tot == P.num_some}")
+    return P, d_px, d_co
+
+
+print("== config 1: 512x512 plumbing (CPU oracle round trip; GPU parity) ==")
+g = gen_image("smooth", 512, 512, 1, 1)
+t0 = time.perf_counter()
+W1 = O.Wavelet(g, 512, 512, 1)
+W3 = O.Wavelet(np.repeat(g, 3, axis=2), 512, 512, 3)
+dt = time.perf_counter() - t0
+print(f"  oracle: luma round trip lossless {np.array_equal(W1.to_raster(), g.reshape(-1))}; RGB(R=G=B) channel 0 == luma {np.array_equal(W1.coefficients()[0], W3.coefficients()[0])}; "
+      f"F={W1.num_cells} (BFS {W1.num_bfs_cells}); {dt:.2f} s for both")
+P = frave_amd.Plan(ctx, 512, 512, 1)
+print(f"  GPU == oracle, bit for bit: {np.array_equal(P.transform_quant(g), W1.coefficients())}")
+
+print("== config 2: single 4096x4096 on 1 MI355X ==")
+for c in (1, 3):
+    P, d_px, d_co = kernels(4096, 4096, c, 8 if c == 1 else 3, f"C={c}")
+    if not QUICK:
+        img = d_px[0].cpu().numpy()
+        t0 = time.perf_counter()
+        W = O.Wavelet(img, 4096, 4096, c)
+        dt = time.perf_counter() - t0
+        P.transform_quant_dev(d_px[0].data_ptr(), d_co[0].data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        same = np.array_equal(d_co[0].cpu().numpy().reshape(c, P.num_cells, 512), W.coefficients())
+        print(f"    CPU oracle transform: {dt:.1f} s = {4096 * 4096 / dt / 1e6:.2f} Mpix/s (1 thread);  GPU == oracle bit for bit: {same}")
+        W.close()
+    del d_px, d_co
+
+print("== config 3: 256 x 1920x1080 on 1 MI355X ==")
+P = frave_amd.Plan(ctx, 1920, 1080, 1)
+n = 256
+d_px = torch.randint(0, 256, (n, P.pixel_bytes), dtype=torch.uint8, device="cuda")
+d_co = torch.empty((n, P.coef_count), dtype=torch.int32, device="cuda")
+us = timed(lambda: P.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=s, n_images=n, pixel_stride=P.pixel_bytes, coef_stride=P.coef_count), 5)
+line(f"K1, one launch over {n} frames", us, n * 1920 * 1080, n * (P.pixel_bytes + P.coef_count * 4))
+del d_px, d_co
+drv = os.path.join(ROOT, "frave_amd", "host", "fri_driver")
+if os.path.exists(drv):
+    print("   ", subprocess.run([drv, "batch", "1920", "1080", "1", "256"], capture_output=True, text=True).stdout.strip())
+
+print("== config 4: 1024 x 4096x4096 over 8 GPUs -> this GPU's share is 128 images (image i -> rank i mod 8, no collective) ==")
+P = frave_amd.Plan(ctx, 4096, 4096, 1)
+n = 32
+d_px = torch.randint(0, 256, (n, P.pixel_bytes), dtype=torch.uint8, device="cuda")
+d_co = torch.empty((n, P.coef_count), dtype=torch.int32, device="cuda")
+
+
+def share():
+    for _ in range(4):  # 4 launches x 32 images = 128
+        P.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=s, n_images=n, pixel_stride=P.pixel_bytes, coef_stride=P.coef_count)
+
+
+us = timed(share, 3)
+line("K1, 128 images as 4 launches of 32", us, 128 * 4096 * 4096, 128 * (P.pixel_bytes + P.coef_count * 4))
+del d_px, d_co
+
+print("== config 5: single 16384x16384, histogram on the device ==")
+kernels(16384, 16384, 1, 1, "C=1")
