@@ -251,3 +251,40 @@ def test_config5_16384_square(ctx):
     assert int(d_b.max()) <= 9
     # the predictor outputs of None nodes stay (0, 0)
     assert int(d_b.view(P.num_cells, 512)[~valid].max()) == 0 and int(d_p.view(P.num_cells, 512)[~valid].abs().max()) == 0
+
+
+@pytest.mark.parametrize("shape", [(12, 4, 1), (20, 8, 3), (100, 64, 1), (52, 40, 3)])
+def test_row_stride_not_multiple_of_16(ctx, oracle, shape):
+    """width * channels is not a multiple of 16 but the image size is: the generic (neither FAST nor EDGE) staging variant."""
+    w, h, c = shape
+    assert (w * c) % 16 and (w * h * c) % 16 == 0
+    img = gen_image("noise", w, h, c, 77)
+    P = _plan(ctx, w, h, c)
+    assert np.array_equal(P.transform_quant(img), oracle.Wavelet(img, h, w, c).coefficients())
+
+
+@pytest.mark.parametrize("offset", [1, 3, 8, 15])
+@pytest.mark.parametrize("shape", [(640, 360, 1), (101, 67, 3)])
+def test_unaligned_device_pointers(ctx, oracle, shape, offset):
+    """Image buffers that do not start on a 16-byte boundary (and sit between other data): the EDGE variant must neither read
+    outside the caller's buffer nor produce different coefficients."""
+    import torch
+
+    w, h, c = shape
+    P = _plan(ctx, w, h, c)
+    img = gen_image("noise", w, h, c, offset)
+    guard = 64
+    host = np.full(guard + offset + P.pixel_bytes + guard, 0xA5, np.uint8)
+    host[guard + offset: guard + offset + P.pixel_bytes] = img.reshape(-1)
+    d_buf = torch.from_numpy(host).cuda()
+    d_co = torch.empty(P.coef_count, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    P.transform_quant_dev(d_buf.data_ptr() + guard + offset, d_co.data_ptr(), stream=s)
+    want = oracle.Wavelet(img, h, w, c).coefficients()
+    assert np.array_equal(d_co.cpu().numpy().reshape(want.shape), want)
+    # and the inverse writes only inside its buffer
+    d_out = torch.full((guard + offset + P.pixel_bytes + guard,), 0x5A, dtype=torch.uint8, device="cuda")
+    P.inverse_transform_dev(d_co.data_ptr(), d_out.data_ptr() + guard + offset, stream=s)
+    out = d_out.cpu().numpy()
+    assert np.array_equal(out[guard + offset: guard + offset + P.pixel_bytes], img.reshape(-1))
+    assert (out[:guard + offset] == 0x5A).all() and (out[guard + offset + P.pixel_bytes:] == 0x5A).all()
