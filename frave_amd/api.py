@@ -6,7 +6,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libfri_hip.so")
+# FRI_HIP_LIBRARY: path of an alternative build of the same library (kernel experiments); default = the in-tree build
+_SO = os.environ.get("FRI_HIP_LIBRARY") or os.path.join(_HERE, "libfri_hip.so")
 NONE = -(2 ** 31)
 
 # every symbol include/fri_hip.h declares (tests/test_abi_symbols.py checks the header against this list)
@@ -19,7 +20,7 @@ SYMBOLS = [
     "fri_hip_transform_quant_batch_dev", "fri_hip_transform_quant_batch", "fri_hip_predict_histogram",
     "fri_hip_predict_histogram_dev", "fri_hip_fit_value_sums", "fri_hip_fit_value_sums_dev", "fri_hip_fit_width_sums",
     "fri_hip_fit_width_sums_dev", "fri_hip_inverse_transform", "fri_hip_inverse_transform_dev",
-    "fri_hip_time_transform_quant_dev",
+    "fri_hip_time_transform_quant_dev", "fri_hip_plan_read_trace",
 ]
 
 
@@ -98,6 +99,7 @@ def load_library():
     L.fri_hip_fit_width_sums_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     L.fri_hip_inverse_transform.argtypes = [vp, vp, vp, vp]
     L.fri_hip_inverse_transform_dev.argtypes = [vp, vp, vp, vp, vp]
+    L.fri_hip_plan_read_trace.argtypes = [vp, vp]
     L.fri_hip_time_transform_quant_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, u32, vp, C.POINTER(C.c_double)]
     _lib = L
     return L
@@ -222,6 +224,12 @@ class Plan:
         out = np.empty(8, np.int32)
         _check(load_library().fri_hip_plan_tiling(self._h, _p(out)), "fri_hip_plan_tiling")
         return dict(zip(("n_wg", "n_tiles", "lds_pitch", "lds_rows", "max_tile_cells", "band_rows", "cells_per_tile", "cells_per_wg"), (int(v) for v in out)))
+
+    def read_trace(self):
+        """[n_wg, 16] uint64 time stamps (100 MHz ticks) of the last forward/inverse launch; needs FRI_HIP_TRACE=1 at plan creation."""
+        out = np.zeros((self.tiling()["n_wg"], 16), np.uint64)
+        _check(load_library().fri_hip_plan_read_trace(self._h, _p(out)), "fri_hip_plan_read_trace", self.ctx)
+        return out
 
     def tile_table(self):
         t = self.tiling()

@@ -243,10 +243,23 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.lds_rows = g.lds_rows;
         d.cells_per_tile = g.cells_per_tile;
         d.max_tile_cells = g.max_tile_cells;
+        d.covers_image = g.n_valid_leaves == (uint64_t)g.width * g.height;
         d.max_wg_tiles = g.max_wg_tiles;
+        d.max_wg_cells = g.max_wg_cells;
         d.n_wg = (uint32_t)g.wg_tiles.size() - 1;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
+        d.k3_ablate = env_int("FRI_HIP_K3_ABLATE");
+        if (env_int("FRI_HIP_TRACE") > 0) {
+            const size_t bytes = (size_t)d.n_wg * 16 * sizeof(unsigned long long);
+            void *t = nullptr;
+            if (hipMalloc(&t, bytes) != hipSuccess || hipMemset(t, 0, bytes) != hipSuccess) {
+                fri_hip_plan_destroy(p);
+                return FRI_HIP_ERR_HIP;
+            }
+            p->owned.push_back(t);
+            d.trace = static_cast<unsigned long long *>(t);
+        }
         int hb = env_int("FRI_HIP_HIST_BLOCKS");
         if (hb > 0) d.hist_blocks = (uint32_t)hb;
     }
@@ -300,6 +313,13 @@ int fri_hip_plan_tiling(const fri_hip_plan *p, int32_t out[8]) {
     const Geometry &g = p->geo;
     const int32_t v[8] = {(int32_t)g.wg_tiles.size() - 1, (int32_t)g.tiles.size(), g.lds_pitch, g.lds_rows, g.max_tile_cells, g.band_rows, g.cells_per_tile, g.cells_per_wg};
     std::memcpy(out, v, sizeof(v));
+    return FRI_HIP_OK;
+}
+int fri_hip_plan_read_trace(fri_hip_plan *p, uint64_t *out) {
+    if (!p || !out || !p->ctx || !p->dev.trace) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    HIP_TRY(p->ctx, hipDeviceSynchronize());
+    HIP_TRY(p->ctx, hipMemcpy(out, p->dev.trace, (size_t)p->dev.n_wg * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return FRI_HIP_OK;
 }
 int fri_hip_plan_tile_table(const fri_hip_plan *p, int32_t *tiles, int32_t *tile_cells, int32_t *wg_tiles) {

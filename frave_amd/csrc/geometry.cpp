@@ -294,6 +294,7 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         for (int p = 1; p < kCell; p++)
             if (nodev[p]) m[p >> 5] |= 1u << (p & 31);
         for (int i = 0; i < 16; i++) g.n_some += (uint64_t)__builtin_popcount(m[i]);
+        g.n_valid_leaves += (uint64_t)nvalid;
         g.interior[k] = nvalid == kCell;
         g.n_interior += nvalid == kCell;
         for (int i = 0; i < 7; i++) {
@@ -378,6 +379,7 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
     g.wg_tiles.push_back(0);
     for (size_t sh = 0; sh < n_wg; sh++) {
         const size_t s0 = F * sh / n_wg, s1 = F * (sh + 1) / n_wg;
+        g.max_wg_cells = std::max(g.max_wg_cells, (int32_t)(s1 - s0));
         size_t i = s0;
         while (i < s1) { // maximal run inside one band, cut evenly into tiles of <= cells_per_tile cells
             size_t j = i;

@@ -52,6 +52,7 @@ struct Geometry {
     uint32_t n_bfs_cells = 0;
     uint32_t n_interior = 0;
     uint64_t n_some = 0;                // Some coefficients per channel
+    uint64_t n_valid_leaves = 0;        // pixels that are a leaf of a retained cell (== width * height unless the lattice has holes)
     std::vector<Int2> centers;          // [F] canonical order (ascending im, then re)
     std::vector<uint8_t> interior;      // [F] 1 = all 512 leaves inside the image
     std::vector<uint32_t> valid_mask;   // [F][16]
@@ -69,6 +70,7 @@ struct Geometry {
     int32_t band_rows = 0, cells_per_tile = 0, cells_per_wg = 0;
     int32_t max_tile_cells = 0; // largest cell_count over all tiles (<= cells_per_tile)
     int32_t max_wg_tiles = 0;   // most tiles in one workgroup share
+    int32_t max_wg_cells = 0;   // most cells in one workgroup share
     // Gather kernel (K2): blocks of kPredBlock x kPredBlock cells in lattice coordinates plus a one-cell halo ring.
     // pred_slots[t][(kPredBlock+2)^2] = cell id held by each LDS slot of tile t (-1 = no retained cell there).
     std::vector<int32_t> pred_slots;

@@ -72,6 +72,7 @@ struct FwdArgs {
     uint32_t cpr, cpr_magic;
     int32_t q_identity;
     int32_t ablate; // timing-only ablation (FRI_HIP_K1_ABLATE): 1 = skip staging, 2 = skip the cell loop, 4 = skip stores. 0 in production.
+    unsigned long long *trace; // diagnostic timeline, null in production
     QMatrix q;
 };
 
@@ -79,6 +80,8 @@ struct FwdArgs {
 // Every value of the transform fits 16 bits (differences in [-255, 255], low-pass values in [0, 255]) and K1 is bound by
 // VALU issue (a wave64 integer instruction occupies its SIMD for 4 cycles), so one wave transforms TWO items at once:
 // item A in the low half, item B in the high half of each VGPR, v_pk_*_i16 arithmetic. DPP / permlane moves carry both.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
@@ -204,10 +207,44 @@ __device__ __forceinline__ void store_item(int32_t *__restrict__ coefs, uint32_t
         v[7] = quant_one(v[7], lane, a);
     }
     int32_t *out = coefs + elem_off; // 32-bit element offset off a wave-uniform base: saddr + voffset addressing
-    *reinterpret_cast<int4 *>(out + 256 + 4 * lane) = make_int4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<int2 *>(out + 128 + 2 * lane) = make_int2(v[4], v[5]);
+    // Streaming (nontemporal) stores: the coefficients are written once and not read back by this kernel. Regular stores leave
+    // up to 32 MB of dirty lines in the eight L2s, which the end-of-kernel release then has to write back while nothing else
+    // runs (measured: 27.3 -> 21.7 us per 4096^2 launch).
+#ifndef FRI_K1_STORE
+#define FRI_K1_STORE 1
+#endif
+#if FRI_K1_STORE == 0
+    *reinterpret_cast<i32x4 *>(out + 256 + 4 * lane) = i32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<i32x2 *>(out + 128 + 2 * lane) = i32x2{v[4], v[5]};
     out[64 + lane] = v[6];
     out[lane] = v[7];
+#elif FRI_K1_STORE == 1
+    __builtin_nontemporal_store(i32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<i32x4 *>(out + 256 + 4 * lane));
+    __builtin_nontemporal_store(i32x2{v[4], v[5]}, reinterpret_cast<i32x2 *>(out + 128 + 2 * lane));
+    __builtin_nontemporal_store(v[6], out + 64 + lane);
+    __builtin_nontemporal_store(v[7], out + lane);
+#else
+#if FRI_K1_STORE == 2
+#define FRI_ST_MOD "sc1"
+#elif FRI_K1_STORE == 3
+#define FRI_ST_MOD "sc0 sc1"
+#elif FRI_K1_STORE == 4
+#define FRI_ST_MOD "sc0 sc1 nt"
+#elif FRI_K1_STORE == 5
+#define FRI_ST_MOD "nt"
+#else
+#define FRI_ST_MOD "sc0"
+#endif
+    const uint32_t vo = (elem_off + 4u * (uint32_t)lane) * 4u;
+    const i32x4 q4{v[0], v[1], v[2], v[3]};
+    const i32x2 q2{v[4], v[5]};
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024 " FRI_ST_MOD ::"v"(vo), "v"(q4), "s"(coefs) : "memory");
+    const uint32_t vo2 = (elem_off + 2u * (uint32_t)lane) * 4u;
+    asm volatile("global_store_dwordx2 %0, %1, %2 offset:512 " FRI_ST_MOD ::"v"(vo2), "v"(q2), "s"(coefs) : "memory");
+    const uint32_t vo1 = (elem_off + (uint32_t)lane) * 4u;
+    asm volatile("global_store_dword %0, %1, %2 offset:256 " FRI_ST_MOD ::"v"(vo1), "v"(v[6]), "s"(coefs) : "memory");
+    asm volatile("global_store_dword %0, %1, %2 " FRI_ST_MOD ::"v"(vo1), "v"(v[7]), "s"(coefs) : "memory");
+#endif
 }
 
 // Native vector type on purpose: HIP's uint4 is a struct whose copies become llvm.memcpy, which kept the staging
@@ -307,6 +344,25 @@ __device__ __forceinline__ uint32_t xcd_contiguous_share(uint32_t b, uint32_t n)
     return x * q + min(x, r) + idx;
 }
 
+// Diagnostic timeline (instrumented build + FRI_HIP_TRACE=1; compiled out of the product): thread 0 of a workgroup stamps the
+// 100 MHz constant clock into slot `slot` of its share's record. Slot 0 = entry, 1 = prologue done, 2 + i = tile i done
+// (i < 12), 14 = hardware id (HW_ID | XCC_ID << 32), 15 = exit.
+#ifndef FRI_HIP_ENABLE_TRACE
+#define FRI_HIP_ENABLE_TRACE 0 // `make trace` builds the instrumented library; the stamps are compiled out of the product
+#endif
+constexpr bool kTraceBuild = FRI_HIP_ENABLE_TRACE != 0;
+constexpr int kTraceSlots = 16;
+__device__ __forceinline__ void trace_stamp(unsigned long long *trace, uint32_t wg, int slot, int tid) {
+    if (kTraceBuild && trace && tid == 0) trace[(size_t)wg * kTraceSlots + min(slot, 13)] = wall_clock64();
+}
+__device__ __forceinline__ void trace_exit(unsigned long long *trace, uint32_t wg, int tid) {
+    if (kTraceBuild && trace && tid == 0) {
+        const unsigned long long hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        trace[(size_t)wg * kTraceSlots + 14] = hw | (xcc << 32);
+        trace[(size_t)wg * kTraceSlots + 15] = wall_clock64();
+    }
+}
+
 // Workgroup barrier that orders LDS traffic only. __syncthreads() would also emit s_waitcnt vmcnt(0), i.e. wait
 // for every coefficient store of the tile to drain (vmcnt counts stores on CDNA4) -- exactly the latency the
 // pipeline is built to hide. Global memory is never exchanged between the waves of a workgroup here.
@@ -389,6 +445,7 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t wg = xcd_contiguous_share(blockIdx.x, a.n_wg);
     const int tb = a.wg_tiles[wg], te = a.wg_tiles[wg + 1];
+    trace_stamp(a.trace, wg, 0, tid);
     // The share's tile descriptors go to LDS once, before any store is issued: fetching them inside the loop would be a
     // vector load behind s_waitcnt vmcnt(0) per tile (scalar loads are off the table once the kernel has stored), and that
     // wait would also drain the previous tile's coefficient stores.
@@ -416,6 +473,7 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
     stage_issue<C, EDGE, FAST, NCH>(a, t, img, tid, cm, st);
     stage_commit<NCH>(a, t, lds, junk, tid, st);
     __syncthreads();
+    trace_stamp(a.trace, wg, 1, tid);
 
     for (int ti = tb; ti < te; ti++) {
         const uint8_t *cur = lds + ((ti - tb) & 1) * a.buf_bytes;
@@ -506,9 +564,11 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
                 }
             }
         }
+        trace_stamp(a.trace, wg, 2 + ti - tb, tid);
         lds_barrier();
         t = tn;
     }
+    trace_exit(a.trace, wg, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -880,16 +940,34 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: inverse transform. One wave per (cell, channel); mirror of fwd_wave. Pixels are written with
-// byte stores straight from registers (each pixel has exactly one owning cell).
+// K3: inverse transform. A workgroup walks the forward kernel's tiles of its share (<= cells_per_tile cells of one
+// band each), one wave per (cell, channel) item; mirror of fwd_wave. A cell's 512 pixels are scattered over ~50
+// rows, so byte stores straight from registers cost one L2 write request per pixel (measured: 41 us). Instead the
+// waves scatter into an LDS image of the tile's pixel rectangle -- 16 bit per byte: value | 0x100, the ninth bit
+// says "a cell of this tile owns the byte" -- and the workgroup then writes the rectangle out row by row: one
+// aligned dword store where all four bytes are owned (90 % of the bytes: the interior of the tile's footprint);
+// the dwords on its fractal rim are queued and written with byte stores from densely packed lanes afterwards
+// (a store instruction costs the same with 2 or 64 active lanes). Every pixel has exactly one owning cell, so no
+// byte is written twice and none is skipped. The coefficients of tile i + 1 are loaded while tile i is processed.
 // ------------------------------------------------------------------------------------------------
+constexpr int kInvThreads = 256;
+constexpr int kInvWaves = kInvThreads / 64;
+constexpr int kInvMaxItemsPerWave = 4; // (cell, channel) items of one tile per transform wave
+
 struct InvArgs {
     const int32_t *coefs;
     uint8_t *pixels;
-    const Int2 *centers;
+    const Tile *tiles;
+    const TileCell *tile_meta; // in tile order
+    const int32_t *wg_tiles;   // [n_wg + 1]
     int32_t width, height, channels;
-    uint32_t F;
+    uint32_t F, n_wg;
+    int32_t buf_bytes;   // LDS pixel rectangle (16 bit per byte), multiple of 16
+    int32_t queue_bytes; // LDS rim queue per wave
+    int32_t max_wg_tiles;
     int32_t q_identity;
+    int32_t ablate; // timing experiments only (FRI_HIP_K3_ABLATE): 1 = no global stores, 2 = no LDS scatter
+    unsigned long long *trace; // diagnostic timeline, null in production
     QMatrix q;
 };
 
@@ -910,54 +988,189 @@ __device__ __forceinline__ void unpair(int low, int d, int &left, int &right) {
     }
 }
 
-__global__ void __launch_bounds__(256) inverse_transform_kernel(const InvArgs a) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= a.F * (uint32_t)a.channels) return;
-    const uint32_t ch = item / a.F, cell = item - ch * a.F;
-    const int32_t *in = a.coefs + ((size_t)ch * a.F + cell) * kCell;
-    const int4 c8 = *reinterpret_cast<const int4 *>(in + 256 + 4 * lane);
-    const int2 c7 = *reinterpret_cast<const int2 *>(in + 128 + 2 * lane);
-    int d8[4] = {c8.x, c8.y, c8.z, c8.w}, d7[2] = {c7.x, c7.y};
-    int d6 = in[64 + lane], low = in[lane];
-#pragma unroll
-    for (int i = 0; i < 4; i++) d8[i] = dequant_ref(d8[i], 256 + 4 * lane + i, a);
-#pragma unroll
-    for (int i = 0; i < 2; i++) d7[i] = dequant_ref(d7[i], 128 + 2 * lane + i, a);
-    d6 = dequant_ref(d6, 64 + lane, a);
-    low = dequant_ref(low, lane, a);
+// The eight coefficient dwords a lane holds of one (cell, channel) item: heap nodes lane (levels 0-5 and the DC), 64 + lane,
+// 128 + 2 lane + {0, 1}, 256 + 4 lane + {0..3}.
+struct InvRegs {
+    int32_t d8[4], d7[2], d6, low;
+};
 
-    int s = __shfl(low, 0); // low_pass_values[1] = coefficients[0].unwrap()  (:361)
+__device__ __forceinline__ InvRegs inv_load(const int32_t *in, int lane) {
+    const i32x4 c8 = *reinterpret_cast<const i32x4 *>(in + 256 + 4 * lane);
+    const i32x2 c7 = *reinterpret_cast<const i32x2 *>(in + 128 + 2 * lane);
+    InvRegs r;
+    r.d8[0] = c8.x, r.d8[1] = c8.y, r.d8[2] = c8.z, r.d8[3] = c8.w;
+    r.d7[0] = c7.x, r.d7[1] = c7.y;
+    r.d6 = in[64 + lane];
+    r.low = in[lane];
+    return r;
+}
+
+// extract_values for one item (wavelet_transform.rs:358-380) on the lane-distributed tree: six cross-lane levels top-down,
+// then levels 6-8 in registers. leaf[j] = value of leaf 8 lane + j (0 where the last difference is None: `if let Some(dif)`
+// at :365 leaves those pixels at the raster's initial 0).
+__device__ __forceinline__ void inv_wave(InvRegs c, int lane, const InvArgs &a, int (&leaf)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) c.d8[i] = dequant_ref(c.d8[i], 256 + 4 * lane + i, a);
+#pragma unroll
+    for (int i = 0; i < 2; i++) c.d7[i] = dequant_ref(c.d7[i], 128 + 2 * lane + i, a);
+    c.d6 = dequant_ref(c.d6, 64 + lane, a);
+    c.low = dequant_ref(c.low, lane, a);
+    int s = __shfl(c.low, 0); // low_pass_values[1] = coefficients[0].unwrap()  (:361)
 #pragma unroll
     for (int j = 5; j >= 0; j--) { // levels 0..5
         const int lv = 5 - j;
-        const int d = __shfl(low, (1 << lv) + (lane >> (j + 1)));
+        const int d = __shfl(c.low, (1 << lv) + (lane >> (j + 1)));
         int l, r;
         unpair(s, d, l, r);
         s = ((lane >> j) & 1) ? r : l;
     }
-    int s7[2], s8[4], leaf[8];
-    unpair(s, d6, s7[0], s7[1]);
+    int s7[2], s8[4];
+    unpair(s, c.d6, s7[0], s7[1]);
 #pragma unroll
-    for (int i = 0; i < 2; i++) unpair(s7[i], d7[i], s8[2 * i], s8[2 * i + 1]);
+    for (int i = 0; i < 2; i++) unpair(s7[i], c.d7[i], s8[2 * i], s8[2 * i + 1]);
 #pragma unroll
-    for (int i = 0; i < 4; i++) unpair(s8[i], d8[i], leaf[2 * i], leaf[2 * i + 1]);
+    for (int i = 0; i < 4; i++) unpair(s8[i], c.d8[i], leaf[2 * i], leaf[2 * i + 1]);
+}
 
-    const Int2 cen = a.centers[cell];
-    const int x0 = cen.x + lane_dx(lane), y0 = cen.y + lane_dy(lane);
+// The loads of one tile's items for this wave. Slots past the tile's items re-load its last item (no conditional loads:
+// a load the compiler cannot prove executed costs an immediate wait).
+template <int NI>
+__device__ __forceinline__ void inv_prefetch(const InvArgs &a, const Tile &t, const TileCell *cells, int wave, int lane, InvRegs (&r)[NI]) {
+    const int C = a.channels, n_items = t.cell_count * C;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        if (d8[j >> 1] == kNone) continue; // `if let Some(dif)` at the last level (:365, :368-372)
-        const int x = x0 + leaf_dx(j), y = y0 + leaf_dy(j);
-        if (x >= 0 && y >= 0 && x < a.width && y < a.height) // set_pixel, images.rs:104
-            a.pixels[((size_t)y * a.width + x) * a.channels + ch] = (uint8_t)min(max(leaf[j], 0), 255);
+    for (int s = 0; s < NI; s++) {
+        const int item = min(wave + kInvWaves * s, n_items - 1);
+        const int cl = item / C, ch = item - cl * C;
+        r[s] = inv_load(a.coefs + ((size_t)ch * a.F + (uint32_t)cells[cl].cell) * kCell, lane);
     }
+}
+
+template <int NI>
+__global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const InvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint16_t *img16 = reinterpret_cast<uint16_t *>(lds);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint16_t *queue = reinterpret_cast<uint16_t *>(lds + a.buf_bytes + wave * a.queue_bytes);
+    Tile *lds_tiles = reinterpret_cast<Tile *>(lds + a.buf_bytes + kInvWaves * a.queue_bytes);
+    TileCell *lds_cells = reinterpret_cast<TileCell *>(lds_tiles + a.max_wg_tiles);
+    // Blocks of one XCD take a contiguous range of shares: the rim bytes of neighbouring tiles complete their lines in ONE L2.
+    const uint32_t wg = xcd_contiguous_share(blockIdx.x, a.n_wg);
+    const int tb = a.wg_tiles[wg], te = a.wg_tiles[wg + 1];
+    const int C = a.channels;
+    const uint32_t base_lo = (uint32_t)reinterpret_cast<uintptr_t>(a.pixels);
+    const uint32_t wc = (uint32_t)a.width * (uint32_t)C;
+    trace_stamp(a.trace, wg, 0, tid);
+    {
+        const Tile first = a.tiles[tb], last = a.tiles[te - 1];
+        const int n_cells = last.cell_begin + last.cell_count - first.cell_begin;
+        if (tid < te - tb) lds_tiles[tid] = a.tiles[tb + tid];
+        for (int i = tid; i < n_cells; i += kInvThreads) {
+            TileCell tc = a.tile_meta[first.cell_begin + i];
+            lds_cells[i] = tc;
+        }
+        u32x4 *z = reinterpret_cast<u32x4 *>(lds);
+        for (int i = tid; i < a.buf_bytes / 16; i += kInvThreads) z[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    const int cell0 = lds_tiles[0].cell_begin;
+    trace_stamp(a.trace, wg, 1, tid);
+
+    InvRegs pre[NI];
+    inv_prefetch<NI>(a, lds_tiles[0], lds_cells, wave, lane, pre);
+    for (int ti = tb; ti < te; ti++) {
+        const Tile t = lds_tiles[ti - tb];
+        InvRegs cur[NI];
+#pragma unroll
+        for (int s = 0; s < NI; s++) cur[s] = pre[s];
+        {
+            const Tile tn = lds_tiles[min(ti + 1, te - 1) - tb];
+            inv_prefetch<NI>(a, tn, lds_cells + (tn.cell_begin - cell0), wave, lane, pre);
+        }
+        const int n_items = t.cell_count * C;
+        const int rd = (t.width_px * C + 6) >> 2; // dwords per staged row: up to 3 bytes of lead-in so that global dwords are aligned
+        const int pitch16 = rd * 4;               // LDS halfwords per staged row
+        int leaf[NI][8];
+#pragma unroll
+        for (int s = 0; s < NI; s++) inv_wave(cur[s], lane, a, leaf[s]);
+#pragma unroll
+        for (int s = 0; s < NI; s++) {
+            const int item = wave + kInvWaves * s;
+            if (item < n_items && !(a.ablate & 2)) {
+                const int cl = item / C, ch = item - cl * C;
+                const TileCell tc = lds_cells[t.cell_begin - cell0 + cl];
+                const int x0 = tc.cx + lane_dx(lane), y0 = tc.cy + lane_dy(lane);
+                int rowbase[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) {
+                    const int y = y0 + dy;
+                    const uint32_t g = (uint32_t)y * wc + (uint32_t)(t.x_lo * C); // byte offset of the staged row (only bits 0-1 matter)
+                    rowbase[dy] = (y - t.y_lo) * pitch16 + (int)((base_lo + g) & 3u) + (x0 - t.x_lo) * C + ch;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int x = x0 + leaf_dx(j), y = y0 + leaf_dy(j);
+                    if (tc.interior || (x >= 0 && y >= 0 && x < a.width && y < a.height)) // set_pixel, images.rs:104
+                        img16[rowbase[leaf_dy(j)] + leaf_dx(j) * C] = (uint16_t)(0x100 | min(max(leaf[s][j], 0), 255));
+                }
+            }
+        }
+        lds_barrier(); // the rectangle is complete
+
+        // Row pass: whole dwords go out, rim dwords are queued as (row << 8 | dword).
+        int qn = 0;
+        for (int r = wave; r < t.n_rows; r += kInvWaves) {
+            const size_t g = ((size_t)(t.y_lo + r) * (size_t)a.width + (size_t)t.x_lo) * (size_t)C;
+            uint8_t *row = a.pixels + g - (int)((base_lo + (uint32_t)g) & 3u); // dword aligned
+            uint2 *src = reinterpret_cast<uint2 *>(img16 + r * pitch16);
+            for (int k0 = 0; k0 < rd; k0 += 64) {
+                const int k = k0 + lane;
+                uint2 v = make_uint2(0u, 0u);
+                if (k < rd) v = src[k];
+                const uint32_t own = (v.x & 0x01000100u) | ((v.y & 0x01000100u) << 1); // bits 8, 24, 9, 25
+                const bool full = own == 0x03000300u, rim = own != 0 && !full;
+                if (full) {
+                    src[k] = make_uint2(0u, 0u);
+                    if (!(a.ablate & 1)) *reinterpret_cast<uint32_t *>(row + 4 * k) = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u);
+                }
+                const unsigned long long m = __ballot(rim);
+                if (rim) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(r << 8 | k);
+                qn += __popcll(m);
+            }
+        }
+        // Rim pass: one queued dword per lane, its owned bytes as byte stores.
+        for (int e0 = 0; e0 < qn; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < qn) {
+                const int rk = queue[e], r = rk >> 8, k = rk & 255;
+                const size_t g = ((size_t)(t.y_lo + r) * (size_t)a.width + (size_t)t.x_lo) * (size_t)C;
+                uint8_t *p = a.pixels + g - (int)((base_lo + (uint32_t)g) & 3u) + 4 * k;
+                uint2 *src = reinterpret_cast<uint2 *>(img16 + r * pitch16) + k;
+                const uint2 v = *src;
+                *src = make_uint2(0u, 0u);
+                if (!(a.ablate & 1)) {
+                    if (v.x & 0x00000100u) p[0] = (uint8_t)v.x;
+                    if (v.x & 0x01000000u) p[1] = (uint8_t)(v.x >> 16);
+                    if (v.y & 0x00000100u) p[2] = (uint8_t)v.y;
+                    if (v.y & 0x01000000u) p[3] = (uint8_t)(v.y >> 16);
+                }
+            }
+        }
+        lds_barrier(); // the rectangle is all zero again
+        trace_stamp(a.trace, wg, 2 + ti - tb, tid);
+    }
+    trace_exit(a.trace, wg, tid);
 }
 
 } // namespace
 
 static size_t fwd_meta_offset(const DevicePlan &p) { return ((size_t)p.lds_pitch * p.lds_rows + 15) & ~(size_t)15; }
 static size_t fwd_buf_bytes(const DevicePlan &p) { return fwd_meta_offset(p) + (size_t)p.max_tile_cells * sizeof(TileCell); }
+// 16 bit per staged byte; a staged row holds <= lds_pitch bytes including its lead-in (lds_pitch >= widest row + 15).
+static size_t inv_buf_bytes(const DevicePlan &p) { return (size_t)p.lds_rows * (size_t)p.lds_pitch * 2; }
+// worst case: every dword of a wave's rows is a rim dword (2 bytes per entry), rounded to 16
+static size_t inv_queue_bytes(const DevicePlan &p) { return ((size_t)((p.lds_rows + kInvWaves - 1) / kInvWaves) * (size_t)(p.lds_pitch / 4) * 2 + 15) & ~(size_t)15; }
+size_t inv_lds_bytes(const DevicePlan &p) { return inv_buf_bytes(p) + kInvWaves * inv_queue_bytes(p) + (size_t)p.max_wg_tiles * sizeof(Tile) + (size_t)p.max_wg_cells * sizeof(TileCell); }
 size_t fwd_lds_bytes(const DevicePlan &p) { return 2 * fwd_buf_bytes(p) + 16 * kFwdThreads + (size_t)p.max_wg_tiles * sizeof(Tile); }
 static size_t fwd_chunks(const DevicePlan &p) { return (size_t)p.lds_rows * (p.lds_pitch / 16); }
 
@@ -1000,6 +1213,7 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
     a.q_identity = 1;
     for (int i = 0; i <= 9; i++) a.q_identity &= (q.q[i] == 1); // layers 0..9 are the only ones a 512-node cell uses
     a.ablate = p.k1_ablate;
+    a.trace = p.trace;
     const size_t lds = fwd_lds_bytes(p);
     const dim3 grid(p.n_wg, n_images), block(kFwdThreads);
     // EDGE variant only when a 16-byte chunk could straddle the ends of one of the caller's image buffers
@@ -1074,22 +1288,40 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, int mode, const int32_t *c
 }
 
 hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, const QMatrix &q, uint8_t *pixels, hipStream_t stream) {
-    // RasterImage::from_wavelet starts from an all-zero raster (wavelet_transform.rs:309-317)
-    hipError_t e = hipMemsetAsync(pixels, 0, (size_t)p.width * p.height * p.channels, stream);
-    if (e != hipSuccess) return e;
+    // RasterImage::from_wavelet starts from an all-zero raster (wavelet_transform.rs:309-317). When every pixel belongs to a
+    // retained cell the kernel writes all of them (zeros included); only a lattice with holes (very thin images) needs the fill.
+    if (!p.covers_image) {
+        hipError_t e = hipMemsetAsync(pixels, 0, (size_t)p.width * p.height * p.channels, stream);
+        if (e != hipSuccess) return e;
+    }
     InvArgs a{};
     a.coefs = coefs;
     a.pixels = pixels;
-    a.centers = p.centers;
+    a.tiles = p.tiles;
+    a.tile_meta = p.tile_meta;
+    a.wg_tiles = p.wg_tiles;
     a.width = p.width;
     a.height = p.height;
     a.channels = p.channels;
     a.F = p.F;
+    a.n_wg = p.n_wg;
+    a.buf_bytes = (int32_t)inv_buf_bytes(p);
+    a.max_wg_tiles = p.max_wg_tiles;
+    a.ablate = p.k3_ablate;
+    a.trace = p.trace;
     a.q = q;
     a.q_identity = 1;
     for (int i = 0; i <= 9; i++) a.q_identity &= (q.q[i] == 1);
-    const uint32_t items = p.F * (uint32_t)p.channels;
-    hipLaunchKernelGGL(inverse_transform_kernel, dim3((items + 3) / 4), dim3(256), 0, stream, a);
+    a.queue_bytes = (int32_t)inv_queue_bytes(p);
+    const int items_per_wave = (p.max_tile_cells * p.channels + kInvWaves - 1) / kInvWaves;
+    if (items_per_wave > kInvMaxItemsPerWave || p.max_wg_tiles > kInvThreads || p.lds_rows > 256 || p.lds_pitch / 4 > 256) return hipErrorInvalidConfiguration;
+    const size_t lds = inv_lds_bytes(p);
+    void (*kern)(const InvArgs) = items_per_wave <= 1 ? inverse_transform_kernel<1> : items_per_wave == 2 ? inverse_transform_kernel<2> : inverse_transform_kernel<4>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.n_wg), dim3(kInvThreads), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -17,7 +17,9 @@ struct DevicePlan {
     const int32_t *wg_tiles = nullptr;    // [n_wg + 1] tile range per workgroup share
     uint32_t n_wg = 0;
     int32_t max_tile_cells = 0;
+    bool covers_image = false;            // every pixel of the image is a leaf of a retained cell
     int32_t max_wg_tiles = 0;
+    int32_t max_wg_cells = 0;             // most cells in one workgroup share
     const Int2 *centers = nullptr;
     const uint8_t *interior = nullptr;
     const uint32_t *valid_mask = nullptr; // [F][16]
@@ -33,6 +35,8 @@ struct DevicePlan {
     int32_t width = 0, height = 0, channels = 0;
     int32_t lds_pitch = 0, lds_rows = 0, cells_per_tile = 0;
     int32_t k1_ablate = 0; // timing-only ablation flags, see FwdArgs::ablate
+    unsigned long long *trace = nullptr; // [n_wg][16] diagnostic timeline (FRI_HIP_TRACE=1), else null
+    int32_t k3_ablate = 0; // same for the inverse kernel, see InvArgs::ablate
 };
 
 struct QMatrix {
@@ -57,6 +61,7 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, int mode, const int32_t *c
 hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, const QMatrix &q, uint8_t *pixels, hipStream_t stream);
 
 size_t fwd_lds_bytes(const DevicePlan &p);
+size_t inv_lds_bytes(const DevicePlan &p);
 // True iff the lane/leaf footprint hard-wired in the kernels equals the table derived from LITERALS.
 bool device_footprint_matches(const StaticTables &st);
 // True iff the plan's tiles fit the forward kernel's static register/LDS budget.

@@ -176,6 +176,11 @@ int fri_hip_time_transform_quant_dev(fri_hip_plan *plan, uint32_t n_images, cons
                                      const int32_t qmatrix[32], int32_t *d_coefs, size_t coef_stride, uint32_t iters, void *stream,
                                      double *mean_us);
 
+/* Diagnostic timeline (plans created with FRI_HIP_TRACE=1 in the environment; INVALID_ARGUMENT otherwise): copies the
+ * record of the most recent forward or inverse launch, out[n_wg][16] = {entry, prologue done, tile 0 done, ... (12 slots),
+ * hardware id, exit}, time stamps in ticks of the GPU's constant 100 MHz clock. Synchronises the device. */
+int fri_hip_plan_read_trace(fri_hip_plan *plan, uint64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,58 @@
+"""Per-workgroup timeline of K1 (forward) or K3 (inverse) at 4096x4096 from the diagnostic trace. GPU only.
+usage: FRI_HIP_TRACE=1 python tools/trace_timeline.py [k1|k3] [C]"""
+import os
+import sys
+
+os.environ["FRI_HIP_TRACE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import frave_amd
+
+which = sys.argv[1] if len(sys.argv) > 1 else "k1"
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+ctx = frave_amd.Context(0)
+plan = frave_amd.Plan(ctx, 4096, 4096, C)
+s = torch.cuda.current_stream().cuda_stream
+SLOTS = 4
+d_px = torch.randint(0, 256, (SLOTS, plan.pixel_bytes), dtype=torch.uint8, device="cuda")
+d_co = torch.empty((SLOTS, plan.coef_count), dtype=torch.int32, device="cuda")
+d_back = torch.empty((SLOTS, plan.pixel_bytes), dtype=torch.uint8, device="cuda")
+for k in range(SLOTS):
+    plan.transform_quant_dev(d_px[k].data_ptr(), d_co[k].data_ptr(), stream=s)
+for rep in range(3):  # the last launch (cold slot) is the one read back
+    for k in range(SLOTS):
+        if which == "k1":
+            plan.transform_quant_dev(d_px[k].data_ptr(), d_co[k].data_ptr(), stream=s)
+        else:
+            plan.inverse_transform_dev(d_co[k].data_ptr(), d_back[k].data_ptr(), stream=s)
+torch.cuda.synchronize()
+tr = plan.read_trace().astype(np.int64)
+_, _, wg_tiles = plan.tile_table()
+n_tiles = np.diff(wg_tiles)
+t0 = tr[:, 0].min()
+us = lambda a: (a - t0) / 100.0
+entry, pro, end = us(tr[:, 0]), us(tr[:, 1]), us(tr[:, 15])
+print(f"{which} C={C}: {len(tr)} workgroups, tiles per share {n_tiles.min()}..{n_tiles.max()} (mean {n_tiles.mean():.2f})")
+pc = lambda a: " ".join(f"{np.percentile(a, q):7.2f}" for q in (0, 10, 50, 90, 100))
+print("                      min     p10     p50     p90     max   [us since first entry]")
+print("entry              ", pc(entry))
+print("prologue done      ", pc(pro))
+for i in range(int(n_tiles.max())):
+    m = n_tiles > i
+    print(f"tile {i} done ({m.sum():4d})", pc(us(tr[m, 2 + i])))
+print("exit               ", pc(end))
+print("prologue duration  ", pc(pro - entry))
+dur = []
+for i in range(int(n_tiles.max())):
+    m = n_tiles > i
+    prev = tr[m, 1] if i == 0 else tr[m, 1 + i]
+    dur.append((tr[m, 2 + i] - prev) / 100.0)
+    print(f"tile {i} duration    ", pc(dur[-1]))
+print("lifetime           ", pc(end - entry))
+xcc = (tr[:, 14] >> 32) & 0xF
+for x in range(8):
+    m = xcc == x
+    if m.any():
+        print(f"xcc {x}: {m.sum():4d} wgs  entry {entry[m].min():6.2f}..{entry[m].max():6.2f}  exit {end[m].min():6.2f}..{end[m].max():6.2f}")
