@@ -189,6 +189,14 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
     tp.band_rows = env_int("FRI_HIP_BAND_ROWS");
     tp.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
     tp.cells_per_wg = env_int("FRI_HIP_CELLS_PER_WG");
+    // Shares by dispatch rank, measured on MI355X at 4096^2 (tools/sweep_rank_weights.sh): equal shares 22.3-23.4 us,
+    // these weights 20.5-21.7 us; steeper is worse again. Host-only plans keep equal shares.
+    if (ctx) tp.rank_weight[0] = 1.3f, tp.rank_weight[1] = 1.1f, tp.rank_weight[2] = 0.9f, tp.rank_weight[3] = 0.7f;
+    if (const char *w = std::getenv("FRI_HIP_RANK_WEIGHTS")) { // "w0,w1,w2,w3" (tuning; "1,1,1,1" = equal shares)
+        float v[4];
+        if (std::sscanf(w, "%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3]) == 4)
+            for (int i = 0; i < 4; i++) tp.rank_weight[i] = v[i];
+    }
     tp.target_wgs = env_int("FRI_HIP_TARGET_WGS");
     if (tp.target_wgs <= 0 && ctx) tp.target_wgs = ctx->cu_count * 4; // 4 resident workgroups per CU (register budget of K1)
     // Shrink the tiles until they fit the forward kernel's static register / LDS budget (irregular centre spacing

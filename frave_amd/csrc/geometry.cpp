@@ -376,9 +376,29 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         g.max_tile_cells = std::max(g.max_tile_cells, t.cell_count);
         g.tiles.push_back(t);
     };
+    // Share boundaries. Equal shares (+-1 cell) unless rank weights are given: share sh is run by workgroup b(sh) (the inverse
+    // of the kernels' XCD-contiguous block -> share map), whose dispatch rank is b / (target_wgs / 4).
+    std::vector<size_t> bound(n_wg + 1);
+    {
+        const bool weighted = tp.rank_weight[0] > 0 && tp.rank_weight[1] > 0 && tp.rank_weight[2] > 0 && tp.rank_weight[3] > 0;
+        std::vector<double> cum(n_wg + 1, 0.0);
+        const size_t q = n_wg >> 3, r = n_wg & 7, per_rank = std::max<size_t>(1, (size_t)target_wgs / 4);
+        for (size_t x = 0, sh = 0; x < 8; x++) {
+            const size_t n_x = q + (x < r ? 1 : 0);
+            for (size_t idx = 0; idx < n_x; idx++, sh++) {
+                const size_t b = idx * 8 + x;
+                cum[sh + 1] = cum[sh] + (weighted ? (double)tp.rank_weight[std::min<size_t>(b / per_rank, 3)] : 1.0);
+            }
+        }
+        for (size_t sh = 0; sh <= n_wg; sh++) bound[sh] = (size_t)((double)F * cum[sh] / cum[n_wg] + 0.5);
+        bound[0] = 0;
+        bound[n_wg] = F;
+        for (size_t sh = 1; sh <= n_wg; sh++) // every share keeps at least one cell (n_wg <= F)
+            bound[sh] = std::min(std::max(bound[sh], bound[sh - 1] + 1), F - (n_wg - sh));
+    }
     g.wg_tiles.push_back(0);
     for (size_t sh = 0; sh < n_wg; sh++) {
-        const size_t s0 = F * sh / n_wg, s1 = F * (sh + 1) / n_wg;
+        const size_t s0 = bound[sh], s1 = bound[sh + 1];
         g.max_wg_cells = std::max(g.max_wg_cells, (int32_t)(s1 - s0));
         size_t i = s0;
         while (i < s1) { // maximal run inside one band, cut evenly into tiles of <= cells_per_tile cells

@@ -85,6 +85,9 @@ struct TilingParams {
     int band_rows = 0, cells_per_tile = 0; // 0 = default
     int target_wgs = 0;   // workgroup shares to aim for (resident workgroups of the device); 0 = 1024
     int cells_per_wg = 0; // if > 0 overrides target_wgs
+    // Relative share size by dispatch rank (workgroup b has rank min(4 b / target_wgs, 3): the r-th workgroup placed on its CU).
+    // The CU's arbiter favours older waves, so later workgroups progress more slowly and get fewer cells. {0,..} = equal shares.
+    float rank_weight[4] = {0, 0, 0, 0};
 };
 
 // Returns "" on success, else an error string.

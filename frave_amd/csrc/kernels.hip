@@ -209,42 +209,11 @@ __device__ __forceinline__ void store_item(int32_t *__restrict__ coefs, uint32_t
     int32_t *out = coefs + elem_off; // 32-bit element offset off a wave-uniform base: saddr + voffset addressing
     // Streaming (nontemporal) stores: the coefficients are written once and not read back by this kernel. Regular stores leave
     // up to 32 MB of dirty lines in the eight L2s, which the end-of-kernel release then has to write back while nothing else
-    // runs (measured: 27.3 -> 21.7 us per 4096^2 launch).
-#ifndef FRI_K1_STORE
-#define FRI_K1_STORE 1
-#endif
-#if FRI_K1_STORE == 0
-    *reinterpret_cast<i32x4 *>(out + 256 + 4 * lane) = i32x4{v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<i32x2 *>(out + 128 + 2 * lane) = i32x2{v[4], v[5]};
-    out[64 + lane] = v[6];
-    out[lane] = v[7];
-#elif FRI_K1_STORE == 1
+    // runs. A/B on one box, us per 4096^2 launch: plain 27.5, nt 22.0-23.6, sc1 26.0, sc0 sc1 25.5, sc0 sc1 nt 22.0-23.2.
     __builtin_nontemporal_store(i32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<i32x4 *>(out + 256 + 4 * lane));
     __builtin_nontemporal_store(i32x2{v[4], v[5]}, reinterpret_cast<i32x2 *>(out + 128 + 2 * lane));
     __builtin_nontemporal_store(v[6], out + 64 + lane);
     __builtin_nontemporal_store(v[7], out + lane);
-#else
-#if FRI_K1_STORE == 2
-#define FRI_ST_MOD "sc1"
-#elif FRI_K1_STORE == 3
-#define FRI_ST_MOD "sc0 sc1"
-#elif FRI_K1_STORE == 4
-#define FRI_ST_MOD "sc0 sc1 nt"
-#elif FRI_K1_STORE == 5
-#define FRI_ST_MOD "nt"
-#else
-#define FRI_ST_MOD "sc0"
-#endif
-    const uint32_t vo = (elem_off + 4u * (uint32_t)lane) * 4u;
-    const i32x4 q4{v[0], v[1], v[2], v[3]};
-    const i32x2 q2{v[4], v[5]};
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024 " FRI_ST_MOD ::"v"(vo), "v"(q4), "s"(coefs) : "memory");
-    const uint32_t vo2 = (elem_off + 2u * (uint32_t)lane) * 4u;
-    asm volatile("global_store_dwordx2 %0, %1, %2 offset:512 " FRI_ST_MOD ::"v"(vo2), "v"(q2), "s"(coefs) : "memory");
-    const uint32_t vo1 = (elem_off + (uint32_t)lane) * 4u;
-    asm volatile("global_store_dword %0, %1, %2 offset:256 " FRI_ST_MOD ::"v"(vo1), "v"(v[6]), "s"(coefs) : "memory");
-    asm volatile("global_store_dword %0, %1, %2 " FRI_ST_MOD ::"v"(vo1), "v"(v[7]), "s"(coefs) : "memory");
-#endif
 }
 
 // Native vector type on purpose: HIP's uint4 is a struct whose copies become llvm.memcpy, which kept the staging

@@ -56,3 +56,35 @@ for x in range(8):
     m = xcc == x
     if m.any():
         print(f"xcc {x}: {m.sum():4d} wgs  entry {entry[m].min():6.2f}..{entry[m].max():6.2f}  exit {end[m].min():6.2f}..{end[m].max():6.2f}")
+
+# ---- where does the spread come from? ----------------------------------------------------------
+life = end - entry
+for n in sorted(set(n_tiles)):
+    m = n_tiles == n
+    print(f"shares with {n} tiles: {m.sum():4d}  lifetime {pc(life[m])}")
+hw = tr[:, 14] & 0xFFFFFFFF
+cu = (hw >> 8) & 0xF
+sh = (hw >> 12) & 1
+se = (hw >> 13) & 0x7
+key = (xcc * 8 + se) * 32 + sh * 16 + cu
+cu_mean = {}
+for k in np.unique(key):
+    m = key == k
+    cu_mean[int(k)] = (m.sum(), life[m].mean(), life[m].min(), life[m].max())
+cnt = np.array([v[0] for v in cu_mean.values()])
+means = np.array([v[1] for v in cu_mean.values()])
+print(f"{len(cu_mean)} distinct (xcc, se, sh, cu); workgroups per CU min/mean/max {cnt.min()}/{cnt.mean():.2f}/{cnt.max()}")
+print("per-CU mean lifetime   ", pc(means))
+within = np.array([v[3] - v[2] for v in cu_mean.values()])
+print("within-CU max-min      ", pc(within))
+print(f"variance: total {life.var():.2f}, between CUs {np.average((means - life.mean()) ** 2, weights=cnt):.2f}")
+for x in range(8):
+    for s_ in range(8):
+        m = (xcc == x) & (se == s_)
+        if m.any():
+            print(f"xcc {x} se {s_}: {m.sum():3d} wgs on {len(np.unique(key[m])):2d} CUs  lifetime mean {life[m].mean():6.2f} max {life[m].max():6.2f}")
+order = np.argsort(end)
+print("last 12 shares to exit (share id, tiles, entry, exit, xcc/se/cu):")
+for i in order[-12:]:
+    print(f"  share {i:4d} tiles {n_tiles[i]} entry {entry[i]:5.2f} exit {end[i]:6.2f}  {xcc[i]}/{se[i]}/{sh[i]}/{cu[i]}")
+np.save(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"trace_{which}_c{C}.npy"), tr)
