@@ -255,6 +255,28 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.max_wg_tiles = g.max_wg_tiles;
         d.max_wg_cells = g.max_wg_cells;
         d.n_wg = (uint32_t)g.wg_tiles.size() - 1;
+        {
+            void *j = nullptr;
+            if (hipMalloc(&j, 4096) != hipSuccess) {
+                fri_hip_plan_destroy(p);
+                return FRI_HIP_ERR_HIP;
+            }
+            p->owned.push_back(j);
+            d.junk = static_cast<uint8_t *>(j);
+        }
+        {
+            const size_t bytes = (size_t)kPredAccRing * kPredAccWords * sizeof(uint32_t);
+            void *acc = nullptr;
+            if (hipMalloc(&acc, bytes) != hipSuccess || hipMemset(acc, 0, bytes) != hipSuccess) {
+                fri_hip_plan_destroy(p);
+                return FRI_HIP_ERR_HIP;
+            }
+            p->owned.push_back(acc);
+            d.pred_acc = static_cast<uint32_t *>(acc);
+        }
+        d.pred_blocks = (uint32_t)ctx->cu_count;
+        if (env_int("FRI_HIP_PRED_BLOCKS") > 0) d.pred_blocks = (uint32_t)env_int("FRI_HIP_PRED_BLOCKS");
+        d.k2_single_buffered = env_int("FRI_HIP_K2_V1") > 0;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
         d.k3_ablate = env_int("FRI_HIP_K3_ABLATE");

@@ -594,22 +594,82 @@ struct PredArgs {
     int32_t *prediction;
     uint32_t *hist;
     unsigned long long *n_oob;
+    uint8_t *junk_bucket;      // 512 B / 2 KB of plan scratch: where the pipelined K2 writes what the caller does not want
+    int32_t *junk_prediction;
+    unsigned long long *trace; // diagnostic timeline, null in production
+    uint32_t *acc;             // plan scratch, all zero between launches: [kHistBins] counts, then kAccOob (u64), kAccTicket
     uint32_t n_tiles;
     PredictParams pp;
 };
 
+// Histogram hand-over without a memset in front of the kernel (two fill kernels cost ~6 us per call): every workgroup adds
+// its LDS table into the plan's accumulator, then takes a ticket; the workgroup that draws the last ticket moves the totals to
+// the caller's arrays with atomic exchanges, which leaves the accumulator zero for the next launch.
+constexpr int kAccOob = kHistBins, kAccTicket = kHistBins + 2;
+static_assert(kHistBins + 4 == (int)kPredAccWords, "accumulator layout");
+__device__ __forceinline__ void pred_hand_over(const PredArgs &a, const uint32_t *s_hist, uint32_t *s_flag, int tid, int n_threads) {
+    for (int i = tid; i < kHistBins; i += n_threads) {
+        const uint32_t c = s_hist[i];
+        if (c) __hip_atomic_fetch_add(a.acc + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0 && s_hist[kHistBins])
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.acc + kAccOob), (unsigned long long)s_hist[kHistBins], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Order without fences: an agent-scope fence on this multi-XCD part writes back and invalidates the whole L2 (measured:
+    // +80 us per launch). The adds above are device-scope atomics, executed at the coherence point and acknowledged through
+    // vmcnt; __syncthreads() waits for vmcnt(0) in every wave, so all of this workgroup's adds are performed before thread 0
+    // draws the ticket. The last workgroup then reads with device-scope loads, which do not hit a stale L2 line.
+    __syncthreads();
+    if (tid == 0) *s_flag = __hip_atomic_fetch_add(a.acc + kAccTicket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (*s_flag == 0) return;
+    // all other workgroups have finished (their adds precede their tickets): plain coherent loads, all in flight together
+    // (an atomic exchange per bin, one after the other, took 30-60 us), then the zeros for the next launch
+    static_assert(kHistBins % 512 == 0, "unrolled by 512-thread strides");
+    if (n_threads == 1024) {
+        uint32_t v[kHistBins / 1024];
+#pragma unroll
+        for (int k = 0; k < kHistBins / 1024; k++) v[k] = __hip_atomic_load(a.acc + tid + 1024 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < kHistBins / 1024; k++) {
+            a.hist[tid + 1024 * k] = v[k];
+            __hip_atomic_store(a.acc + tid + 1024 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        uint32_t v[kHistBins / 512];
+#pragma unroll
+        for (int k = 0; k < kHistBins / 512; k++) v[k] = __hip_atomic_load(a.acc + tid + 512 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < kHistBins / 512; k++) {
+            a.hist[tid + 512 * k] = v[k];
+            __hip_atomic_store(a.acc + tid + 512 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid == 0) {
+        *a.n_oob = __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(a.acc + kAccOob), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.acc + kAccTicket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---- shared by the gather kernels (K2 and the fit accumulators) -----------------------------------------------------
 // Neighbour halfword offsets of node p relative to the own LDS slot, two per register: out[0] = {k0, k1}, out[1] = {k2, k3},
 // out[2] = {k4, k5} (k = left, up_left, up_right, right, down_left, down_right; context_modeling.rs:37-71).
-__device__ __forceinline__ void pred_node_offsets(const uint16_t *nbr_table, int p, uint32_t (&out)[3]) {
+// Two steps so that a kernel can issue the table loads of all its nodes back to back (one wait instead of one round trip per
+// entry: 48 serialised loads used to open every workgroup of K2): the 12-byte row of node p, then the arithmetic.
+__device__ __forceinline__ void pred_load_row(const uint16_t *nbr_table, int p, uint32_t (&row)[3]) {
+    const uint32_t *r = reinterpret_cast<const uint32_t *>(nbr_table + p * 6); // 12-byte rows: 4-byte aligned
+    row[0] = r[0], row[1] = r[1], row[2] = r[2];
+}
+__device__ __forceinline__ void pred_offsets_from_row(const uint32_t (&row)[3], uint32_t (&out)[3]) {
     uint32_t h[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        const uint32_t e = nbr_table[p * 6 + k];
+        const uint32_t e = (row[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
         const int slot = (e >> 9) & 7; // index into {self, +V9[0..5]} = lattice deltas (0,0),(1,0),(1,-1),(0,-1),(-1,0),(-1,1),(0,1)
-        const int da = slot == 1 || slot == 2 ? 1 : slot == 4 || slot == 5 ? -1 : 0;
-        const int db = slot == 2 || slot == 3 ? -1 : slot == 5 || slot == 6 ? 1 : 0;
-        const int o = (e & 0x8000u) ? 512 : (da * kPredSide + db) * (kSlotStride / 2) + (int)(e & 511u); // 512 = the slot's zero pad
+        // da = +1 for slots 1, 2; -1 for 4, 5.  db = -1 for slots 2, 3; +1 for 5, 6.  As 2-bit fields of constants (0 -> 0, 1 -> +1, 3 -> -1).
+        const int da = (int)((0x0F14u >> (2 * slot)) & 3u), db = (int)((0x14F0u >> (2 * slot)) & 3u);
+        const int sa = (da & 1) - (da & 2), sb = (db & 1) - (db & 2);
+        const int rel = (sa * kPredSide + sb) * (kSlotStride / 2) + (int)(e & 511u);
+        const int o = (e & 0x8000u) ? 512 : rel; // 512 = the slot's zero pad ("never a node")
         h[k] = (uint32_t)o & 0xFFFFu;
     }
     out[0] = h[0] | (h[1] << 16);
@@ -723,12 +783,18 @@ __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(cons
     __shared__ uint32_t s_hist[kHistBins + 2]; // + out-of-alphabet counter + trash bin
     __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
     __shared__ int32_t s_slot_cell[kPredSlots];
+    __shared__ uint32_t s_flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < kHistBins + 2; i += kPredThreads) s_hist[i] = 0;
 
     uint32_t off[8][3]; // neighbour halfword offsets relative to the own slot, loop invariant
+    {
+        uint32_t rows[8][3];
 #pragma unroll
-    for (int i = 0; i < 8; i++) pred_node_offsets(a.nbr_table, lane + 64 * i, off[i]);
+        for (int i = 0; i < 8; i++) pred_load_row(a.nbr_table, lane + 64 * i, rows[i]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) pred_offsets_from_row(rows[i], off[i]);
+    }
 
     const PredTileWalk walk(a.n_tiles);
     for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step) {
@@ -764,11 +830,196 @@ __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(cons
         }
     }
     __syncthreads();
-    for (int i = tid; i < kHistBins; i += kPredThreads) {
-        const uint32_t c = s_hist[i];
-        if (c) atomicAdd(&a.hist[i], c);
+    pred_hand_over(a, s_hist, &s_flag, tid, kPredThreads);
+}
+
+// K2, pipelined form. One 1024-thread workgroup per CU (16 waves = the 16 block cells of a tile), two LDS cell images:
+// while tile i is gathered / predicted out of one image, the 36 cells of tile i + 1 are in flight from HBM/L2 into registers
+// (2-3 cells per wave) and are committed to the other image at the end of the iteration, so a tile costs one barrier and
+// the staging latency overlaps the arithmetic (the single-buffered kernel above leaves the VALU idle 44 % of the time).
+// The slot lists (which cell sits in which LDS slot) run two tiles ahead through a three-entry ring. Bucket and prediction
+// are written once and never read here: nontemporal stores.
+constexpr int kPred2Threads = 1024;
+constexpr int kPred2Waves = kPred2Threads / 64;
+constexpr int kPred2Stage = (kPredSlots + kPred2Waves - 1) / kPred2Waves; // cells staged per wave
+constexpr int kPredCellsBytes = kPredSlots * kSlotStride;
+constexpr int kPredHistBytes = ((kHistBins + 2) * 4 + 15) & ~15;
+constexpr int kPred2LdsBytes = kPredHistBytes + 2 * kPredCellsBytes + 3 * kPredSlots * 4;
+static_assert(kPred2Waves == kPredBlock * kPredBlock, "one wave per block cell");
+
+template <int I, bool INTERIOR>
+__device__ __forceinline__ void predict_node2(const uint8_t *own, int lane, uint32_t o01, uint32_t o23, uint32_t o45, bool some, const PredictParams &pp,
+                                              uint32_t *s_hist, uint8_t *bucket_dst, int32_t *pred_dst) {
+    constexpr int g = I >= 4 ? 0 : I >= 2 ? 1 : 2;
+    const float *wp = pp.width[g], *vp = pp.value[g];
+    const int value = *reinterpret_cast<const short *>(own + 2 * (lane + 64 * I));
+    const int o[6] = {(int)(short)(o01 & 0xFFFFu), (int)o01 >> 16, (int)(short)(o23 & 0xFFFFu), (int)o23 >> 16, (int)(short)(o45 & 0xFFFFu), (int)o45 >> 16};
+    float f[6];
+    int v[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        v[k] = *reinterpret_cast<const short *>(own + 2 * o[k]);
+        f[k] = (float)v[k];
     }
-    if (tid == 0 && s_hist[kHistBins]) atomicAdd(a.n_oob, (unsigned long long)s_hist[kHistBins]);
+    // get_hf_context_bucket, prediction.rs:165-206 (see predict_node)
+    float width = wp[0];
+    width = __fadd_rn(width, __fmul_rn(wp[1], fabsf(__fsub_rn(f[0], f[3]))));
+    width = __fadd_rn(width, __fmul_rn(wp[2], fabsf(__fsub_rn(f[1], f[2]))));
+    width = __fadd_rn(width, __fmul_rn(wp[3], fabsf(__fsub_rn(f[4], f[5]))));
+    width = __fadd_rn(width, __fmul_rn(wp[4], fabsf(__fsub_rn(f[1], f[5]))));
+    width = __fadd_rn(width, __fmul_rn(wp[5], fabsf(__fsub_rn(f[2], f[4]))));
+    uint32_t bucket = assign_bucket(width);
+    float pf = __fmul_rn(f[0], vp[0]);
+    pf = __fadd_rn(pf, __fmul_rn(f[1], vp[1]));
+    pf = __fadd_rn(pf, __fmul_rn(f[2], vp[2]));
+    pf = __fadd_rn(pf, __fmul_rn(f[3], vp[3]));
+    pf = __fadd_rn(pf, __fmul_rn(f[4], vp[4]));
+    pf = __fadd_rn(pf, __fmul_rn(f[5], vp[5]));
+    int prediction = f32_as_i32(pf);
+    if (I == 0) { // heap index 0 (DC) and 1 (root) live in lanes 0, 1: get_lf_context_bucket, prediction.rs:134-144
+        const uint32_t w = (uint32_t)iabs_w(sub_w(v[0], v[2]));
+        const int mx = max(v[0], v[2]), mn = min(v[0], v[2]);
+        const int lf_pred = v[1] >= mx ? mx : v[1] <= mn ? mn : sub_w(add_w(v[0], v[2]), v[1]);
+        const bool lf = lane < 2;
+        bucket = lf ? bucket_of_rt(w) : bucket;
+        prediction = lf ? lf_pred : prediction;
+    }
+    const uint32_t sym = pack_signed(sub_w(value, prediction));
+    uint32_t bin = sym < 1024u ? bucket * 1024u + sym : (uint32_t)kHistBins;
+    if (!INTERIOR) { // a None node goes to the trash bin and stays (0, 0) in the outputs (wavelet_transform.rs:60-64)
+        bin = some ? bin : (uint32_t)kHistBins + 1u;
+        bucket = some ? bucket : 0u;
+        prediction = some ? prediction : 0;
+    }
+    atomicAdd(&s_hist[bin], 1u); // bump_freq, entropy_coding.rs:98-100
+    __builtin_nontemporal_store((uint8_t)bucket, bucket_dst + 64 * I);
+    __builtin_nontemporal_store(prediction, pred_dst + 64 * I);
+}
+
+__global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const PredArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(lds); // 10 x 1024 + out-of-alphabet counter + trash bin
+    uint8_t *s_cells = lds + kPredHistBytes;              // [2][kPredCellsBytes]
+    int32_t *s_ring = reinterpret_cast<int32_t *>(s_cells + 2 * kPredCellsBytes); // [3][kPredSlots]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    trace_stamp(a.trace, blockIdx.x, 0, tid);
+    for (int i = tid; i < kHistBins + 2; i += kPred2Threads) s_hist[i] = 0;
+
+    uint32_t off[8][3]; // neighbour halfword offsets relative to the own slot, loop invariant
+    {
+        uint32_t rows[8][3];
+#pragma unroll
+        for (int i = 0; i < 8; i++) pred_load_row(a.nbr_table, lane + 64 * i, rows[i]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) pred_offsets_from_row(rows[i], off[i]);
+    }
+
+    const PredTileWalk walk(a.n_tiles);
+    if (walk.first < walk.end) { // (a workgroup without a tile still takes part in the hand-over below)
+    const uint32_t last = walk.first + ((walk.end - 1 - walk.first) / walk.step) * walk.step; // this workgroup's last tile
+    const int slot_lane = tid % kPredSlots;
+    if (tid < kPredSlots) {
+        s_ring[tid] = a.pred_slots[(size_t)walk.first * kPredSlots + tid];
+        s_ring[kPredSlots + tid] = a.pred_slots[(size_t)min(walk.first + walk.step, last) * kPredSlots + tid];
+    }
+    __syncthreads();
+    // stage tile 0 straight into image 0
+    for (int sl = wave; sl < kPredSlots; sl += kPred2Waves) {
+        const int cell = s_ring[sl];
+        i32x4 lo = i32x4{0, 0, 0, 0}, hi = lo;
+        if (cell >= 0) {
+            const i32x4 *src = reinterpret_cast<const i32x4 *>(a.coefs + (size_t)cell * kCell + 8 * lane);
+            lo = src[0], hi = src[1];
+        }
+        uint8_t *dst = s_cells + sl * kSlotStride;
+        *reinterpret_cast<u32x4 *>(dst + 16 * lane) = u32x4{__builtin_amdgcn_perm((uint32_t)lo.y, (uint32_t)lo.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)lo.w, (uint32_t)lo.z, 0x05040100u),
+                                                            __builtin_amdgcn_perm((uint32_t)hi.y, (uint32_t)hi.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)hi.w, (uint32_t)hi.z, 0x05040100u)};
+        if (lane == 0) *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    trace_stamp(a.trace, blockIdx.x, 1, tid);
+
+    int it = 0;
+    for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step, it++) {
+        const bool more = tile + walk.step < walk.end;
+        const int32_t *cur_slots = s_ring + (it % 3) * kPredSlots, *nxt_slots = s_ring + ((it + 1) % 3) * kPredSlots;
+        const uint8_t *cur = s_cells + (it & 1) * kPredCellsBytes;
+        uint8_t *nxt = s_cells + ((it & 1) ^ 1) * kPredCellsBytes;
+        // in flight across the arithmetic below: the slot list of tile i + 2 and the cells of tile i + 1
+        const int32_t slot_pre = a.pred_slots[(size_t)min(tile + 2 * walk.step, last) * kPredSlots + slot_lane];
+        i32x4 st_lo[kPred2Stage], st_hi[kPred2Stage];
+        int st_cell[kPred2Stage];
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < kPred2Stage; j++) {
+                const int sl = wave + kPred2Waves * j;
+                if (sl < kPredSlots) {
+                    st_cell[j] = __builtin_amdgcn_readfirstlane(nxt_slots[sl]);
+                    const i32x4 *src = reinterpret_cast<const i32x4 *>(a.coefs + (size_t)max(st_cell[j], 0) * kCell + 8 * lane);
+                    st_lo[j] = src[0], st_hi[j] = src[1];
+                }
+            }
+        }
+
+        { // One block cell per wave. Every path issues exactly 16 stores (a wave without a retained cell at its block slot
+          // writes zeros to the plan's junk lines), so the compiler can count them: the commit below waits for the staging
+          // loads with vmcnt(16) instead of vmcnt(0) and does not sit out the acknowledgement of the stores just issued.
+            const int slot = (1 + wave / kPredBlock) * kPredSide + 1 + (wave % kPredBlock);
+            const int cell = __builtin_amdgcn_readfirstlane(cur_slots[slot]);
+            const bool has = cell >= 0;
+            const uint8_t *own = cur + slot * kSlotStride;
+            uint8_t *bd = (has ? a.bucket + (size_t)cell * kCell : a.junk_bucket) + lane;
+            int32_t *pd = (has ? a.prediction + (size_t)cell * kCell : a.junk_prediction) + lane;
+            if (has && __builtin_amdgcn_readfirstlane((int)a.interior[has ? cell : 0])) {
+                predict_node2<0, true>(own, lane, off[0][0], off[0][1], off[0][2], true, a.pp, s_hist, bd, pd);
+                predict_node2<1, true>(own, lane, off[1][0], off[1][1], off[1][2], true, a.pp, s_hist, bd, pd);
+                predict_node2<2, true>(own, lane, off[2][0], off[2][1], off[2][2], true, a.pp, s_hist, bd, pd);
+                predict_node2<3, true>(own, lane, off[3][0], off[3][1], off[3][2], true, a.pp, s_hist, bd, pd);
+                predict_node2<4, true>(own, lane, off[4][0], off[4][1], off[4][2], true, a.pp, s_hist, bd, pd);
+                predict_node2<5, true>(own, lane, off[5][0], off[5][1], off[5][2], true, a.pp, s_hist, bd, pd);
+                predict_node2<6, true>(own, lane, off[6][0], off[6][1], off[6][2], true, a.pp, s_hist, bd, pd);
+                predict_node2<7, true>(own, lane, off[7][0], off[7][1], off[7][2], true, a.pp, s_hist, bd, pd);
+            } else { // boundary cell: Some/None of node lane + 64 i is bit (lane & 31) of mask word 2 i + (lane >> 5)
+                uint32_t some_bits = 0;
+                if (has) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) some_bits |= ((a.valid_mask[(size_t)cell * 16 + 2 * i + (lane >> 5)] >> (lane & 31)) & 1u) << i;
+                }
+                predict_node2<0, false>(own, lane, off[0][0], off[0][1], off[0][2], some_bits & 1u, a.pp, s_hist, bd, pd);
+                predict_node2<1, false>(own, lane, off[1][0], off[1][1], off[1][2], some_bits & 2u, a.pp, s_hist, bd, pd);
+                predict_node2<2, false>(own, lane, off[2][0], off[2][1], off[2][2], some_bits & 4u, a.pp, s_hist, bd, pd);
+                predict_node2<3, false>(own, lane, off[3][0], off[3][1], off[3][2], some_bits & 8u, a.pp, s_hist, bd, pd);
+                predict_node2<4, false>(own, lane, off[4][0], off[4][1], off[4][2], some_bits & 16u, a.pp, s_hist, bd, pd);
+                predict_node2<5, false>(own, lane, off[5][0], off[5][1], off[5][2], some_bits & 32u, a.pp, s_hist, bd, pd);
+                predict_node2<6, false>(own, lane, off[6][0], off[6][1], off[6][2], some_bits & 64u, a.pp, s_hist, bd, pd);
+                predict_node2<7, false>(own, lane, off[7][0], off[7][1], off[7][2], some_bits & 128u, a.pp, s_hist, bd, pd);
+            }
+        }
+
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < kPred2Stage; j++) {
+                const int sl = wave + kPred2Waves * j;
+                if (sl < kPredSlots) {
+                    i32x4 lo = st_lo[j], hi = st_hi[j];
+                    if (st_cell[j] < 0) lo = hi = i32x4{0, 0, 0, 0}; // no retained cell at this slot: the reference reads 0 there
+                    uint8_t *dst = nxt + sl * kSlotStride;
+                    *reinterpret_cast<u32x4 *>(dst + 16 * lane) = u32x4{__builtin_amdgcn_perm((uint32_t)lo.y, (uint32_t)lo.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)lo.w, (uint32_t)lo.z, 0x05040100u),
+                                                                        __builtin_amdgcn_perm((uint32_t)hi.y, (uint32_t)hi.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)hi.w, (uint32_t)hi.z, 0x05040100u)};
+                    if (lane == 0) *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        }
+        if (tid < kPredSlots) s_ring[((it + 2) % 3) * kPredSlots + tid] = slot_pre;
+        lds_barrier();
+        trace_stamp(a.trace, blockIdx.x, 2 + it, tid);
+    }
+    }
+    __syncthreads();
+    trace_stamp(a.trace, blockIdx.x, 13, tid);
+    pred_hand_over(a, s_hist, reinterpret_cast<uint32_t *>(s_ring), tid, kPred2Threads);
+    trace_exit(a.trace, blockIdx.x, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -814,9 +1065,13 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
     // they would not fit 128 VGPRs, and this kernel is not on the critical path. The map is per lane, identical in all waves.
     __shared__ uint32_t s_off[8][64][3];
     if (wave == 0) {
+        uint32_t rows[8][3];
+#pragma unroll
+        for (int i = 0; i < 8; i++) pred_load_row(a.nbr_table, p0 + pstep * i, rows[i]);
+#pragma unroll
         for (int i = 0; i < 8; i++) {
             uint32_t o[3];
-            pred_node_offsets(a.nbr_table, p0 + pstep * i, o);
+            pred_offsets_from_row(rows[i], o);
             s_off[i][lane][0] = o[0];
             s_off[i][lane][1] = o[1];
             s_off[i][lane][2] = o[2];
@@ -1250,11 +1505,10 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
 
 hipError_t launch_predict_histogram(const DevicePlan &p, const int32_t *coefs_channel, const PredictParams &pp, uint8_t *bucket,
                                     int32_t *prediction, uint32_t *hist, unsigned long long *n_oob, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(hist, 0, kHistBins * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(n_oob, 0, sizeof(unsigned long long), stream);
-    if (e != hipSuccess) return e;
+    if (!p.pred_acc) return hipErrorInvalidValue;
+    hipError_t e = hipSuccess;
     PredArgs a{};
+    a.acc = p.pred_acc + (size_t)(p.pred_seq++ % kPredAccRing) * kPredAccWords; // one accumulator per launch in flight
     a.coefs = coefs_channel;
     a.pred_slots = p.pred_slots;
     a.nbr_table = p.nbr_table;
@@ -1266,9 +1520,20 @@ hipError_t launch_predict_histogram(const DevicePlan &p, const int32_t *coefs_ch
     a.n_oob = n_oob;
     a.n_tiles = p.n_pred_tiles;
     a.pp = pp;
-    uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
+    if (p.k2_single_buffered || !bucket || !prediction) { // optional outputs: the single-buffered kernel skips the stores of a NULL output
+        uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
+        if (!blocks) blocks = 1;
+        hipLaunchKernelGGL(predict_histogram_kernel, dim3(blocks), dim3(kPredThreads), 0, stream, a);
+        return hipGetLastError();
+    }
+    uint32_t blocks = p.n_pred_tiles < p.pred_blocks ? p.n_pred_tiles : p.pred_blocks;
     if (!blocks) blocks = 1;
-    hipLaunchKernelGGL(predict_histogram_kernel, dim3(blocks), dim3(kPredThreads), 0, stream, a);
+    a.junk_bucket = p.junk;
+    a.trace = p.trace;
+    a.junk_prediction = reinterpret_cast<int32_t *>(p.junk + 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(predict_histogram_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, kPred2LdsBytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(predict_histogram_kernel2, dim3(blocks), dim3(kPred2Threads), kPred2LdsBytes, stream, a);
     return hipGetLastError();
 }
 

@@ -30,6 +30,11 @@ struct DevicePlan {
     uint32_t *hist_partial = nullptr;     // [hist_blocks][10*1024] scratch for the histogram reduction
     unsigned long long *oob_partial = nullptr; // [hist_blocks]
     uint32_t hist_blocks = 0;
+    uint8_t *junk = nullptr;              // 4 KB: output lines of block slots without a cell (pipelined K2)
+    uint32_t *pred_acc = nullptr;         // [kPredAccRing][kPredAccWords] K2 histogram accumulators, all zero between launches
+    mutable uint32_t pred_seq = 0;
+    uint32_t pred_blocks = 0;             // workgroups of the pipelined K2: one 1024-thread workgroup per CU
+    bool k2_single_buffered = false;      // FRI_HIP_K2_V1=1: the earlier single-buffered K2 (A/B)
     uint32_t n_tiles = 0;
     uint32_t F = 0;
     int32_t width = 0, height = 0, channels = 0;
@@ -38,6 +43,8 @@ struct DevicePlan {
     unsigned long long *trace = nullptr; // [n_wg][16] diagnostic timeline (FRI_HIP_TRACE=1), else null
     int32_t k3_ablate = 0; // same for the inverse kernel, see InvArgs::ablate
 };
+
+constexpr uint32_t kPredAccRing = 8, kPredAccWords = 10 * 1024 + 4;
 
 struct QMatrix {
     int32_t q[32];
