@@ -189,6 +189,9 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
     tp.band_rows = env_int("FRI_HIP_BAND_ROWS");
     tp.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
     tp.cells_per_wg = env_int("FRI_HIP_CELLS_PER_WG");
+    // LDS budget of one forward tile buffer: 4 chunks of 16 bytes per thread for planes (the tuned variant), 6 for RGB
+    tp.tile_buffer_bytes = (channels == 1 ? 4 : 6) * 256 * 16;
+    if (env_int("FRI_HIP_TILE_BYTES") > 0) tp.tile_buffer_bytes = env_int("FRI_HIP_TILE_BYTES");
     // Shares by dispatch rank, measured on MI355X at 4096^2 (tools/sweep_rank_weights.sh): equal shares 22.3-23.4 us,
     // these weights 20.5-21.7 us; steeper is worse again. Host-only plans keep equal shares.
     if (ctx) tp.rank_weight[0] = 1.3f, tp.rank_weight[1] = 1.1f, tp.rank_weight[2] = 0.9f, tp.rank_weight[3] = 0.7f;

@@ -396,6 +396,18 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         for (size_t sh = 1; sh <= n_wg; sh++) // every share keeps at least one cell (n_wg <= F)
             bound[sh] = std::min(std::max(bound[sh], bound[sh - 1] + 1), F - (n_wg - sh));
     }
+    // Widest tile the LDS budget allows: the largest pitch = 8 or 24 (mod 32 dwords) with rows * pitch <= budget, minus the
+    // 30 bytes of lead-in / round-up. Cells of a run are sorted by x.
+    int width_cap = INT_MAX;
+    if (tp.tile_buffer_bytes > 0) {
+        int pitch = (tp.tile_buffer_bytes / (band_rows + 20)) / 16 * 16;
+        while (pitch > 0 && ((pitch / 4) % 32) != 8 && ((pitch / 4) % 32) != 24) pitch -= 16;
+        width_cap = std::max(46, (pitch - 30) / (int)channels); // a single cell (46 px) must always fit
+    }
+    auto width_of = [&](size_t a, size_t b2) {
+        const int x0 = std::max(g.centers[order[a]].x - 15, 0), x1 = std::min(g.centers[order[b2 - 1]].x + 30, W - 1);
+        return x1 - x0 + 1;
+    };
     g.wg_tiles.push_back(0);
     for (size_t sh = 0; sh < n_wg; sh++) {
         const size_t s0 = bound[sh], s1 = bound[sh + 1];
@@ -406,7 +418,18 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
             const int b = band(order[i]);
             while (j < s1 && band(order[j]) == b) j++;
             const size_t m = j - i, n_t = (m + cells_per_tile - 1) / cells_per_tile;
-            for (size_t t = 0; t < n_t; t++) emit_tile(i + m * t / n_t, i + m * (t + 1) / n_t);
+            bool fits = true;
+            for (size_t t = 0; t < n_t && fits; t++) fits = width_of(i + m * t / n_t, i + m * (t + 1) / n_t) <= width_cap;
+            if (fits) {
+                for (size_t t = 0; t < n_t; t++) emit_tile(i + m * t / n_t, i + m * (t + 1) / n_t);
+            } else { // a sparse band: greedy, as many cells as the width cap allows (always at least one)
+                for (size_t a = i; a < j;) {
+                    size_t b2 = a + 1;
+                    while (b2 < j && b2 - a < (size_t)cells_per_tile && width_of(a, b2 + 1) <= width_cap) b2++;
+                    emit_tile(a, b2);
+                    a = b2;
+                }
+            }
             i = j;
         }
         g.max_wg_tiles = std::max(g.max_wg_tiles, (int32_t)g.tiles.size() - g.wg_tiles.back());

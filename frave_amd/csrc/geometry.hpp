@@ -88,6 +88,9 @@ struct TilingParams {
     // Relative share size by dispatch rank (workgroup b has rank min(4 b / target_wgs, 3): the r-th workgroup placed on its CU).
     // The CU's arbiter favours older waves, so later workgroups progress more slowly and get fewer cells. {0,..} = equal shares.
     float rank_weight[4] = {0, 0, 0, 0};
+    // Bytes one LDS tile buffer may take (rows * pitch); tiles of sparse bands (the image's last rows) are cut narrower
+    // instead of sizing every buffer for them. 0 = no cap.
+    int tile_buffer_bytes = 0;
 };
 
 // Returns "" on success, else an error string.
