@@ -263,16 +263,18 @@ class Plan:
         _check(load_library().fri_hip_transform_quant_batch(self._h, n, pin, _p(q), pout), "fri_hip_transform_quant_batch", self.ctx)
         return outs
 
-    def predict_histogram(self, coefs, channel, value_params, width_params):
+    def predict_histogram(self, coefs, channel, value_params, width_params, want_bucket=True, want_prediction=True):
+        """(bucket, prediction, hist, n_out_of_alphabet); an output that is not wanted is passed as NULL and returned as None."""
         co = np.ascontiguousarray(coefs, np.int32)
         assert co.size == self.coef_count
         vp = np.ascontiguousarray(value_params, np.float32).reshape(3, 6)
         wp = np.ascontiguousarray(width_params, np.float32).reshape(3, 6)
-        bucket = np.empty((self.num_cells, 512), np.uint8)
-        pred = np.empty((self.num_cells, 512), np.int32)
+        bucket = np.empty((self.num_cells, 512), np.uint8) if want_bucket else None
+        pred = np.empty((self.num_cells, 512), np.int32) if want_prediction else None
         hist = np.empty((10, 1024), np.uint32)
         oob = C.c_uint64(0)
-        _check(load_library().fri_hip_predict_histogram(self._h, _p(co), channel, _p(vp), _p(wp), _p(bucket), _p(pred), _p(hist), C.addressof(oob)),
+        _check(load_library().fri_hip_predict_histogram(self._h, _p(co), channel, _p(vp), _p(wp), _p(bucket) if want_bucket else None,
+                                                        _p(pred) if want_prediction else None, _p(hist), C.addressof(oob)),
                "fri_hip_predict_histogram", self.ctx)
         return bucket, pred, hist, oob.value
 

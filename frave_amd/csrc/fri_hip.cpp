@@ -454,8 +454,8 @@ int fri_hip_predict_histogram(fri_hip_plan *p, const int32_t *coefs, uint32_t ch
     if (int rc = ensure_staging(p)) return rc;
     const size_t F = p->geo.centers.size();
     HIP_TRY(p->ctx, hipMemcpy(p->d_coefs, coefs, fri_hip_plan_coef_count(p) * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (int rc = fri_hip_predict_histogram_dev(p, p->d_coefs, channel, value_params, width_params, p->d_bucket, p->d_prediction, p->d_hist,
-                                               (uint64_t *)p->d_oob, nullptr))
+    if (int rc = fri_hip_predict_histogram_dev(p, p->d_coefs, channel, value_params, width_params, bucket ? p->d_bucket : nullptr,
+                                               prediction ? p->d_prediction : nullptr, p->d_hist, (uint64_t *)p->d_oob, nullptr))
         return rc;
     HIP_TRY(p->ctx, hipMemcpy(hist, p->d_hist, 10 * 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (bucket) HIP_TRY(p->ctx, hipMemcpy(bucket, p->d_bucket, F * kCell, hipMemcpyDeviceToHost));

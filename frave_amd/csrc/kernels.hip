@@ -696,10 +696,31 @@ struct PredTileWalk {
     }
 };
 
+// The LDS images hold coefficients as int16. Every coefficient the forward kernel produces fits (|v| <= 255 before the
+// quantiser divides), but the ABI takes any int32 array: a Some value outside [-32768, 32767] cannot be staged, so it is
+// counted as out of alphabet (what the caller must treat as "the reference would not have produced a stream": its symbol
+// |value - prediction| could only stay below 1024 if the predictor tracked such values). Cheap common case: one and-or per
+// value; only a wave that sees a None or an outlier does the exact count.
+__device__ __forceinline__ uint32_t pred_count_outliers(const int (&v)[8]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) m |= ((uint32_t)v[i] + 0x8000u) & 0xFFFF0000u;
+    if (!__any(m != 0)) return 0;
+    uint32_t n = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) n += (v[i] != kNone && v[i] != (int)(short)v[i]) ? 1u : 0u;
+    return n;
+}
+__device__ __forceinline__ bool pred_is_block_slot(int slot) {
+    const int r = slot / kPredSide, c = slot - r * kPredSide;
+    return r >= 1 && r <= kPredBlock && c >= 1 && c <= kPredBlock;
+}
+
 // Stages the 36 cells of a tile: 64 lanes x 8 coefficients per cell, int32 -> int16 by truncation. Every Some coefficient
 // fits, and None (INT32_MIN = 0x80000000) truncates to 0, which is what the reference's .unwrap_or(0) reads; a slot without
 // a retained cell is all zeros. One v_perm_b32 packs two low halves.
-__device__ __forceinline__ void pred_stage_tile(const int32_t *__restrict__ coefs, const int32_t *s_slot_cell, uint8_t *s_cells, int lane, int wave) {
+__device__ __forceinline__ void pred_stage_tile(const int32_t *__restrict__ coefs, const int32_t *s_slot_cell, uint8_t *s_cells, int lane, int wave,
+                                                uint32_t *outlier_counter = nullptr) {
     for (int slot = wave; slot < kPredSlots; slot += kPredWaves) {
         const int cell = s_slot_cell[slot];
         int4 lo = make_int4(0, 0, 0, 0), hi = lo;
@@ -707,6 +728,11 @@ __device__ __forceinline__ void pred_stage_tile(const int32_t *__restrict__ coef
             const int4 *src = reinterpret_cast<const int4 *>(coefs + (size_t)cell * kCell + 8 * lane);
             lo = src[0];
             hi = src[1];
+            if (outlier_counter && pred_is_block_slot(slot)) { // every cell is a block cell of exactly one tile
+                const int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const uint32_t n = pred_count_outliers(v);
+                if (n) atomicAdd(outlier_counter, n);
+            }
         }
         auto pk = [](int lo16, int hi16) -> uint32_t { return __builtin_amdgcn_perm((uint32_t)hi16, (uint32_t)lo16, 0x05040100u); };
         uint4 packed;
@@ -801,7 +827,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(cons
         __syncthreads(); // everyone is done with the previous tile's LDS image (and the histogram is zeroed on the first pass)
         if (tid < kPredSlots) s_slot_cell[tid] = a.pred_slots[(size_t)tile * kPredSlots + tid];
         __syncthreads();
-        pred_stage_tile(a.coefs, s_slot_cell, s_cells, lane, wave);
+        pred_stage_tile(a.coefs, s_slot_cell, s_cells, lane, wave, &s_hist[kHistBins]);
         __syncthreads();
 
         for (int r = wave; r < kPredBlock * kPredBlock; r += kPredWaves) { // two block cells per wave
@@ -931,6 +957,11 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
         if (cell >= 0) {
             const i32x4 *src = reinterpret_cast<const i32x4 *>(a.coefs + (size_t)cell * kCell + 8 * lane);
             lo = src[0], hi = src[1];
+            if (pred_is_block_slot(sl)) {
+                const int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const uint32_t n = pred_count_outliers(v);
+                if (n) atomicAdd(&s_hist[kHistBins], n);
+            }
         }
         uint8_t *dst = s_cells + sl * kSlotStride;
         *reinterpret_cast<u32x4 *>(dst + 16 * lane) = u32x4{__builtin_amdgcn_perm((uint32_t)lo.y, (uint32_t)lo.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)lo.w, (uint32_t)lo.z, 0x05040100u),
@@ -1003,7 +1034,13 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
                 const int sl = wave + kPred2Waves * j;
                 if (sl < kPredSlots) {
                     i32x4 lo = st_lo[j], hi = st_hi[j];
-                    if (st_cell[j] < 0) lo = hi = i32x4{0, 0, 0, 0}; // no retained cell at this slot: the reference reads 0 there
+                    if (st_cell[j] < 0) {
+                        lo = hi = i32x4{0, 0, 0, 0}; // no retained cell at this slot: the reference reads 0 there
+                    } else if (pred_is_block_slot(sl)) {
+                        const int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        const uint32_t n = pred_count_outliers(v);
+                        if (n) atomicAdd(&s_hist[kHistBins], n);
+                    }
                     uint8_t *dst = nxt + sl * kSlotStride;
                     *reinterpret_cast<u32x4 *>(dst + 16 * lane) = u32x4{__builtin_amdgcn_perm((uint32_t)lo.y, (uint32_t)lo.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)lo.w, (uint32_t)lo.z, 0x05040100u),
                                                                         __builtin_amdgcn_perm((uint32_t)hi.y, (uint32_t)hi.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)hi.w, (uint32_t)hi.z, 0x05040100u)};

@@ -126,7 +126,10 @@ int fri_hip_transform_quant_batch(fri_hip_plan *plan, uint32_t n_images, const u
  * group 0 = level 8, 1 = level 7, 2 = levels 1..6 (prediction.rs:165-179).
  * coefs is the whole [channels][F][512] array (quantised); `channel` selects the plane.
  * hist is overwritten. Symbols >= 1024 (Rust: index panic, entropy_coding.rs:99) are not
- * histogrammed; their count is returned in *n_out_of_alphabet. bucket/prediction may be NULL. */
+ * histogrammed; their count is returned in *n_out_of_alphabet. bucket/prediction may be NULL.
+ * The kernel holds coefficients as int16 (every output of fri_hip_transform_quant fits): a Some
+ * coefficient outside [-32768, 32767] is also counted in *n_out_of_alphabet, and outputs that depend
+ * on it are unspecified. *n_out_of_alphabet == 0 means: every output is what libfri computes. */
 int fri_hip_predict_histogram(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, const float value_params[3][6],
                               const float width_params[3][6], uint8_t *bucket, int32_t *prediction, uint32_t *hist,
                               uint64_t *n_out_of_alphabet);
