@@ -147,7 +147,10 @@ int fri_hip_predict_histogram_dev(fri_hip_plan *plan, const int32_t *d_coefs, ui
  * Layer groups g: 0 = level 8, 1 = level 7, 2 = levels 1..6 (matrices[0..2], :87-96). Rows exist for Some coefficients of
  * heap index >= 2 only; None rows are all zero in the reference (:109-134).
  * gram[g][28] = upper triangle (row major) of sum u u^T with u = [v0..v5, value], v = get_neighbour_values:
- *              A^T A = rows/columns 0..5, A^T b = column 6, b^T b = entry (6,6). Exact integers. */
+ *              A^T A = rows/columns 0..5, A^T b = column 6, b^T b = entry (6,6). Exact integers.
+ * Precondition (both fit entry points): Some coefficients lie in [-32768, 32767], as every output of
+ * fri_hip_transform_quant does; the kernels stage them as int16 like fri_hip_predict_histogram, whose
+ * n_out_of_alphabet reports a violation. */
 int fri_hip_fit_value_sums(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, int64_t gram[3][28]);
 int fri_hip_fit_value_sums_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint32_t channel, int64_t *d_gram, void *stream);
 /* Width fit (optimize_width_prediction, :144-173) for given value parameters x: residual r = |f32(value) - A x| in f32
