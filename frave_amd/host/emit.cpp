@@ -1,0 +1,371 @@
+// emit.cpp -- see emit.hpp. Citations are relative to /root/reference/crates/libfri/src/.
+#include "emit.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "../csrc/geometry.hpp"
+
+namespace libfri {
+namespace emit {
+
+// ---- symbol order ---------------------------------------------------------------------------------------------------
+std::vector<uint32_t> symbol_order(const int32_t *centers, uint32_t n_cells, int level) {
+    std::vector<uint32_t> out;
+    if (level < 0 || level >= kDepth || !n_cells) return out;
+    const fri::StaticTables &st = fri::static_tables();
+    fri::Int2 nv[6];
+    fri::nearby_vectors(kDepth - level, nv);
+    const fri::Int2 row = nv[3], col = nv[1];
+    // normal of the scan lines, pointing the way the reference advances from line to line (row_dir, :513-517, :619-628)
+    int64_t nx = -col.y, ny = col.x;
+    if ((int64_t)row.x * nx + (int64_t)row.y * ny < 0) nx = -nx, ny = -ny;
+    // offset of node i of `level` from its cell centre (Fractal::new, :42-69): child 2p+1 of a level-v node adds LITERALS[8 - v]
+    const uint32_t per_cell = 1u << level;
+    std::vector<fri::Int2> node_off(per_cell);
+    for (uint32_t i = 0; i < per_cell; i++) {
+        fri::Int2 o{0, 0};
+        for (int j = 0; j < level; j++)
+            if (i >> j & 1) o = {o.x + st.literals[kDepth - level + j].x, o.y + st.literals[kDepth - level + j].y};
+        node_off[i] = o;
+    }
+    struct Key {
+        int64_t line, along;
+        uint32_t id;
+    };
+    std::vector<Key> keys((size_t)n_cells * per_cell);
+    for (uint32_t c = 0; c < n_cells; c++)
+        for (uint32_t i = 0; i < per_cell; i++) {
+            const int64_t x = (int64_t)centers[2 * c] + node_off[i].x, y = (int64_t)centers[2 * c + 1] + node_off[i].y;
+            keys[(size_t)c * per_cell + i] = Key{x * nx + y * ny, x * col.x + y * col.y, c << 9 | (per_cell + i)};
+        }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) { return a.line != b.line ? a.line < b.line : a.along < b.along; });
+    out.resize(keys.size());
+    for (size_t k = 0; k < keys.size(); k++) out[k] = keys[k].id;
+    return out;
+}
+
+// ---- small helpers ----------------------------------------------------------------------------------------------------
+float width_from_bucket(int bucket) {
+    static const float w[kContexts] = {2.5f, 4.5f, 6.3f, 8.5f, 12.7f, 16.f, 20.f, 24.f, 28.f, 36.f};
+    return bucket >= 0 && bucket < kContexts ? w[bucket] : 50.f;
+}
+uint32_t pack_signed(int32_t k) { return ((uint32_t)k << 1) ^ (uint32_t)(k >> 31); }
+int32_t unpack_signed(uint32_t k) { return (k & 1u) ? (int32_t)(k + 1) / -2 : (int32_t)(k / 2); }
+
+namespace {
+// utils.rs:5-14 (the or-cascade stops at 16: exact below 2^32, which is all a u32 sum can reach)
+uint64_t prev_power_two(uint64_t x) {
+    uint64_t n = x;
+    n |= n >> 1, n |= n >> 2, n |= n >> 4, n |= n >> 8, n |= n >> 16;
+    return n ^ (n >> 1);
+}
+uint32_t trailing_zeros64(uint64_t x) { return x ? (uint32_t)__builtin_ctzll(x) : 64u; }
+// `1 << bits` on a 32-bit integer in a release build: the shift amount wraps modulo 32 (debug builds panic from 32 up)
+uint32_t shl1_release(uint32_t bits) { return 1u << (bits & 31u); }
+// Rust `f32 as u32`: truncating, saturating, NaN -> 0
+uint32_t f32_as_u32(float v) {
+    if (!(v > 0.0f)) return 0;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+} // namespace
+
+// ---- AnsContext -----------------------------------------------------------------------------------------------------
+std::string AnsContext::finalize(int bucket) {
+    if (max_freq_bits < 8) max_freq_bits = 8; // :103-105
+    // fill_with_laplace, :82-96. f32 throughout; `exp` is the platform libm's expf, as it is for the reference.
+    const float width = width_from_bucket(bucket);
+    const float scale = (float)(int32_t)shl1_release(max_freq_bits);
+    for (int j = 0; j < kAlphabet; j++) {
+        const float x = (float)unpack_signed((uint32_t)j);
+        const float lap = std::exp(-std::fabs(x - 0.0f) / width) / (2.0f * width); // prediction.rs:219-221
+        const uint32_t lv = f32_as_u32(lap * scale);
+        uint32_t &f = freqs[j];
+        if (lv == 0 && f == 0 && std::find(off_distribution_values.begin(), off_distribution_values.end(), (uint16_t)j) != off_distribution_values.end()) {
+            f = 1;
+        } else if (f != 0 && lv == 0) {
+            f = 1;
+            off_distribution_values.push_back((uint16_t)j);
+        } else {
+            f = lv;
+        }
+    }
+    // normalize_freqs(1 << max_freq_bits), :119-159
+    const uint32_t target = shl1_release(max_freq_bits);
+    std::array<uint32_t, kAlphabet> cum{};
+    {
+        uint32_t acc = 0;
+        for (int i = 0; i < kAlphabet; i++) {
+            cum[i] = acc;
+            acc += freqs[i];
+        }
+    }
+    const uint32_t cur_total = cum[kAlphabet - 1] + freqs[kAlphabet - 1];
+    if (cur_total == 0) return "empty context: libfri divides by zero here (entropy_coding.rs:123)";
+    for (int i = 1; i < kAlphabet; i++) cum[i] = (uint32_t)(((uint64_t)target * cum[i]) / cur_total);
+    for (int i = 0; i < kAlphabet - 1; i++) { // a used symbol whose slot collapsed steals one count from the smallest slot > 1
+        if (freqs[i] != 0 && cum[i + 1] == cum[i]) {
+            uint32_t best_freq = 0xFFFFFFFFu;
+            int best = -1;
+            for (int j = 0; j < kAlphabet - 1; j++) {
+                const uint32_t f = cum[j + 1] - cum[j];
+                if (f > 1 && f < best_freq) best_freq = f, best = j;
+            }
+            if (best < 0) continue;
+            if (best < i)
+                for (int j = best + 1; j <= i; j++) cum[j] -= 1;
+            else
+                for (int j = i + 1; j <= best; j++) cum[j] += 1;
+        }
+    }
+    for (int i = 0; i < kAlphabet - 1; i++) freqs[i] = cum[i + 1] - cum[i];
+    freqs[kAlphabet - 1] = cum[kAlphabet - 1] - target; // :156 as written (wraps in a release build unless the last slot is empty)
+    cdf = cum;
+    uint64_t sum = 0; // `iter().sum::<u32>()` wraps in a release build
+    for (uint32_t f : freqs) sum = (uint32_t)(sum + f);
+    max_freq_bits = trailing_zeros64(prev_power_two(sum)); // :113-114
+    return "";
+}
+
+// ---- rANS (ryg_rans rans64: state in [2^31, 2^63), 32-bit renormalisation) ----------------------------------------------
+void RansEncoderMulti::put_at(int s, uint32_t start, uint32_t freq, uint32_t scale_bits) {
+    uint64_t x = x_[s];
+    const uint64_t x_max = ((((uint64_t)1 << 31) >> scale_bits) << 32) * freq;
+    if (x >= x_max) {
+        rev_.push_back((uint32_t)x);
+        x >>= 32;
+    }
+    x_[s] = ((x / freq) << scale_bits) + (x % freq) + start;
+}
+void RansEncoderMulti::flush_all() {
+    for (int s = 0; s < kContexts; s++) { // each flush prepends two words: state kContexts-1 ends up first in the stream
+        rev_.push_back((uint32_t)(x_[s] >> 32));
+        rev_.push_back((uint32_t)x_[s]);
+    }
+}
+std::vector<uint8_t> RansEncoderMulti::data() const {
+    std::vector<uint8_t> out(rev_.size() * 4);
+    for (size_t i = 0; i < rev_.size(); i++) {
+        const uint32_t w = rev_[rev_.size() - 1 - i];
+        out[4 * i] = (uint8_t)w, out[4 * i + 1] = (uint8_t)(w >> 8), out[4 * i + 2] = (uint8_t)(w >> 16), out[4 * i + 3] = (uint8_t)(w >> 24);
+    }
+    return out;
+}
+RansDecoderMulti::RansDecoderMulti(const std::vector<uint8_t> &d) {
+    w_.resize(d.size() / 4);
+    for (size_t i = 0; i < w_.size(); i++) w_[i] = (uint32_t)d[4 * i] | (uint32_t)d[4 * i + 1] << 8 | (uint32_t)d[4 * i + 2] << 16 | (uint32_t)d[4 * i + 3] << 24;
+    for (int s = 0; s < kContexts; s++) {
+        if (pos_ + 2 > w_.size()) {
+            ok_ = false;
+            x_[s] = 1ull << 31;
+            continue;
+        }
+        x_[s] = (uint64_t)w_[pos_] | (uint64_t)w_[pos_ + 1] << 32;
+        pos_ += 2;
+    }
+}
+uint32_t RansDecoderMulti::get_at(int s, uint32_t scale_bits) const { return (uint32_t)(x_[s] & (((uint64_t)1 << scale_bits) - 1)); }
+void RansDecoderMulti::advance_at(int s, uint32_t start, uint32_t freq, uint32_t scale_bits) {
+    const uint64_t mask = ((uint64_t)1 << scale_bits) - 1;
+    uint64_t x = x_[s];
+    x = (uint64_t)freq * (x >> scale_bits) + (x & mask) - start;
+    if (x < (1ull << 31)) {
+        if (pos_ < w_.size())
+            x = (x << 32) | w_[pos_++];
+        else
+            ok_ = false;
+    }
+    x_[s] = x;
+}
+
+// ---- one channel -------------------------------------------------------------------------------------------------------
+void channel_symbols(const int32_t *centers, uint32_t n_cells, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction,
+                     std::vector<uint16_t> &symbols, std::vector<uint8_t> &buckets) {
+    symbols.clear();
+    buckets.clear();
+    auto push = [&](uint32_t cell, uint32_t heap) {
+        const size_t at = (size_t)cell * kNodes + heap;
+        if (coefs[at] == kNone) return; // `if let Some(value)`, entropy_coding.rs:288, :300, :317
+        symbols.push_back((uint16_t)pack_signed((int32_t)((uint32_t)coefs[at] - (uint32_t)prediction[at])));
+        buckets.push_back(bucket[at]);
+    };
+    const std::vector<uint32_t> cells = symbol_order(centers, n_cells, 0);
+    for (uint32_t e : cells) push(e >> 9, 0); // first scan: DC
+    for (uint32_t e : cells) push(e >> 9, 1); // second scan: root
+    for (int level = 1; level < kDepth; level++)
+        for (uint32_t e : symbol_order(centers, n_cells, level)) push(e >> 9, e & 511u);
+}
+
+std::string encode_channel(const int32_t *centers, uint32_t n_cells, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction, const uint32_t *hist,
+                           ChannelStream &out) {
+    for (int b = 0; b < kContexts; b++) { // prediction.rs:302-305
+        AnsContext &c = out.contexts[b];
+        uint64_t sum = 0;
+        for (int j = 0; j < kAlphabet; j++) {
+            c.freqs[j] = hist[b * kAlphabet + j];
+            sum = (uint32_t)(sum + c.freqs[j]);
+        }
+        c.off_distribution_values.clear();
+        c.max_freq_bits = trailing_zeros64(prev_power_two(sum));
+        const std::string err = c.finalize(b);
+        if (!err.empty()) return "context " + std::to_string(b) + ": " + err;
+    }
+    std::vector<uint16_t> symbols;
+    std::vector<uint8_t> buckets;
+    channel_symbols(centers, n_cells, coefs, bucket, prediction, symbols, buckets);
+    RansEncoderMulti enc;
+    for (size_t k = symbols.size(); k-- > 0;) { // fed in reverse, :332-334
+        const AnsContext &c = out.contexts[buckets[k]];
+        const uint32_t sym = symbols[k];
+        if (sym >= (uint32_t)kAlphabet) return "symbol outside the alphabet (libfri panics, entropy_coding.rs:99)";
+        if (c.freqs[sym] == 0) return "symbol with zero model frequency";
+        enc.put_at(buckets[k], c.cdf[sym], c.freqs[sym], c.max_freq_bits);
+    }
+    enc.flush_all();
+    out.data = enc.data();
+    out.n_symbols = symbols.size();
+    return "";
+}
+
+std::string decode_symbols(const ChannelStream &s, const std::vector<uint8_t> &buckets, std::vector<uint16_t> &symbols) {
+    RansDecoderMulti dec(s.data);
+    symbols.resize(buckets.size());
+    for (size_t k = 0; k < buckets.size(); k++) {
+        const int b = buckets[k];
+        if (b < 0 || b >= kContexts) return "bucket out of range";
+        const AnsContext &c = s.contexts[b];
+        const int state = kContexts - b - 1; // entropy_coding.rs:239
+        const uint32_t v = dec.get_at(state, c.max_freq_bits);
+        // the slot containing v: the last symbol with cdf <= v and a non-empty slot (find_nearest_or_equal + the skip loop, :244-256)
+        int sym = (int)(std::upper_bound(c.cdf.begin(), c.cdf.end(), v) - c.cdf.begin()) - 1;
+        if (sym < 0 || c.freqs[sym] == 0) return "stream does not match the model";
+        dec.advance_at(state, c.cdf[sym], c.freqs[sym], c.max_freq_bits);
+        if (!dec.ok()) return "stream truncated";
+        symbols[k] = (uint16_t)sym;
+    }
+    return "";
+}
+
+// ---- container ---------------------------------------------------------------------------------------------------------
+namespace {
+void put_u16(std::vector<uint8_t> &v, uint16_t x) { v.push_back((uint8_t)x), v.push_back((uint8_t)(x >> 8)); }
+void put_u32(std::vector<uint8_t> &v, uint32_t x) {
+    for (int i = 0; i < 4; i++) v.push_back((uint8_t)(x >> (8 * i)));
+}
+void put_u64(std::vector<uint8_t> &v, uint64_t x) {
+    for (int i = 0; i < 8; i++) v.push_back((uint8_t)(x >> (8 * i)));
+}
+void put_f32(std::vector<uint8_t> &v, float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    put_u32(v, u);
+}
+constexpr uint8_t kEHD[2] = {0xFF, 0xB2}, kDAT[2] = {0xFF, 0xB4}, kEOC[2] = {0xFF, 0xB8}, kPRD[2] = {0xFF, 0xBB}, kEOI[2] = {0xFF, 0xDF}; // serialize.rs:41-47
+} // namespace
+
+std::vector<uint8_t> serialize(uint32_t height, uint32_t width, ColorSpaceCode cs, const std::vector<ChannelStream> &channels, const std::vector<ChannelParams> &params) {
+    std::vector<uint8_t> s;
+    s.insert(s.end(), {'f', 'r', 'i', 'f'});
+    put_u32(s, height);
+    put_u32(s, width);
+    put_u32(s, (uint32_t)cs << 30 | 1u << 28); // variant: TameTwindragon = 0b01 (images.rs:49-55)
+    for (size_t ch = 0; ch < channels.size(); ch++) {
+        s.insert(s.end(), kPRD, kPRD + 2);
+        for (int g = 0; g < 3; g++)
+            for (int k = 0; k < 6; k++) put_f32(s, params[ch].value[g][k]);
+        for (int g = 0; g < 3; g++)
+            for (int k = 0; k < 6; k++) put_f32(s, params[ch].width[g][k]);
+        for (const AnsContext &c : channels[ch].contexts) {
+            s.insert(s.end(), kEHD, kEHD + 2);
+            put_u32(s, c.max_freq_bits);
+            put_u64(s, c.off_distribution_values.size()); // usize
+            for (uint16_t v : c.off_distribution_values) put_u16(s, v);
+        }
+        s.insert(s.end(), kDAT, kDAT + 2);
+        put_u64(s, channels[ch].data.size());
+        s.insert(s.end(), channels[ch].data.begin(), channels[ch].data.end());
+        s.insert(s.end(), kEOC, kEOC + 2);
+    }
+    s.insert(s.end(), kEOI, kEOI + 2);
+    return s;
+}
+
+std::string deserialize(const std::vector<uint8_t> &b, ParsedImage &out) {
+    size_t o = 0;
+    auto need = [&](size_t n) { return o + n <= b.size(); };
+    auto u32 = [&]() {
+        uint32_t v = (uint32_t)b[o] | (uint32_t)b[o + 1] << 8 | (uint32_t)b[o + 2] << 16 | (uint32_t)b[o + 3] << 24;
+        o += 4;
+        return v;
+    };
+    auto u64 = [&]() {
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v |= (uint64_t)b[o + i] << (8 * i);
+        o += 8;
+        return v;
+    };
+    if (!need(16) || std::memcmp(b.data(), "frif", 4) != 0) return "Invalid signature for FRIF image.";
+    o = 4;
+    out.height = u32();
+    out.width = u32();
+    const uint32_t mdat = u32();
+    out.colorspace = mdat >> 30 & 3u;
+    out.variant = mdat >> 28 & 3u;
+    if (out.colorspace == 0 || out.variant == 0) return "Invalid metadata";
+    ChannelStream cur;
+    ChannelParams prm{};
+    int n_ctx = 0;
+    for (;;) {
+        if (!need(2)) return "Malformed image bytes";
+        const uint8_t m0 = b[o], m1 = b[o + 1];
+        o += 2;
+        if (m0 != 0xFF) return "Malformed image bytes";
+        if (m1 == kPRD[1]) {
+            if (!need(36 * 4)) return "Malformed image bytes";
+            for (int g = 0; g < 3; g++)
+                for (int k = 0; k < 6; k++) {
+                    const uint32_t u = u32();
+                    std::memcpy(&prm.value[g][k], &u, 4);
+                }
+            for (int g = 0; g < 3; g++)
+                for (int k = 0; k < 6; k++) {
+                    const uint32_t u = u32();
+                    std::memcpy(&prm.width[g][k], &u, 4);
+                }
+        } else if (m1 == kEHD[1]) {
+            if (!need(12) || n_ctx >= kContexts) return "Malformed image bytes";
+            AnsContext c;
+            c.max_freq_bits = u32();
+            const uint64_t n = u64();
+            if (n > kAlphabet || !need(n * 2)) return "Malformed image bytes";
+            for (uint64_t i = 0; i < n; i++) {
+                c.off_distribution_values.push_back((uint16_t)(b[o] | b[o + 1] << 8));
+                o += 2;
+            }
+            const std::string err = c.finalize(n_ctx); // serialize.rs:232: the decoder rebuilds the table from the two fields
+            if (!err.empty()) return err;
+            cur.contexts[n_ctx++] = c;
+        } else if (m1 == kDAT[1]) {
+            if (!need(8)) return "Malformed image bytes";
+            const uint64_t n = u64();
+            if (!need(n)) return "Malformed image bytes";
+            cur.data.assign(b.begin() + o, b.begin() + o + n);
+            o += n;
+        } else if (m1 == kEOC[1]) {
+            out.channels.push_back(cur);
+            out.params.push_back(prm);
+            cur = ChannelStream{};
+            prm = ChannelParams{};
+            n_ctx = 0;
+        } else if (m1 == kEOI[1]) {
+            return "";
+        } else {
+            return "Malformed image bytes";
+        }
+    }
+}
+
+} // namespace emit
+} // namespace libfri

@@ -1,0 +1,104 @@
+// emit.hpp -- host side of libfri's encode path behind the device kernels:
+// symbol order (sort_lattice, stages/wavelet_transform.rs:505-705), ANS model construction
+// (AnsContext::finalize_context, stages/entropy_coding.rs:82-175), the ten interleaved rANS streams of a channel
+// (entropy_coding::encode, :266-352) and the `frif` container (stages/serialize.rs:40-117).
+//
+// Pure host code: inputs are the arrays the C ABI of include/fri_hip.h produces (centres, coefficients, bucket,
+// prediction, histogram). Nothing here touches the GPU, so the CPU test-suite exercises it against the oracle.
+//
+// PARITY UNPINNED for the byte stream: the rANS coder of the reference is the third-party crate `rans` (0.2.x, a
+// binding of ryg_rans' 64-bit coder) whose source is not part of the reference tree, and f32 `exp` is the platform's
+// libm. What is restated here is ryg_rans' published rans64 algorithm plus the call pattern of entropy_coding.rs; the
+// word order of flush/init is inferred from the reference's decoder index `CONTEXT_AMOUNT - bucket - 1` (:239).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace libfri {
+namespace emit {
+
+constexpr int kDepth = 9, kNodes = 512;
+constexpr int kContexts = 10;      // CONTEXT_AMOUNT, stages/prediction.rs
+constexpr int kAlphabet = 1024;    // ALPHABET_SIZE, stages/entropy_coding.rs:25
+constexpr int32_t kNone = INT32_MIN;
+
+// ---- symbol order ---------------------------------------------------------------------------------------------
+// Stream order of the nodes of `level` (0..8) over all retained cells: entry = cell << 9 | heap index, heap index in
+// [2^level, 2^(level+1)). Level 0 lists the cells themselves (heap index 1); the reference walks that list twice, for the
+// DC (heap 0) and for the root (heap 1) (entropy_coding.rs:285-308).
+// The reference finds the order by walking the level's lattice row by row (scan_level). The walk visits the lines parallel
+// to nearby(9 - level)[1] one after the other in the direction of nearby(9 - level)[3], each line front to back, so the order
+// is the sort by (n . p, col . p) with n normal to col; tests/test_emit.py checks that against the oracle's literal walk.
+std::vector<uint32_t> symbol_order(const int32_t *centers_re_im, uint32_t n_cells, int level);
+
+// ---- ANS model --------------------------------------------------------------------------------------------------
+struct AnsContext {
+    std::array<uint32_t, kAlphabet> freqs{};
+    std::array<uint32_t, kAlphabet> cdf{};
+    std::vector<uint16_t> off_distribution_values;
+    uint32_t max_freq_bits = 0;
+    // prediction.rs:302-305 + entropy_coding.rs:102-117. Returns "" or the reason libfri would panic.
+    std::string finalize(int bucket);
+};
+float width_from_bucket(int bucket);                       // prediction.rs:70-84
+uint32_t pack_signed(int32_t k);                           // utils.rs:34-40
+int32_t unpack_signed(uint32_t k);                         // utils.rs:42-48
+
+// ---- rANS: kContexts interleaved 64-bit states, one backwards-growing word stream (ryg_rans rans64) ---------------
+class RansEncoderMulti {
+  public:
+    void put_at(int state, uint32_t start, uint32_t freq, uint32_t scale_bits);
+    void flush_all();
+    std::vector<uint8_t> data() const; // little-endian words, first word of the stream first
+  private:
+    std::vector<uint32_t> rev_; // words in reverse stream order
+    uint64_t x_[kContexts] = {1ull << 31, 1ull << 31, 1ull << 31, 1ull << 31, 1ull << 31, 1ull << 31, 1ull << 31, 1ull << 31, 1ull << 31, 1ull << 31};
+};
+class RansDecoderMulti {
+  public:
+    explicit RansDecoderMulti(const std::vector<uint8_t> &data);
+    uint32_t get_at(int state, uint32_t scale_bits) const;
+    void advance_at(int state, uint32_t start, uint32_t freq, uint32_t scale_bits);
+    bool ok() const { return ok_; }
+  private:
+    std::vector<uint32_t> w_;
+    size_t pos_ = 0;
+    uint64_t x_[kContexts];
+    bool ok_ = true;
+};
+
+// ---- one channel -------------------------------------------------------------------------------------------------
+struct ChannelStream {
+    std::array<AnsContext, kContexts> contexts;
+    std::vector<uint8_t> data;
+    uint64_t n_symbols = 0;
+};
+// coefs / bucket / prediction: this channel's [n_cells][512] planes; hist: [10][1024] counts of K2.
+// Returns "" or an error (conditions under which the reference panics).
+std::string encode_channel(const int32_t *centers_re_im, uint32_t n_cells, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction,
+                           const uint32_t *hist, ChannelStream &out);
+// The (symbol, bucket) sequence in stream order (what encode_channel feeds to the coder); for self-checks.
+void channel_symbols(const int32_t *centers_re_im, uint32_t n_cells, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction,
+                     std::vector<uint16_t> &symbols, std::vector<uint8_t> &buckets);
+// Entropy-layer inverse for self-checks: given the bucket of every symbol in stream order, recover the symbols.
+std::string decode_symbols(const ChannelStream &s, const std::vector<uint8_t> &buckets, std::vector<uint16_t> &symbols);
+
+// ---- container ---------------------------------------------------------------------------------------------------
+struct ChannelParams {
+    float value[3][6];
+    float width[3][6];
+};
+enum ColorSpaceCode : uint32_t { kLuma = 1, kRGB = 2, kYCbCr = 3 }; // images.rs:23-29
+std::vector<uint8_t> serialize(uint32_t height, uint32_t width, ColorSpaceCode cs, const std::vector<ChannelStream> &channels,
+                               const std::vector<ChannelParams> &params);
+struct ParsedImage {
+    uint32_t height = 0, width = 0, colorspace = 0, variant = 0;
+    std::vector<ChannelStream> channels; // contexts rebuilt from (max_freq_bits, off_distribution_values) like serialize.rs:214-237
+    std::vector<ChannelParams> params;
+};
+std::string deserialize(const std::vector<uint8_t> &bytes, ParsedImage &out);
+
+} // namespace emit
+} // namespace libfri

@@ -1,0 +1,109 @@
+// emit_abi.cpp -- C entry points over emit.hpp (libfri_emit.so): what the CPU test-suite and a foreign-language host
+// bind. Plain pointers and sizes; every function returns 0 or a negative code and writes a message into `err`.
+#include <cstdio>
+#include <cstring>
+
+#include "emit.hpp"
+
+using namespace libfri::emit;
+
+namespace {
+int fail(char *err, size_t cap, const std::string &msg, int code = -1) {
+    if (err && cap) std::snprintf(err, cap, "%s", msg.c_str());
+    return code;
+}
+} // namespace
+
+extern "C" {
+
+// out[n_cells << level] = cell << 9 | heap index, in stream order (level 0: heap index 1)
+int fri_emit_symbol_order(const int32_t *centers_re_im, uint32_t n_cells, uint32_t level, uint32_t *out) {
+    if (!centers_re_im || !out || level >= (uint32_t)kDepth) return -1;
+    const std::vector<uint32_t> v = symbol_order(centers_re_im, n_cells, (int)level);
+    std::memcpy(out, v.data(), v.size() * sizeof(uint32_t));
+    return 0;
+}
+
+// freqs: in = the measured counts of one context, out = the model; cdf/off/n_off/max_freq_bits: outputs
+int fri_emit_finalize_context(uint32_t freqs[1024], uint32_t bucket, uint32_t cdf[1024], uint16_t off[1024], uint32_t *n_off, uint32_t *max_freq_bits, char *err,
+                              size_t err_cap) {
+    if (!freqs || !cdf || !off || !n_off || !max_freq_bits || bucket >= (uint32_t)kContexts) return -1;
+    AnsContext c;
+    uint64_t sum = 0;
+    for (int j = 0; j < kAlphabet; j++) {
+        c.freqs[j] = freqs[j];
+        sum = (uint32_t)(sum + freqs[j]);
+    }
+    uint64_t n = sum;
+    n |= n >> 1, n |= n >> 2, n |= n >> 4, n |= n >> 8, n |= n >> 16;
+    n ^= n >> 1;
+    c.max_freq_bits = n ? (uint32_t)__builtin_ctzll(n) : 64u; // prediction.rs:302-303
+    const std::string e = c.finalize((int)bucket);
+    if (!e.empty()) return fail(err, err_cap, e, -2);
+    std::memcpy(freqs, c.freqs.data(), sizeof(uint32_t) * kAlphabet);
+    std::memcpy(cdf, c.cdf.data(), sizeof(uint32_t) * kAlphabet);
+    *n_off = (uint32_t)c.off_distribution_values.size();
+    std::memcpy(off, c.off_distribution_values.data(), c.off_distribution_values.size() * sizeof(uint16_t));
+    *max_freq_bits = c.max_freq_bits;
+    return 0;
+}
+
+// symbols/buckets: capacity n_cells * 512 each; *n = symbols written (stream order)
+int fri_emit_channel_symbols(const int32_t *centers_re_im, uint32_t n_cells, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction,
+                             uint16_t *symbols, uint8_t *buckets, uint64_t *n) {
+    if (!centers_re_im || !coefs || !bucket || !prediction || !symbols || !buckets || !n) return -1;
+    std::vector<uint16_t> s;
+    std::vector<uint8_t> b;
+    channel_symbols(centers_re_im, n_cells, coefs, bucket, prediction, s, b);
+    std::memcpy(symbols, s.data(), s.size() * sizeof(uint16_t));
+    std::memcpy(buckets, b.data(), b.size());
+    *n = s.size();
+    return 0;
+}
+
+// The whole .frv: coefs/bucket/prediction are [channels][n_cells][512], hist [channels][10][1024], params [channels][3][6].
+// Returns 0 and *len; -3 if `cap` is too small (*len = needed size).
+int fri_emit_encode_image(uint32_t width, uint32_t height, uint32_t channels, const int32_t *centers_re_im, uint32_t n_cells, const int32_t *coefs,
+                          const uint8_t *bucket, const int32_t *prediction, const uint32_t *hist, const float *value_params, const float *width_params, uint8_t *out,
+                          size_t cap, size_t *len, char *err, size_t err_cap) {
+    if (!centers_re_im || !coefs || !bucket || !prediction || !hist || !value_params || !width_params || !len || (channels != 1 && channels != 3))
+        return fail(err, err_cap, "invalid argument");
+    std::vector<ChannelStream> streams(channels);
+    std::vector<ChannelParams> params(channels);
+    const size_t plane = (size_t)n_cells * kNodes;
+    for (uint32_t ch = 0; ch < channels; ch++) {
+        const std::string e = encode_channel(centers_re_im, n_cells, coefs + ch * plane, bucket + ch * plane, prediction + ch * plane,
+                                             hist + (size_t)ch * kContexts * kAlphabet, streams[ch]);
+        if (!e.empty()) return fail(err, err_cap, "channel " + std::to_string(ch) + ": " + e, -2);
+        std::memcpy(params[ch].value, value_params + (size_t)ch * 18, sizeof(params[ch].value));
+        std::memcpy(params[ch].width, width_params + (size_t)ch * 18, sizeof(params[ch].width));
+    }
+    const std::vector<uint8_t> bytes = serialize(height, width, channels == 1 ? kLuma : kRGB, streams, params);
+    *len = bytes.size();
+    if (!out || cap < bytes.size()) return -3;
+    std::memcpy(out, bytes.data(), bytes.size());
+    return 0;
+}
+
+// Entropy-layer self-check of a .frv against the arrays it was made from: parse the container, rebuild every context from its
+// two serialised fields, decode all symbols with the known bucket sequence and compare. 0 = identical.
+int fri_emit_check_image(const uint8_t *frv, size_t len, uint32_t channels, const int32_t *centers_re_im, uint32_t n_cells, const int32_t *coefs,
+                         const uint8_t *bucket, const int32_t *prediction, char *err, size_t err_cap) {
+    if (!frv || !centers_re_im || !coefs || !bucket || !prediction) return fail(err, err_cap, "invalid argument");
+    ParsedImage img;
+    std::string e = deserialize(std::vector<uint8_t>(frv, frv + len), img);
+    if (!e.empty()) return fail(err, err_cap, e, -2);
+    if (img.channels.size() != channels) return fail(err, err_cap, "channel count", -2);
+    const size_t plane = (size_t)n_cells * kNodes;
+    for (uint32_t ch = 0; ch < channels; ch++) {
+        std::vector<uint16_t> want, got;
+        std::vector<uint8_t> buckets;
+        channel_symbols(centers_re_im, n_cells, coefs + ch * plane, bucket + ch * plane, prediction + ch * plane, want, buckets);
+        e = decode_symbols(img.channels[ch], buckets, got);
+        if (!e.empty()) return fail(err, err_cap, "channel " + std::to_string(ch) + ": " + e, -2);
+        if (got != want) return fail(err, err_cap, "channel " + std::to_string(ch) + ": decoded symbols differ", -4);
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -1,6 +1,8 @@
 // fri_driver.cpp -- command-line driver over the C++ mirror / C ABI (the counterpart of fri-cli's encode/decode/bench
 // for this path; crates/fri-cli/src/commands/*.rs). Synthetic inputs only (SURVEY.md section 8d generators).
 //   fri_driver roundtrip <width> <height> <channels>         encode -> predict -> decode, checks the lossless identity
+//   fri_driver encode <width> <height> <channels> <out.frv>  the whole encode pipeline on a synthetic image: device stages, then
+//                                                            symbol order / ANS models / rANS / frif container on the host; self-checks the stream
 //   fri_driver batch <width> <height> <channels> <n_images>  BASELINE config 3: host batch with H2D / kernel / D2H overlap
 #include <chrono>
 #include <cstdio>
@@ -58,6 +60,60 @@ int main(int argc, char **argv) {
         std::printf("cells=%u hist_total_ch0=%llu lossless=%s (parameters fitted on the device sums)\n", enc.value.image.num_cells, (unsigned long long)total,
                     same ? "yes" : "NO");
         return same ? 0 : 1;
+    }
+    if (cmd == "encode") {
+        if (argc < 6) {
+            std::fprintf(stderr, "usage: %s encode <width> <height> <channels> <out.frv>\n", argv[0]);
+            return 2;
+        }
+        // left half smooth, right half noise (SURVEY.md section 8d generators): fills all ten ANS contexts; pure noise leaves some
+        // empty at small sizes, and libfri panics on an empty context
+        std::vector<uint8_t> img = noise_image(w, h, c, 0);
+        for (uint32_t y = 0; y < h; y++)
+            for (uint32_t x = 0; x < w / 2; x++)
+                for (uint32_t k = 0; k < c; k++) img[((size_t)y * w + x) * c + k] = (uint8_t)((((x + 2 * y) >> 3) + (img[((size_t)y * w + x) * c + k] & 7)) & 0xFF);
+        libfri::FRIEncoder encoder(opts);
+        auto t0 = std::chrono::steady_clock::now();
+        auto st = encoder.encode(img, h, w, cs);
+        if (!st.ok) {
+            std::fprintf(stderr, "%s\n", st.error.c_str());
+            return 1;
+        }
+        const double t_dev = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        t0 = std::chrono::steady_clock::now();
+        auto comp = libfri::stages::entropy_coding::encode(st.value.image, st.value.contexts, encoder.opts());
+        if (!comp.ok) {
+            std::fprintf(stderr, "%s\n", comp.error.c_str());
+            return 1;
+        }
+        const std::vector<uint8_t> bytes = libfri::stages::serialize::encode(comp.value);
+        const double t_host = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        // self-check: parse the container, rebuild the models from it, decode every symbol
+        libfri::emit::ParsedImage parsed;
+        std::string err = libfri::emit::deserialize(bytes, parsed);
+        const size_t plane = (size_t)st.value.image.num_cells * 512;
+        for (uint32_t ch = 0; err.empty() && ch < c; ch++) {
+            std::vector<uint16_t> want, got;
+            std::vector<uint8_t> buckets;
+            libfri::emit::channel_symbols(st.value.image.centers.data(), st.value.image.num_cells, st.value.image.coefficients.data() + ch * plane,
+                                          st.value.image.bucket[ch].data(), st.value.image.prediction[ch].data(), want, buckets);
+            err = libfri::emit::decode_symbols(parsed.channels[ch], buckets, got);
+            if (err.empty() && got != want) err = "decoded symbols differ";
+        }
+        if (!err.empty()) {
+            std::fprintf(stderr, "self-check failed: %s\n", err.c_str());
+            return 1;
+        }
+        if (FILE *f = std::fopen(argv[5], "wb")) {
+            std::fwrite(bytes.data(), 1, bytes.size(), f);
+            std::fclose(f);
+        } else {
+            std::fprintf(stderr, "cannot write %s\n", argv[5]);
+            return 1;
+        }
+        std::printf("%ux%ux%u: %zu bytes, %.3f bits per pixel; device stages (incl. plan + PCIe) %.3f s, host emit %.3f s; stream self-check ok\n", w, h, c,
+                    bytes.size(), 8.0 * bytes.size() / ((double)w * h), t_dev, t_host);
+        return 0;
     }
     if (cmd == "batch") {
         const uint32_t n = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 16;

@@ -264,6 +264,58 @@ Result<EncodedStages> FRIEncoder::encode(std::vector<uint8_t> data, uint32_t hei
     return r;
 }
 
+Result<CompressedImage> stages::entropy_coding::encode(const WaveletImage &image, const std::array<std::vector<AnsContext>, 3> &contexts, const EncoderOpts &opts) {
+    Result<CompressedImage> r;
+    const uint32_t channels = num_channels(image.metadata.colorspace);
+    const size_t plane = (size_t)image.num_cells * 512;
+    r.value.metadata = image.metadata;
+    r.value.channel_data.resize(channels);
+    r.value.params.resize(channels);
+    for (uint32_t ch = 0; ch < channels; ch++) {
+        if (contexts[ch].size() != (size_t)CONTEXT_AMOUNT) {
+            r.error = "missing contexts";
+            return r;
+        }
+        std::vector<uint32_t> hist((size_t)CONTEXT_AMOUNT * ALPHABET_SIZE);
+        for (int b = 0; b < CONTEXT_AMOUNT; b++) std::copy(contexts[ch][b].freqs.begin(), contexts[ch][b].freqs.end(), hist.begin() + (size_t)b * ALPHABET_SIZE);
+        const std::string err = emit::encode_channel(image.centers.data(), image.num_cells, image.coefficients.data() + ch * plane, image.bucket[ch].data(),
+                                                     image.prediction[ch].data(), hist.data(), r.value.channel_data[ch]);
+        if (!err.empty()) {
+            r.error = "channel " + std::to_string(ch) + ": " + err;
+            return r;
+        }
+        for (int g = 0; g < 3; g++)
+            for (int k = 0; k < 6; k++) {
+                r.value.params[ch].value[g][k] = opts.value_prediction_params[ch][g][k];
+                r.value.params[ch].width[g][k] = opts.width_prediction_params[ch][g][k];
+            }
+    }
+    r.ok = true;
+    return r;
+}
+
+std::vector<uint8_t> stages::serialize::encode(const CompressedImage &image) {
+    const emit::ColorSpaceCode cs = image.metadata.colorspace == ColorSpace::Luma ? emit::kLuma : image.metadata.colorspace == ColorSpace::RGB ? emit::kRGB : emit::kYCbCr;
+    return emit::serialize(image.metadata.height, image.metadata.width, cs, image.channel_data, image.params);
+}
+
+Result<std::vector<uint8_t>> FRIEncoder::encode_bytes(std::vector<uint8_t> data, uint32_t height, uint32_t width, ColorSpace colorspace) {
+    Result<std::vector<uint8_t>> r;
+    auto st = encode(std::move(data), height, width, colorspace);
+    if (!st.ok) {
+        r.error = st.error;
+        return r;
+    }
+    auto c = stages::entropy_coding::encode(st.value.image, st.value.contexts, opts_);
+    if (!c.ok) {
+        r.error = "Failed to decode: " + c.error; // sic, encoder.rs:106
+        return r;
+    }
+    r.value = stages::serialize::encode(c.value);
+    r.ok = true;
+    return r;
+}
+
 Result<RasterImage> FRIDecoder::decode(const WaveletImage &image, const EncoderOpts &opts) {
     Device dev(opts.device);
     Result<RasterImage> r;

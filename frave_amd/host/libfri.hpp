@@ -6,8 +6,10 @@
 //   stages::wavelet_transform::{encode,decode}                      stages/wavelet_transform.rs:708-717
 //   stages::quantization::{encode,decode}                           stages/quantization.rs:7-45
 //   stages::prediction::encode                                      stages/prediction.rs:224-323 (scan loops only)
-// The host-only stages (context-model fit, rANS, frif container) are out of scope: `encode` stops at
-// the state the reference calls EncoderStage::EntropyEncoding(WaveletImage, contexts) (encoder.rs:38).
+//   stages::entropy_coding::encode + stages::serialize::encode      stages/entropy_coding.rs:266-352, stages/serialize.rs:49-117
+// `encode` stops at the state the reference calls EncoderStage::EntropyEncoding(WaveletImage, contexts) (encoder.rs:38);
+// `encode_bytes` runs the two host stages behind it (emit.hpp: symbol order, ANS model, rANS, `frif` container) and returns
+// what the reference's FRIEncoder::encode returns, the file bytes.
 // Errors come back as Result<T>{ok,error} with the reference's "Failed to decode: " prefix (sic, encoder.rs:106).
 #pragma once
 #include <array>
@@ -18,6 +20,7 @@
 #include <tuple>
 #include <vector>
 
+#include "emit.hpp"
 #include "fri_hip.h"
 
 namespace libfri {
@@ -115,6 +118,22 @@ Result<std::array<std::vector<AnsContext>, 3>> encode(WaveletImage &image, Encod
 } // namespace prediction
 } // namespace stages
 
+// CompressedImage (images.rs:115-126): per channel the ten ANS models, the interleaved rANS stream and the predictor parameters
+struct CompressedImage {
+    ImageMetadata metadata;
+    std::vector<emit::ChannelStream> channel_data;
+    std::vector<emit::ChannelParams> params;
+};
+namespace stages {
+namespace entropy_coding {
+// entropy_coding::encode (:266-352); the contexts are rebuilt from the device histograms inside (prediction.rs:302-305)
+Result<CompressedImage> encode(const WaveletImage &image, const std::array<std::vector<AnsContext>, 3> &contexts, const EncoderOpts &opts);
+} // namespace entropy_coding
+namespace serialize {
+std::vector<uint8_t> encode(const CompressedImage &image); // serialize.rs:49-117
+} // namespace serialize
+} // namespace stages
+
 struct EncodedStages { // EncoderStage::EntropyEncoding(WaveletImage, [Vec<AnsContext>; 3]), encoder.rs:12
     WaveletImage image;
     std::array<std::vector<AnsContext>, 3> contexts;
@@ -124,6 +143,9 @@ class FRIEncoder { // encoder.rs:66-109
   public:
     explicit FRIEncoder(EncoderOpts opts) : opts_(std::move(opts)) {}
     Result<EncodedStages> encode(std::vector<uint8_t> data, uint32_t height, uint32_t width, ColorSpace colorspace);
+    // the whole pipeline of encoder.rs:19-48: ... -> EntropyEncoding -> Serialization -> EncodedImage(Vec<u8>)
+    Result<std::vector<uint8_t>> encode_bytes(std::vector<uint8_t> data, uint32_t height, uint32_t width, ColorSpace colorspace);
+    const EncoderOpts &opts() const { return opts_; } // after encode: the fitted predictor parameters
 
   private:
     EncoderOpts opts_;
