@@ -7,11 +7,11 @@ import torch
 
 import frave_amd
 
-W = H = 4096
+W = H = int(os.environ.get("SWEEP_SIZE", "4096"))
 C = int(os.environ.get("SWEEP_C", "1"))
 combos = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:] if "," in a] or [(32, 9, 1024)]
 ctx = frave_amd.Context(0)
-slots = 8
+slots = 8 if W <= 4096 else 2
 for band, cpt, cpwg in combos:
     os.environ["FRI_HIP_BAND_ROWS"] = str(band)
     os.environ["FRI_HIP_CELLS_PER_TILE"] = str(cpt)
