@@ -21,6 +21,8 @@
 
 #include "kernels.hpp"
 
+#include <cstring>
+
 namespace fri {
 namespace {
 
@@ -588,6 +590,7 @@ struct PredArgs {
     const int32_t *coefs;      // one channel plane [F][512]
     const int32_t *pred_slots; // [n_tiles][kPredSlots]
     const uint16_t *nbr_table; // [512][6]
+    const uint32_t *pred_off;  // [512][4] packed neighbour halfword offsets of every node (build_pred_offsets)
     const uint8_t *interior;   // [F]
     const uint32_t *valid_mask; // [F][16]
     uint8_t *bucket;
@@ -659,7 +662,7 @@ __device__ __forceinline__ void pred_load_row(const uint16_t *nbr_table, int p, 
     const uint32_t *r = reinterpret_cast<const uint32_t *>(nbr_table + p * 6); // 12-byte rows: 4-byte aligned
     row[0] = r[0], row[1] = r[1], row[2] = r[2];
 }
-__device__ __forceinline__ void pred_offsets_from_row(const uint32_t (&row)[3], uint32_t (&out)[3]) {
+__host__ __device__ __forceinline__ void pred_offsets_from_row(const uint32_t (&row)[3], uint32_t (&out)[3]) {
     uint32_t h[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -814,12 +817,10 @@ __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(cons
     for (int i = tid; i < kHistBins + 2; i += kPredThreads) s_hist[i] = 0;
 
     uint32_t off[8][3]; // neighbour halfword offsets relative to the own slot, loop invariant
-    {
-        uint32_t rows[8][3];
 #pragma unroll
-        for (int i = 0; i < 8; i++) pred_load_row(a.nbr_table, lane + 64 * i, rows[i]);
-#pragma unroll
-        for (int i = 0; i < 8; i++) pred_offsets_from_row(rows[i], off[i]);
+    for (int i = 0; i < 8; i++) { // precomputed at plan creation (build_pred_offsets): 8 loads, no arithmetic
+        const u32x4 o = reinterpret_cast<const u32x4 *>(a.pred_off)[lane + 64 * i];
+        off[i][0] = o.x, off[i][1] = o.y, off[i][2] = o.z;
     }
 
     const PredTileWalk walk(a.n_tiles);
@@ -870,12 +871,12 @@ constexpr int kPred2Waves = kPred2Threads / 64;
 constexpr int kPred2Stage = (kPredSlots + kPred2Waves - 1) / kPred2Waves; // cells staged per wave
 constexpr int kPredCellsBytes = kPredSlots * kSlotStride;
 constexpr int kPredHistBytes = ((kHistBins + 2) * 4 + 15) & ~15;
-constexpr int kPred2LdsBytes = kPredHistBytes + 2 * kPredCellsBytes + 3 * kPredSlots * 4;
+constexpr int kPred2LdsBytes = kPredHistBytes + 2 * kPredCellsBytes + 3 * kPredSlots * 4 + 32 * 2;
 static_assert(kPred2Waves == kPredBlock * kPredBlock, "one wave per block cell");
 
 template <int I, bool INTERIOR>
 __device__ __forceinline__ void predict_node2(const uint8_t *own, int lane, uint32_t o01, uint32_t o23, uint32_t o45, bool some, const PredictParams &pp,
-                                              uint32_t *s_hist, uint8_t *bucket_dst, int32_t *pred_dst) {
+                                              uint32_t *s_hist, const uint16_t *s_bkt, uint8_t *bucket_dst, int32_t *pred_dst) {
     constexpr int g = I >= 4 ? 0 : I >= 2 ? 1 : 2;
     const float *wp = pp.width[g], *vp = pp.value[g];
     const int value = *reinterpret_cast<const short *>(own + 2 * (lane + 64 * I));
@@ -894,7 +895,9 @@ __device__ __forceinline__ void predict_node2(const uint8_t *own, int lane, uint
     width = __fadd_rn(width, __fmul_rn(wp[3], fabsf(__fsub_rn(f[4], f[5]))));
     width = __fadd_rn(width, __fmul_rn(wp[4], fabsf(__fsub_rn(f[1], f[5]))));
     width = __fadd_rn(width, __fmul_rn(wp[5], fabsf(__fsub_rn(f[2], f[4]))));
-    uint32_t bucket = assign_bucket(width);
+    // assign_bucket (prediction.rs:55-68) as a 32-entry LDS table of bucket << 10: the kernel is bound by instruction issue and
+    // the LDS pipe has room (one ds_read_u16 instead of nine VALU instructions)
+    uint32_t b10 = s_bkt[min(f32_as_u32(width), 31u)];
     float pf = __fmul_rn(f[0], vp[0]);
     pf = __fadd_rn(pf, __fmul_rn(f[1], vp[1]));
     pf = __fadd_rn(pf, __fmul_rn(f[2], vp[2]));
@@ -907,11 +910,12 @@ __device__ __forceinline__ void predict_node2(const uint8_t *own, int lane, uint
         const int mx = max(v[0], v[2]), mn = min(v[0], v[2]);
         const int lf_pred = v[1] >= mx ? mx : v[1] <= mn ? mn : sub_w(add_w(v[0], v[2]), v[1]);
         const bool lf = lane < 2;
-        bucket = lf ? bucket_of_rt(w) : bucket;
+        b10 = lf ? bucket_of_rt(w) << 10 : b10;
         prediction = lf ? lf_pred : prediction;
     }
     const uint32_t sym = pack_signed(sub_w(value, prediction));
-    uint32_t bin = sym < 1024u ? bucket * 1024u + sym : (uint32_t)kHistBins;
+    uint32_t bin = sym < 1024u ? b10 + sym : (uint32_t)kHistBins;
+    uint32_t bucket = b10 >> 10;
     if (!INTERIOR) { // a None node goes to the trash bin and stays (0, 0) in the outputs (wavelet_transform.rs:60-64)
         bin = some ? bin : (uint32_t)kHistBins + 1u;
         bucket = some ? bucket : 0u;
@@ -927,18 +931,18 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(lds); // 10 x 1024 + out-of-alphabet counter + trash bin
     uint8_t *s_cells = lds + kPredHistBytes;              // [2][kPredCellsBytes]
     int32_t *s_ring = reinterpret_cast<int32_t *>(s_cells + 2 * kPredCellsBytes); // [3][kPredSlots]
+    uint16_t *s_bkt = reinterpret_cast<uint16_t *>(s_ring + 3 * kPredSlots);       // [32] bucket_of(w) << 10
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     trace_stamp(a.trace, blockIdx.x, 0, tid);
     for (int i = tid; i < kHistBins + 2; i += kPred2Threads) s_hist[i] = 0;
+    if (tid < 32) s_bkt[tid] = (uint16_t)(bucket_of((uint32_t)tid) << 10);
 
     uint32_t off[8][3]; // neighbour halfword offsets relative to the own slot, loop invariant
-    {
-        uint32_t rows[8][3];
 #pragma unroll
-        for (int i = 0; i < 8; i++) pred_load_row(a.nbr_table, lane + 64 * i, rows[i]);
-#pragma unroll
-        for (int i = 0; i < 8; i++) pred_offsets_from_row(rows[i], off[i]);
+    for (int i = 0; i < 8; i++) { // precomputed at plan creation (build_pred_offsets): 8 loads, no arithmetic
+        const u32x4 o = reinterpret_cast<const u32x4 *>(a.pred_off)[lane + 64 * i];
+        off[i][0] = o.x, off[i][1] = o.y, off[i][2] = o.z;
     }
 
     const PredTileWalk walk(a.n_tiles);
@@ -1003,28 +1007,28 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
             uint8_t *bd = (has ? a.bucket + (size_t)cell * kCell : a.junk_bucket) + lane;
             int32_t *pd = (has ? a.prediction + (size_t)cell * kCell : a.junk_prediction) + lane;
             if (has && __builtin_amdgcn_readfirstlane((int)a.interior[has ? cell : 0])) {
-                predict_node2<0, true>(own, lane, off[0][0], off[0][1], off[0][2], true, a.pp, s_hist, bd, pd);
-                predict_node2<1, true>(own, lane, off[1][0], off[1][1], off[1][2], true, a.pp, s_hist, bd, pd);
-                predict_node2<2, true>(own, lane, off[2][0], off[2][1], off[2][2], true, a.pp, s_hist, bd, pd);
-                predict_node2<3, true>(own, lane, off[3][0], off[3][1], off[3][2], true, a.pp, s_hist, bd, pd);
-                predict_node2<4, true>(own, lane, off[4][0], off[4][1], off[4][2], true, a.pp, s_hist, bd, pd);
-                predict_node2<5, true>(own, lane, off[5][0], off[5][1], off[5][2], true, a.pp, s_hist, bd, pd);
-                predict_node2<6, true>(own, lane, off[6][0], off[6][1], off[6][2], true, a.pp, s_hist, bd, pd);
-                predict_node2<7, true>(own, lane, off[7][0], off[7][1], off[7][2], true, a.pp, s_hist, bd, pd);
+                predict_node2<0, true>(own, lane, off[0][0], off[0][1], off[0][2], true, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<1, true>(own, lane, off[1][0], off[1][1], off[1][2], true, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<2, true>(own, lane, off[2][0], off[2][1], off[2][2], true, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<3, true>(own, lane, off[3][0], off[3][1], off[3][2], true, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<4, true>(own, lane, off[4][0], off[4][1], off[4][2], true, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<5, true>(own, lane, off[5][0], off[5][1], off[5][2], true, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<6, true>(own, lane, off[6][0], off[6][1], off[6][2], true, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<7, true>(own, lane, off[7][0], off[7][1], off[7][2], true, a.pp, s_hist, s_bkt, bd, pd);
             } else { // boundary cell: Some/None of node lane + 64 i is bit (lane & 31) of mask word 2 i + (lane >> 5)
                 uint32_t some_bits = 0;
                 if (has) {
 #pragma unroll
                     for (int i = 0; i < 8; i++) some_bits |= ((a.valid_mask[(size_t)cell * 16 + 2 * i + (lane >> 5)] >> (lane & 31)) & 1u) << i;
                 }
-                predict_node2<0, false>(own, lane, off[0][0], off[0][1], off[0][2], some_bits & 1u, a.pp, s_hist, bd, pd);
-                predict_node2<1, false>(own, lane, off[1][0], off[1][1], off[1][2], some_bits & 2u, a.pp, s_hist, bd, pd);
-                predict_node2<2, false>(own, lane, off[2][0], off[2][1], off[2][2], some_bits & 4u, a.pp, s_hist, bd, pd);
-                predict_node2<3, false>(own, lane, off[3][0], off[3][1], off[3][2], some_bits & 8u, a.pp, s_hist, bd, pd);
-                predict_node2<4, false>(own, lane, off[4][0], off[4][1], off[4][2], some_bits & 16u, a.pp, s_hist, bd, pd);
-                predict_node2<5, false>(own, lane, off[5][0], off[5][1], off[5][2], some_bits & 32u, a.pp, s_hist, bd, pd);
-                predict_node2<6, false>(own, lane, off[6][0], off[6][1], off[6][2], some_bits & 64u, a.pp, s_hist, bd, pd);
-                predict_node2<7, false>(own, lane, off[7][0], off[7][1], off[7][2], some_bits & 128u, a.pp, s_hist, bd, pd);
+                predict_node2<0, false>(own, lane, off[0][0], off[0][1], off[0][2], some_bits & 1u, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<1, false>(own, lane, off[1][0], off[1][1], off[1][2], some_bits & 2u, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<2, false>(own, lane, off[2][0], off[2][1], off[2][2], some_bits & 4u, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<3, false>(own, lane, off[3][0], off[3][1], off[3][2], some_bits & 8u, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<4, false>(own, lane, off[4][0], off[4][1], off[4][2], some_bits & 16u, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<5, false>(own, lane, off[5][0], off[5][1], off[5][2], some_bits & 32u, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<6, false>(own, lane, off[6][0], off[6][1], off[6][2], some_bits & 64u, a.pp, s_hist, s_bkt, bd, pd);
+                predict_node2<7, false>(own, lane, off[7][0], off[7][1], off[7][2], some_bits & 128u, a.pp, s_hist, s_bkt, bd, pd);
             }
         }
 
@@ -1540,6 +1544,15 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
     return hipGetLastError();
 }
 
+void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out) {
+    for (int p = 0; p < kCell; p++) {
+        uint32_t row[3], o[3];
+        std::memcpy(row, nbr_table + p * 6, sizeof(row));
+        pred_offsets_from_row(row, o);
+        out[4 * p] = o[0], out[4 * p + 1] = o[1], out[4 * p + 2] = o[2], out[4 * p + 3] = 0;
+    }
+}
+
 hipError_t launch_predict_histogram(const DevicePlan &p, const int32_t *coefs_channel, const PredictParams &pp, uint8_t *bucket,
                                     int32_t *prediction, uint32_t *hist, unsigned long long *n_oob, hipStream_t stream) {
     if (!p.pred_acc) return hipErrorInvalidValue;
@@ -1549,6 +1562,7 @@ hipError_t launch_predict_histogram(const DevicePlan &p, const int32_t *coefs_ch
     a.coefs = coefs_channel;
     a.pred_slots = p.pred_slots;
     a.nbr_table = p.nbr_table;
+    a.pred_off = p.pred_off;
     a.interior = p.interior;
     a.valid_mask = p.valid_mask;
     a.bucket = bucket;

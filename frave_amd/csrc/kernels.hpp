@@ -25,6 +25,7 @@ struct DevicePlan {
     const uint32_t *valid_mask = nullptr; // [F][16]
     const int32_t *nbr_cells = nullptr;   // [F][kNbr]
     const uint16_t *nbr_table = nullptr;  // [512][6]
+    const uint32_t *pred_off = nullptr;   // [512][4] K2's packed LDS offsets per node, derived from nbr_table
     const int32_t *pred_slots = nullptr;  // [n_pred_tiles][kPredSlots]
     uint32_t n_pred_tiles = 0;
     uint32_t *hist_partial = nullptr;     // [hist_blocks][10*1024] scratch for the histogram reduction
@@ -67,6 +68,8 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, int mode, const int32_t *c
 // K3: (reference-faithful) dequantisation + inverse transform + clamp.
 hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, const QMatrix &q, uint8_t *pixels, hipStream_t stream);
 
+// K2's per-node neighbour offsets (LDS halfword offsets relative to the own slot, two per word) from the static neighbour table
+void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out /* [512][4] */);
 size_t fwd_lds_bytes(const DevicePlan &p);
 size_t inv_lds_bytes(const DevicePlan &p);
 // True iff the lane/leaf footprint hard-wired in the kernels equals the table derived from LITERALS.
