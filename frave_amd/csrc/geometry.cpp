@@ -322,7 +322,7 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
                         const int a = a0 + i, b = b0 + j;
                         int32_t id = -1;
                         if (a >= amin && a <= amax && b >= bmin && b <= bmax) id = at(a, b);
-                        g.pred_slots[(size_t)t * kPredSlots + i * kPredSide + j] = id >= 0 ? id : -1;
+                        g.pred_slots[(size_t)t * kPredSlots + i * kPredSide + j] = id >= 0 ? (id | (g.interior[id] ? kPredSlotInterior : 0)) : -1;
                     }
             }
         }

@@ -72,11 +72,13 @@ struct Geometry {
     int32_t max_wg_tiles = 0;   // most tiles in one workgroup share
     int32_t max_wg_cells = 0;   // most cells in one workgroup share
     // Gather kernel (K2): blocks of kPredBlock x kPredBlock cells in lattice coordinates plus a one-cell halo ring.
-    // pred_slots[t][(kPredBlock+2)^2] = cell id held by each LDS slot of tile t (-1 = no retained cell there).
+    // pred_slots[t][(kPredBlock+2)^2] = cell id held by each LDS slot of tile t (-1 = no retained cell there), with
+    // kPredSlotInterior set when all 512 leaves of the cell are inside the image (so the gather kernels need no second lookup).
     std::vector<int32_t> pred_slots;
     uint32_t n_pred_tiles = 0;
 };
 
+constexpr int32_t kPredSlotInterior = 0x40000000;          // flag bit in a pred_slots entry; cell ids stay below it
 constexpr int kPredBlock = 4;                              // cells per block edge
 constexpr int kPredSide = kPredBlock + 2;                  // with halo
 constexpr int kPredSlots = kPredSide * kPredSide;          // 36

@@ -656,6 +656,10 @@ __device__ __forceinline__ void pred_hand_over(const PredArgs &a, const uint32_t
 // ---- shared by the gather kernels (K2 and the fit accumulators) -----------------------------------------------------
 // Neighbour halfword offsets of node p relative to the own LDS slot, two per register: out[0] = {k0, k1}, out[1] = {k2, k3},
 // out[2] = {k4, k5} (k = left, up_left, up_right, right, down_left, down_right; context_modeling.rs:37-71).
+// A pred_slots entry: cell id, -1 = no cell, kPredSlotInterior set for interior cells.
+__device__ __forceinline__ int pred_slot_cell(int raw) { return raw < 0 ? -1 : raw & (kPredSlotInterior - 1); }
+__device__ __forceinline__ bool pred_slot_interior(int raw) { return raw >= 0 && (raw & kPredSlotInterior) != 0; }
+
 // Two steps so that a kernel can issue the table loads of all its nodes back to back (one wait instead of one round trip per
 // entry: 48 serialised loads used to open every workgroup of K2): the 12-byte row of node p, then the arithmetic.
 __device__ __forceinline__ void pred_load_row(const uint16_t *nbr_table, int p, uint32_t (&row)[3]) {
@@ -826,7 +830,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(cons
     const PredTileWalk walk(a.n_tiles);
     for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step) {
         __syncthreads(); // everyone is done with the previous tile's LDS image (and the histogram is zeroed on the first pass)
-        if (tid < kPredSlots) s_slot_cell[tid] = a.pred_slots[(size_t)tile * kPredSlots + tid];
+        if (tid < kPredSlots) s_slot_cell[tid] = pred_slot_cell(a.pred_slots[(size_t)tile * kPredSlots + tid]);
         __syncthreads();
         pred_stage_tile(a.coefs, s_slot_cell, s_cells, lane, wave, &s_hist[kHistBins]);
         __syncthreads();
@@ -871,7 +875,8 @@ constexpr int kPred2Waves = kPred2Threads / 64;
 constexpr int kPred2Stage = (kPredSlots + kPred2Waves - 1) / kPred2Waves; // cells staged per wave
 constexpr int kPredCellsBytes = kPredSlots * kSlotStride;
 constexpr int kPredHistBytes = ((kHistBins + 2) * 4 + 15) & ~15;
-constexpr int kPred2LdsBytes = kPredHistBytes + 2 * kPredCellsBytes + 3 * kPredSlots * 4 + 32 * 2;
+constexpr int kPredMaskWords = kPredSlots * 16; // Some/None masks of the staged cells, per image
+constexpr int kPred2LdsBytes = kPredHistBytes + 2 * kPredCellsBytes + 3 * kPredSlots * 4 + 32 * 2 + 2 * kPredMaskWords * 4;
 static_assert(kPred2Waves == kPredBlock * kPredBlock, "one wave per block cell");
 
 template <int I, bool INTERIOR>
@@ -932,6 +937,7 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
     uint8_t *s_cells = lds + kPredHistBytes;              // [2][kPredCellsBytes]
     int32_t *s_ring = reinterpret_cast<int32_t *>(s_cells + 2 * kPredCellsBytes); // [3][kPredSlots]
     uint16_t *s_bkt = reinterpret_cast<uint16_t *>(s_ring + 3 * kPredSlots);       // [32] bucket_of(w) << 10
+    uint32_t *s_masks = reinterpret_cast<uint32_t *>(s_bkt + 32);                  // [2][kPredSlots][16]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     trace_stamp(a.trace, blockIdx.x, 0, tid);
@@ -956,8 +962,9 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
     __syncthreads();
     // stage tile 0 straight into image 0
     for (int sl = wave; sl < kPredSlots; sl += kPred2Waves) {
-        const int cell = s_ring[sl];
+        const int cell = pred_slot_cell(s_ring[sl]);
         i32x4 lo = i32x4{0, 0, 0, 0}, hi = lo;
+        if (lane < 16) s_masks[sl * 16 + lane] = a.valid_mask[(size_t)max(cell, 0) * 16 + lane];
         if (cell >= 0) {
             const i32x4 *src = reinterpret_cast<const i32x4 *>(a.coefs + (size_t)cell * kCell + 8 * lane);
             lo = src[0], hi = src[1];
@@ -981,18 +988,22 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
         const int32_t *cur_slots = s_ring + (it % 3) * kPredSlots, *nxt_slots = s_ring + ((it + 1) % 3) * kPredSlots;
         const uint8_t *cur = s_cells + (it & 1) * kPredCellsBytes;
         uint8_t *nxt = s_cells + ((it & 1) ^ 1) * kPredCellsBytes;
+        const uint32_t *cur_masks = s_masks + (it & 1) * kPredMaskWords;
+        uint32_t *nxt_masks = s_masks + ((it & 1) ^ 1) * kPredMaskWords;
         // in flight across the arithmetic below: the slot list of tile i + 2 and the cells of tile i + 1
         const int32_t slot_pre = a.pred_slots[(size_t)min(tile + 2 * walk.step, last) * kPredSlots + slot_lane];
         i32x4 st_lo[kPred2Stage], st_hi[kPred2Stage];
         int st_cell[kPred2Stage];
+        uint32_t st_mask[kPred2Stage];
         if (more) {
 #pragma unroll
             for (int j = 0; j < kPred2Stage; j++) {
                 const int sl = wave + kPred2Waves * j;
                 if (sl < kPredSlots) {
-                    st_cell[j] = __builtin_amdgcn_readfirstlane(nxt_slots[sl]);
+                    st_cell[j] = pred_slot_cell(__builtin_amdgcn_readfirstlane(nxt_slots[sl]));
                     const i32x4 *src = reinterpret_cast<const i32x4 *>(a.coefs + (size_t)max(st_cell[j], 0) * kCell + 8 * lane);
                     st_lo[j] = src[0], st_hi[j] = src[1];
+                    st_mask[j] = a.valid_mask[(size_t)max(st_cell[j], 0) * 16 + (lane & 15)]; // the cell's Some/None bits travel with it
                 }
             }
         }
@@ -1001,12 +1012,13 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
           // writes zeros to the plan's junk lines), so the compiler can count them: the commit below waits for the staging
           // loads with vmcnt(16) instead of vmcnt(0) and does not sit out the acknowledgement of the stores just issued.
             const int slot = (1 + wave / kPredBlock) * kPredSide + 1 + (wave % kPredBlock);
-            const int cell = __builtin_amdgcn_readfirstlane(cur_slots[slot]);
+            const int raw = __builtin_amdgcn_readfirstlane(cur_slots[slot]); // everything this phase needs is in LDS: a global load here
+            const int cell = pred_slot_cell(raw);                            // would have to wait for the staging loads just issued
             const bool has = cell >= 0;
             const uint8_t *own = cur + slot * kSlotStride;
             uint8_t *bd = (has ? a.bucket + (size_t)cell * kCell : a.junk_bucket) + lane;
             int32_t *pd = (has ? a.prediction + (size_t)cell * kCell : a.junk_prediction) + lane;
-            if (has && __builtin_amdgcn_readfirstlane((int)a.interior[has ? cell : 0])) {
+            if (pred_slot_interior(raw)) {
                 predict_node2<0, true>(own, lane, off[0][0], off[0][1], off[0][2], true, a.pp, s_hist, s_bkt, bd, pd);
                 predict_node2<1, true>(own, lane, off[1][0], off[1][1], off[1][2], true, a.pp, s_hist, s_bkt, bd, pd);
                 predict_node2<2, true>(own, lane, off[2][0], off[2][1], off[2][2], true, a.pp, s_hist, s_bkt, bd, pd);
@@ -1019,7 +1031,7 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
                 uint32_t some_bits = 0;
                 if (has) {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) some_bits |= ((a.valid_mask[(size_t)cell * 16 + 2 * i + (lane >> 5)] >> (lane & 31)) & 1u) << i;
+                    for (int i = 0; i < 8; i++) some_bits |= ((cur_masks[slot * 16 + 2 * i + (lane >> 5)] >> (lane & 31)) & 1u) << i;
                 }
                 predict_node2<0, false>(own, lane, off[0][0], off[0][1], off[0][2], some_bits & 1u, a.pp, s_hist, s_bkt, bd, pd);
                 predict_node2<1, false>(own, lane, off[1][0], off[1][1], off[1][2], some_bits & 2u, a.pp, s_hist, s_bkt, bd, pd);
@@ -1046,6 +1058,7 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
                         if (n) atomicAdd(&s_hist[kHistBins], n);
                     }
                     uint8_t *dst = nxt + sl * kSlotStride;
+                    if (lane < 16) nxt_masks[sl * 16 + lane] = st_mask[j];
                     *reinterpret_cast<u32x4 *>(dst + 16 * lane) = u32x4{__builtin_amdgcn_perm((uint32_t)lo.y, (uint32_t)lo.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)lo.w, (uint32_t)lo.z, 0x05040100u),
                                                                         __builtin_amdgcn_perm((uint32_t)hi.y, (uint32_t)hi.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)hi.w, (uint32_t)hi.z, 0x05040100u)};
                     if (lane == 0) *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{0u, 0u, 0u, 0u};
@@ -1141,7 +1154,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
     const PredTileWalk walk(a.n_tiles);
     for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step) {
         __syncthreads();
-        if (tid < kPredSlots) s_slot_cell[tid] = a.pred_slots[(size_t)tile * kPredSlots + tid];
+        if (tid < kPredSlots) s_slot_cell[tid] = pred_slot_cell(a.pred_slots[(size_t)tile * kPredSlots + tid]);
         __syncthreads();
         pred_stage_tile(a.coefs, s_slot_cell, s_cells, lane, wave);
         __syncthreads();

@@ -44,3 +44,16 @@ for i in range(11):
     prev = np.where(m, tr[:, 2 + i], prev)
 print("loop done          ", pc(us(tr[:, 13])))
 print("exit               ", pc(us(tr[:, 15])), "  merge", pc((tr[:, 15] - tr[:, 13]) / 100.0))
+# which workgroups take the long tiles?
+dur = np.zeros((len(tr), 11))
+prev = tr[:, 1]
+for i in range(11):
+    m = tr[:, 2 + i] > 0
+    dur[m, i] = (tr[m, 2 + i] - prev[m]) / 100.0
+    prev = np.where(m, tr[:, 2 + i], prev)
+slow = np.argwhere(dur > 7.5)
+xcc = (tr[:, 14] >> 32) & 0xF
+hw = tr[:, 14] & 0xFFFFFFFF
+print(f"{len(slow)} tile iterations longer than 7.5 us:")
+for w, i in slow[:40]:
+    print(f"  workgroup {w:3d} tile {i}  {dur[w, i]:5.2f} us  ends at {us(tr[w, 2 + i]):6.2f}  xcc {xcc[w]} se {(hw[w] >> 13) & 7} cu {(hw[w] >> 8) & 15}")
