@@ -260,9 +260,11 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.max_wg_tiles = g.max_wg_tiles;
         d.max_wg_cells = g.max_wg_cells;
         d.n_wg = (uint32_t)g.wg_tiles.size() - 1;
+        d.pred_blocks = (uint32_t)ctx->cu_count;
+        if (env_int("FRI_HIP_PRED_BLOCKS") > 0) d.pred_blocks = (uint32_t)env_int("FRI_HIP_PRED_BLOCKS");
         {
             void *j = nullptr;
-            if (hipMalloc(&j, 4096) != hipSuccess) {
+            if (hipMalloc(&j, (size_t)d.pred_blocks * kPredJunkWaves * kPredJunkBytes) != hipSuccess) {
                 fri_hip_plan_destroy(p);
                 return FRI_HIP_ERR_HIP;
             }
@@ -279,8 +281,6 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             p->owned.push_back(acc);
             d.pred_acc = static_cast<uint32_t *>(acc);
         }
-        d.pred_blocks = (uint32_t)ctx->cu_count;
-        if (env_int("FRI_HIP_PRED_BLOCKS") > 0) d.pred_blocks = (uint32_t)env_int("FRI_HIP_PRED_BLOCKS");
         d.k2_single_buffered = env_int("FRI_HIP_K2_V1") > 0;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");

@@ -597,8 +597,7 @@ struct PredArgs {
     int32_t *prediction;
     uint32_t *hist;
     unsigned long long *n_oob;
-    uint8_t *junk_bucket;      // 512 B / 2 KB of plan scratch: where the pipelined K2 writes what the caller does not want
-    int32_t *junk_prediction;
+    uint8_t *junk;             // plan scratch, kPredJunkBytes per wave of the pipelined K2: output lines of block slots without a cell
     unsigned long long *trace; // diagnostic timeline, null in production
     uint32_t *acc;             // plan scratch, all zero between launches: [kHistBins] counts, then kAccOob (u64), kAccTicket
     uint32_t n_tiles;
@@ -795,11 +794,11 @@ __device__ __forceinline__ void predict_node(const uint8_t *own, int lane, uint3
         bucket = lf ? bucket_of_rt(w) : bucket;
         prediction = lf ? lf_pred : prediction;
     }
-    // histogram update without a branch: a None node goes to the trash bin, an out-of-alphabet symbol (the reference
-    // would panic, entropy_coding.rs:99) to the counter bin behind the 10 x 1024 table
+    // an out-of-alphabet symbol (the reference would panic, entropy_coding.rs:99) goes to the counter bin behind the 10 x 1024 table
     const uint32_t sym = pack_signed(sub_w(value, prediction));
-    const uint32_t bin = !some ? (uint32_t)kHistBins + 1u : sym < 1024u ? bucket * 1024u + sym : (uint32_t)kHistBins;
-    atomicAdd(&s_hist[bin], 1u); // bump_freq, entropy_coding.rs:98-100
+    const uint32_t bin = sym < 1024u ? bucket * 1024u + sym : (uint32_t)kHistBins;
+    if (some) atomicAdd(&s_hist[bin], 1u); // bump_freq, entropy_coding.rs:98-100. None nodes are masked off, not sent to a common trash
+                                           // bin: 64 lanes adding to one LDS address take ~0.7 us per instruction
     // a None node is never written by the reference and stays (0, 0) (wavelet_transform.rs:60-64)
     if (bucket_dst) bucket_dst[64 * I] = (uint8_t)(some ? bucket : 0u);
     if (pred_dst) pred_dst[64 * I] = some ? prediction : 0;
@@ -874,6 +873,7 @@ constexpr int kPred2Threads = 1024;
 constexpr int kPred2Waves = kPred2Threads / 64;
 constexpr int kPred2Stage = (kPredSlots + kPred2Waves - 1) / kPred2Waves; // cells staged per wave
 constexpr int kPredCellsBytes = kPredSlots * kSlotStride;
+static_assert(kPred2Threads / 64 == (int)kPredJunkWaves && 512 + 2048 == (int)kPredJunkBytes, "junk layout");
 constexpr int kPredHistBytes = ((kHistBins + 2) * 4 + 15) & ~15;
 constexpr int kPredMaskWords = kPredSlots * 16; // Some/None masks of the staged cells, per image
 constexpr int kPred2LdsBytes = kPredHistBytes + 2 * kPredCellsBytes + 3 * kPredSlots * 4 + 32 * 2 + 2 * kPredMaskWords * 4;
@@ -921,12 +921,14 @@ __device__ __forceinline__ void predict_node2(const uint8_t *own, int lane, uint
     const uint32_t sym = pack_signed(sub_w(value, prediction));
     uint32_t bin = sym < 1024u ? b10 + sym : (uint32_t)kHistBins;
     uint32_t bucket = b10 >> 10;
-    if (!INTERIOR) { // a None node goes to the trash bin and stays (0, 0) in the outputs (wavelet_transform.rs:60-64)
-        bin = some ? bin : (uint32_t)kHistBins + 1u;
+    if (!INTERIOR) { // a None node is not counted and stays (0, 0) in the outputs (wavelet_transform.rs:60-64). Skipped under the
+                     // exec mask, not sent to a trash bin: 64 lanes adding to ONE LDS address take ~0.7 us per instruction (measured)
         bucket = some ? bucket : 0u;
         prediction = some ? prediction : 0;
+        if (some) atomicAdd(&s_hist[bin], 1u);
+    } else {
+        atomicAdd(&s_hist[bin], 1u); // bump_freq, entropy_coding.rs:98-100
     }
-    atomicAdd(&s_hist[bin], 1u); // bump_freq, entropy_coding.rs:98-100
     __builtin_nontemporal_store((uint8_t)bucket, bucket_dst + 64 * I);
     __builtin_nontemporal_store(prediction, pred_dst + 64 * I);
 }
@@ -1016,8 +1018,10 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
             const int cell = pred_slot_cell(raw);                            // would have to wait for the staging loads just issued
             const bool has = cell >= 0;
             const uint8_t *own = cur + slot * kSlotStride;
-            uint8_t *bd = (has ? a.bucket + (size_t)cell * kCell : a.junk_bucket) + lane;
-            int32_t *pd = (has ? a.prediction + (size_t)cell * kCell : a.junk_prediction) + lane;
+            // (junk lines are private to the wave: one shared line would be a write hot spot for every edge tile of the image)
+            const size_t junk = ((size_t)blockIdx.x * kPred2Waves + wave) * kPredJunkBytes;
+            uint8_t *bd = (has ? a.bucket + (size_t)cell * kCell : a.junk + junk) + lane;
+            int32_t *pd = (has ? a.prediction + (size_t)cell * kCell : reinterpret_cast<int32_t *>(a.junk + junk + 512)) + lane;
             if (pred_slot_interior(raw)) {
                 predict_node2<0, true>(own, lane, off[0][0], off[0][1], off[0][2], true, a.pp, s_hist, s_bkt, bd, pd);
                 predict_node2<1, true>(own, lane, off[1][0], off[1][1], off[1][2], true, a.pp, s_hist, s_bkt, bd, pd);
@@ -1027,9 +1031,15 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
                 predict_node2<5, true>(own, lane, off[5][0], off[5][1], off[5][2], true, a.pp, s_hist, s_bkt, bd, pd);
                 predict_node2<6, true>(own, lane, off[6][0], off[6][1], off[6][2], true, a.pp, s_hist, s_bkt, bd, pd);
                 predict_node2<7, true>(own, lane, off[7][0], off[7][1], off[7][2], true, a.pp, s_hist, s_bkt, bd, pd);
+            } else if (!has) { // no retained cell at this block slot (image edge): only the fixed number of stores, to the wave's junk lines
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    __builtin_nontemporal_store((uint8_t)0, bd + 64 * i);
+                    __builtin_nontemporal_store(0, pd + 64 * i);
+                }
             } else { // boundary cell: Some/None of node lane + 64 i is bit (lane & 31) of mask word 2 i + (lane >> 5)
                 uint32_t some_bits = 0;
-                if (has) {
+                {
 #pragma unroll
                     for (int i = 0; i < 8; i++) some_bits |= ((cur_masks[slot * 16 + 2 * i + (lane >> 5)] >> (lane & 31)) & 1u) << i;
                 }
@@ -1592,9 +1602,8 @@ hipError_t launch_predict_histogram(const DevicePlan &p, const int32_t *coefs_ch
     }
     uint32_t blocks = p.n_pred_tiles < p.pred_blocks ? p.n_pred_tiles : p.pred_blocks;
     if (!blocks) blocks = 1;
-    a.junk_bucket = p.junk;
+    a.junk = p.junk;
     a.trace = p.trace;
-    a.junk_prediction = reinterpret_cast<int32_t *>(p.junk + 1024);
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(predict_histogram_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, kPred2LdsBytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(predict_histogram_kernel2, dim3(blocks), dim3(kPred2Threads), kPred2LdsBytes, stream, a);

@@ -31,7 +31,7 @@ struct DevicePlan {
     uint32_t *hist_partial = nullptr;     // [hist_blocks][10*1024] scratch for the histogram reduction
     unsigned long long *oob_partial = nullptr; // [hist_blocks]
     uint32_t hist_blocks = 0;
-    uint8_t *junk = nullptr;              // 4 KB: output lines of block slots without a cell (pipelined K2)
+    uint8_t *junk = nullptr;              // [pred_blocks][kPredJunkWaves][kPredJunkBytes]: output lines of block slots without a cell (pipelined K2)
     uint32_t *pred_acc = nullptr;         // [kPredAccRing][kPredAccWords] K2 histogram accumulators, all zero between launches
     mutable uint32_t pred_seq = 0;
     uint32_t pred_blocks = 0;             // workgroups of the pipelined K2: one 1024-thread workgroup per CU
@@ -45,6 +45,7 @@ struct DevicePlan {
     int32_t k3_ablate = 0; // same for the inverse kernel, see InvArgs::ablate
 };
 
+constexpr uint32_t kPredJunkWaves = 16, kPredJunkBytes = 2560; // per wave: 512 B of bucket + 2 KiB of prediction
 constexpr uint32_t kPredAccRing = 8, kPredAccWords = 10 * 1024 + 4;
 
 struct QMatrix {
