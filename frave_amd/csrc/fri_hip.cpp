@@ -281,6 +281,16 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             p->owned.push_back(acc);
             d.pred_acc = static_cast<uint32_t *>(acc);
         }
+        {
+            const size_t bytes = (size_t)kPredAccRing * kFitAccWords * sizeof(unsigned long long);
+            void *acc = nullptr;
+            if (hipMalloc(&acc, bytes) != hipSuccess || hipMemset(acc, 0, bytes) != hipSuccess) {
+                fri_hip_plan_destroy(p);
+                return FRI_HIP_ERR_HIP;
+            }
+            p->owned.push_back(acc);
+            d.fit_acc = static_cast<unsigned long long *>(acc);
+        }
         d.k2_single_buffered = env_int("FRI_HIP_K2_V1") > 0;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");

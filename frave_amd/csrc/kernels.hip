@@ -659,12 +659,8 @@ __device__ __forceinline__ void pred_hand_over(const PredArgs &a, const uint32_t
 __device__ __forceinline__ int pred_slot_cell(int raw) { return raw < 0 ? -1 : raw & (kPredSlotInterior - 1); }
 __device__ __forceinline__ bool pred_slot_interior(int raw) { return raw >= 0 && (raw & kPredSlotInterior) != 0; }
 
-// Two steps so that a kernel can issue the table loads of all its nodes back to back (one wait instead of one round trip per
-// entry: 48 serialised loads used to open every workgroup of K2): the 12-byte row of node p, then the arithmetic.
-__device__ __forceinline__ void pred_load_row(const uint16_t *nbr_table, int p, uint32_t (&row)[3]) {
-    const uint32_t *r = reinterpret_cast<const uint32_t *>(nbr_table + p * 6); // 12-byte rows: 4-byte aligned
-    row[0] = r[0], row[1] = r[1], row[2] = r[2];
-}
+// Packed offsets of one node from its 12-byte row of the neighbour table (host: build_pred_offsets at plan creation; the kernels
+// load the result - the 48 entries of a lane used to be 48 serialised round trips at the start of every workgroup).
 __host__ __device__ __forceinline__ void pred_offsets_from_row(const uint32_t (&row)[3], uint32_t (&out)[3]) {
     uint32_t h[6];
 #pragma unroll
@@ -1106,16 +1102,22 @@ struct FitArgs {
     const uint32_t *valid_mask;
     uint32_t n_tiles;
     PredictParams pp;
+    const uint32_t *pred_off;  // [512][4] packed neighbour offsets per node (build_pred_offsets)
     unsigned long long *gram; // [3][28]   (MODE 0)
     unsigned long long *wtw;  // [3][21]   (MODE 1)
     double *wtr;              // [3][6]    (MODE 1)
+    unsigned long long *acc;  // plan scratch, all zero between launches: [kFitAccInt] integer sums, [18] f64 bit patterns, then the ticket
 };
+constexpr int kFitAccInt = 3 * 28, kFitAccDbl = kFitAccInt, kFitAccTicket = kFitAccInt + 18;
+static_assert(kFitAccTicket + 1 == (int)kFitAccWords, "fit accumulator layout");
 
 template <int MODE>
 __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const FitArgs a) {
     constexpr int NI = MODE == 0 ? 28 : 21;
     __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
     __shared__ int32_t s_slot_cell[kPredSlots];
+    __shared__ int32_t s_slot_interior[kPredSlots];
+    __shared__ uint32_t s_flag;
     __shared__ unsigned long long s_int[3][28];
     __shared__ double s_dbl[3][6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1129,16 +1131,12 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
     // they would not fit 128 VGPRs, and this kernel is not on the critical path. The map is per lane, identical in all waves.
     __shared__ uint32_t s_off[8][64][3];
     if (wave == 0) {
-        uint32_t rows[8][3];
-#pragma unroll
-        for (int i = 0; i < 8; i++) pred_load_row(a.nbr_table, p0 + pstep * i, rows[i]);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            uint32_t o[3];
-            pred_offsets_from_row(rows[i], o);
-            s_off[i][lane][0] = o[0];
-            s_off[i][lane][1] = o[1];
-            s_off[i][lane][2] = o[2];
+            const u32x4 o = reinterpret_cast<const u32x4 *>(a.pred_off)[p0 + pstep * i];
+            s_off[i][lane][0] = o.x;
+            s_off[i][lane][1] = o.y;
+            s_off[i][lane][2] = o.z;
         }
     }
     float vp[6];
@@ -1164,7 +1162,11 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
     const PredTileWalk walk(a.n_tiles);
     for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step) {
         __syncthreads();
-        if (tid < kPredSlots) s_slot_cell[tid] = pred_slot_cell(a.pred_slots[(size_t)tile * kPredSlots + tid]);
+        if (tid < kPredSlots) {
+            const int raw = a.pred_slots[(size_t)tile * kPredSlots + tid];
+            s_slot_cell[tid] = pred_slot_cell(raw);
+            s_slot_interior[tid] = pred_slot_interior(raw) ? 1 : 0;
+        }
         __syncthreads();
         pred_stage_tile(a.coefs, s_slot_cell, s_cells, lane, wave);
         __syncthreads();
@@ -1173,7 +1175,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
             const int cell = s_slot_cell[slot];
             if (cell < 0) continue;
             const uint8_t *own = s_cells + slot * kSlotStride;
-            const bool boundary = __builtin_amdgcn_readfirstlane((int)a.interior[cell]) == 0;
+            const bool boundary = __builtin_amdgcn_readfirstlane(s_slot_interior[slot]) == 0;
 #pragma unroll 1
             for (int i = 0; i < 8; i++) {
                 const int p = p0 + pstep * i;
@@ -1214,17 +1216,74 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
             if (++cells_since_flush >= 1024) flush(); // 8 nodes x 255^2 x 1024 cells < 2^31
         }
     }
-    flush();
-    if (MODE == 1) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) atomicAdd(&s_dbl[g][k], dacc[k]);
-    }
+    // Final reduction through LDS scratch instead of atomics: all 32 (16) lanes of a layer group would add to ONE LDS address,
+    // which costs ~0.7 us per instruction (see K2), 28 + 6 times per wave. The cell image is free now: every lane parks its sums
+    // at its own address, then one thread per (wave, sum, group) adds a group's lanes up - in a fixed order, so the f64 sums of
+    // MODE 1 no longer depend on the arrival order of atomics.
     __syncthreads();
+    {
+        constexpr int NS = NI + (MODE == 1 ? 12 : 0); // int sums + 6 doubles as 12 words
+        int32_t *scr = reinterpret_cast<int32_t *>(s_cells); // [4 waves][NS][64] words at a time: the 36-slot image holds 37 440 B
+        static_assert(4 * NS * 64 * 4 <= kPredSlots * kSlotStride, "scratch fits the cell image");
+        for (int half = 0; half < 2; half++) {
+            const bool mine = (wave >> 2) == half;
+            const int w4 = wave & 3;
+            if (mine) {
+#pragma unroll
+                for (int k = 0; k < NI; k++) scr[(w4 * NS + k) * 64 + lane] = acc[k];
+                if (MODE == 1) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const unsigned long long u = __builtin_bit_cast(unsigned long long, dacc[k]);
+                        scr[(w4 * NS + NI + 2 * k) * 64 + lane] = (int32_t)(uint32_t)u;
+                        scr[(w4 * NS + NI + 2 * k + 1) * 64 + lane] = (int32_t)(uint32_t)(u >> 32);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int t = tid; t < 4 * NI * 3; t += kPredThreads) { // integer sums: (wave of this half, k, group)
+                const int ww = t / (NI * 3), k = (t / 3) % NI, gg = t % 3;
+                const int l0 = gg == 0 ? 0 : gg == 1 ? 32 : 48, l1 = gg == 0 ? 32 : gg == 1 ? 48 : 64;
+                long long sum = 0;
+                for (int l = l0; l < l1; l++) sum += scr[(ww * NS + k) * 64 + l];
+                atomicAdd(&s_int[gg][k], (unsigned long long)sum); // <= 8 adds per address in the whole kernel
+            }
+            if (MODE == 1) {
+                for (int t = tid; t < 4 * 6 * 3; t += kPredThreads) {
+                    const int ww = t / 18, k = (t / 3) % 6, gg = t % 3;
+                    const int l0 = gg == 0 ? 0 : gg == 1 ? 32 : 48, l1 = gg == 0 ? 32 : gg == 1 ? 48 : 64;
+                    double sum = 0.0;
+                    for (int l = l0; l < l1; l++) {
+                        const unsigned long long u = (unsigned long long)(uint32_t)scr[(ww * NS + NI + 2 * k) * 64 + l] |
+                                                     (unsigned long long)(uint32_t)scr[(ww * NS + NI + 2 * k + 1) * 64 + l] << 32;
+                        sum += __builtin_bit_cast(double, u);
+                    }
+                    atomicAdd(&s_dbl[gg][k], sum);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // Hand-over like K2's: add into the plan accumulator, draw a ticket, the last workgroup moves the totals out and re-zeroes.
     if (tid < 3 * NI) {
         const int gg = tid / NI, k = tid % NI;
-        atomicAdd((MODE == 0 ? a.gram : a.wtw) + tid, s_int[gg][k]);
+        __hip_atomic_fetch_add(a.acc + tid, s_int[gg][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (MODE == 1 && tid < 18) atomicAdd(a.wtr + tid, (&s_dbl[0][0])[tid]);
+    if (MODE == 1 && tid < 18) __hip_atomic_fetch_add(reinterpret_cast<double *>(a.acc + kFitAccDbl) + tid, (&s_dbl[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads(); // vmcnt(0) in every wave: the adds are performed
+    if (tid == 0) s_flag = __hip_atomic_fetch_add(a.acc + kFitAccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_flag == 0) return;
+    if (tid < 3 * NI) {
+        (MODE == 0 ? a.gram : a.wtw)[tid] = __hip_atomic_load(a.acc + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.acc + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (MODE == 1 && tid < 18) {
+        const unsigned long long u = __hip_atomic_load(a.acc + kFitAccDbl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.wtr[tid] = __builtin_bit_cast(double, u);
+        __hip_atomic_store(a.acc + kFitAccDbl + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) __hip_atomic_store(a.acc + kFitAccTicket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1612,20 +1671,17 @@ hipError_t launch_predict_histogram(const DevicePlan &p, const int32_t *coefs_ch
 
 hipError_t launch_fit_accumulate(const DevicePlan &p, int mode, const int32_t *coefs_channel, const PredictParams &pp, unsigned long long *sums_int,
                                  double *sums_dbl, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(sums_int, 0, (size_t)3 * (mode == 0 ? 28 : 21) * sizeof(unsigned long long), stream);
-    if (e != hipSuccess) return e;
-    if (mode == 1) {
-        e = hipMemsetAsync(sums_dbl, 0, 18 * sizeof(double), stream);
-        if (e != hipSuccess) return e;
-    }
+    if (!p.fit_acc) return hipErrorInvalidValue;
     FitArgs a{};
     a.coefs = coefs_channel;
     a.pred_slots = p.pred_slots;
     a.nbr_table = p.nbr_table;
+    a.pred_off = p.pred_off;
     a.interior = p.interior;
     a.valid_mask = p.valid_mask;
     a.n_tiles = p.n_pred_tiles;
     a.pp = pp;
+    a.acc = p.fit_acc + (size_t)(p.fit_seq++ % kPredAccRing) * kFitAccWords;
     a.gram = sums_int;
     a.wtw = sums_int;
     a.wtr = sums_dbl;

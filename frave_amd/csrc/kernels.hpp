@@ -34,6 +34,8 @@ struct DevicePlan {
     uint8_t *junk = nullptr;              // [pred_blocks][kPredJunkWaves][kPredJunkBytes]: output lines of block slots without a cell (pipelined K2)
     uint32_t *pred_acc = nullptr;         // [kPredAccRing][kPredAccWords] K2 histogram accumulators, all zero between launches
     mutable uint32_t pred_seq = 0;
+    unsigned long long *fit_acc = nullptr; // [kPredAccRing][kFitAccWords] fit-sum accumulators, all zero between launches
+    mutable uint32_t fit_seq = 0;
     uint32_t pred_blocks = 0;             // workgroups of the pipelined K2: one 1024-thread workgroup per CU
     bool k2_single_buffered = false;      // FRI_HIP_K2_V1=1: the earlier single-buffered K2 (A/B)
     uint32_t n_tiles = 0;
@@ -46,6 +48,7 @@ struct DevicePlan {
 };
 
 constexpr uint32_t kPredJunkWaves = 16, kPredJunkBytes = 2560; // per wave: 512 B of bucket + 2 KiB of prediction
+constexpr uint32_t kFitAccWords = 3 * 28 + 18 + 1;
 constexpr uint32_t kPredAccRing = 8, kPredAccWords = 10 * 1024 + 4;
 
 struct QMatrix {
