@@ -32,6 +32,12 @@ constexpr int32_t kNone = INT32_MIN;
 // to nearby(9 - level)[1] one after the other in the direction of nearby(9 - level)[3], each line front to back, so the order
 // is the sort by (n . p, col . p) with n normal to col; tests/test_emit.py checks that against the oracle's literal walk.
 std::vector<uint32_t> symbol_order(const int32_t *centers_re_im, uint32_t n_cells, int level);
+// All nine levels at once: geometry only, so a caller encoding many frames of one size builds it once.
+struct SymbolOrder {
+    std::vector<uint32_t> level[kDepth];
+    SymbolOrder() = default;
+    SymbolOrder(const int32_t *centers_re_im, uint32_t n_cells);
+};
 
 // ---- ANS model --------------------------------------------------------------------------------------------------
 struct AnsContext {
@@ -50,6 +56,7 @@ int32_t unpack_signed(uint32_t k);                         // utils.rs:42-48
 class RansEncoderMulti {
   public:
     void put_at(int state, uint32_t start, uint32_t freq, uint32_t scale_bits);
+    void reserve(size_t n_symbols) { rev_.reserve(n_symbols / 2 + 64); }
     void flush_all();
     std::vector<uint8_t> data() const; // little-endian words, first word of the stream first
   private:
@@ -77,11 +84,11 @@ struct ChannelStream {
 };
 // coefs / bucket / prediction: this channel's [n_cells][512] planes; hist: [10][1024] counts of K2.
 // Returns "" or an error (conditions under which the reference panics).
-std::string encode_channel(const int32_t *centers_re_im, uint32_t n_cells, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction,
-                           const uint32_t *hist, ChannelStream &out);
+std::string encode_channel(const SymbolOrder &order, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction, const uint32_t *hist,
+                           ChannelStream &out);
 // The (symbol, bucket) sequence in stream order (what encode_channel feeds to the coder); for self-checks.
-void channel_symbols(const int32_t *centers_re_im, uint32_t n_cells, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction,
-                     std::vector<uint16_t> &symbols, std::vector<uint8_t> &buckets);
+void channel_symbols(const SymbolOrder &order, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction, std::vector<uint16_t> &symbols,
+                     std::vector<uint8_t> &buckets);
 // Entropy-layer inverse for self-checks: given the bucket of every symbol in stream order, recover the symbols.
 std::string decode_symbols(const ChannelStream &s, const std::vector<uint8_t> &buckets, std::vector<uint16_t> &symbols);
 

@@ -54,7 +54,7 @@ int fri_emit_channel_symbols(const int32_t *centers_re_im, uint32_t n_cells, con
     if (!centers_re_im || !coefs || !bucket || !prediction || !symbols || !buckets || !n) return -1;
     std::vector<uint16_t> s;
     std::vector<uint8_t> b;
-    channel_symbols(centers_re_im, n_cells, coefs, bucket, prediction, s, b);
+    channel_symbols(SymbolOrder(centers_re_im, n_cells), coefs, bucket, prediction, s, b);
     std::memcpy(symbols, s.data(), s.size() * sizeof(uint16_t));
     std::memcpy(buckets, b.data(), b.size());
     *n = s.size();
@@ -71,8 +71,9 @@ int fri_emit_encode_image(uint32_t width, uint32_t height, uint32_t channels, co
     std::vector<ChannelStream> streams(channels);
     std::vector<ChannelParams> params(channels);
     const size_t plane = (size_t)n_cells * kNodes;
+    const SymbolOrder order(centers_re_im, n_cells); // geometry only: once for all channels
     for (uint32_t ch = 0; ch < channels; ch++) {
-        const std::string e = encode_channel(centers_re_im, n_cells, coefs + ch * plane, bucket + ch * plane, prediction + ch * plane,
+        const std::string e = encode_channel(order, coefs + ch * plane, bucket + ch * plane, prediction + ch * plane,
                                              hist + (size_t)ch * kContexts * kAlphabet, streams[ch]);
         if (!e.empty()) return fail(err, err_cap, "channel " + std::to_string(ch) + ": " + e, -2);
         std::memcpy(params[ch].value, value_params + (size_t)ch * 18, sizeof(params[ch].value));
@@ -95,10 +96,11 @@ int fri_emit_check_image(const uint8_t *frv, size_t len, uint32_t channels, cons
     if (!e.empty()) return fail(err, err_cap, e, -2);
     if (img.channels.size() != channels) return fail(err, err_cap, "channel count", -2);
     const size_t plane = (size_t)n_cells * kNodes;
+    const SymbolOrder order(centers_re_im, n_cells);
     for (uint32_t ch = 0; ch < channels; ch++) {
         std::vector<uint16_t> want, got;
         std::vector<uint8_t> buckets;
-        channel_symbols(centers_re_im, n_cells, coefs + ch * plane, bucket + ch * plane, prediction + ch * plane, want, buckets);
+        channel_symbols(order, coefs + ch * plane, bucket + ch * plane, prediction + ch * plane, want, buckets);
         e = decode_symbols(img.channels[ch], buckets, got);
         if (!e.empty()) return fail(err, err_cap, "channel " + std::to_string(ch) + ": " + e, -2);
         if (got != want) return fail(err, err_cap, "channel " + std::to_string(ch) + ": decoded symbols differ", -4);

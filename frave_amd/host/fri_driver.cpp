@@ -92,10 +92,11 @@ int main(int argc, char **argv) {
         libfri::emit::ParsedImage parsed;
         std::string err = libfri::emit::deserialize(bytes, parsed);
         const size_t plane = (size_t)st.value.image.num_cells * 512;
+        const libfri::emit::SymbolOrder order(st.value.image.centers.data(), st.value.image.num_cells);
         for (uint32_t ch = 0; err.empty() && ch < c; ch++) {
             std::vector<uint16_t> want, got;
             std::vector<uint8_t> buckets;
-            libfri::emit::channel_symbols(st.value.image.centers.data(), st.value.image.num_cells, st.value.image.coefficients.data() + ch * plane,
+            libfri::emit::channel_symbols(order, st.value.image.coefficients.data() + ch * plane,
                                           st.value.image.bucket[ch].data(), st.value.image.prediction[ch].data(), want, buckets);
             err = libfri::emit::decode_symbols(parsed.channels[ch], buckets, got);
             if (err.empty() && got != want) err = "decoded symbols differ";

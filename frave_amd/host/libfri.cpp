@@ -271,6 +271,7 @@ Result<CompressedImage> stages::entropy_coding::encode(const WaveletImage &image
     r.value.metadata = image.metadata;
     r.value.channel_data.resize(channels);
     r.value.params.resize(channels);
+    const emit::SymbolOrder order(image.centers.data(), image.num_cells);
     for (uint32_t ch = 0; ch < channels; ch++) {
         if (contexts[ch].size() != (size_t)CONTEXT_AMOUNT) {
             r.error = "missing contexts";
@@ -278,7 +279,7 @@ Result<CompressedImage> stages::entropy_coding::encode(const WaveletImage &image
         }
         std::vector<uint32_t> hist((size_t)CONTEXT_AMOUNT * ALPHABET_SIZE);
         for (int b = 0; b < CONTEXT_AMOUNT; b++) std::copy(contexts[ch][b].freqs.begin(), contexts[ch][b].freqs.end(), hist.begin() + (size_t)b * ALPHABET_SIZE);
-        const std::string err = emit::encode_channel(image.centers.data(), image.num_cells, image.coefficients.data() + ch * plane, image.bucket[ch].data(),
+        const std::string err = emit::encode_channel(order, image.coefficients.data() + ch * plane, image.bucket[ch].data(),
                                                      image.prediction[ch].data(), hist.data(), r.value.channel_data[ch]);
         if (!err.empty()) {
             r.error = "channel " + std::to_string(ch) + ": " + err;
