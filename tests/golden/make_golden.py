@@ -43,7 +43,25 @@ def build(name):
     return out
 
 
+# .frv files of the host emit path (oracle/emit_oracle.py: literal scan_level walk, finalize_context, Python rans64, serialize).
+# Byte-stream parity with the reference's `rans` crate is unpinned: these pin OUR stream against regressions.
+EMIT_CASES = {"emit_mixed_129x65_luma": (129, 65, 1, 7), "emit_mixed_96x257_rgb": (96, 257, 3, 7)}
+
+
+def build_frv(name):
+    from oracle import emit_oracle
+    from tests.test_emit import _arrays
+
+    w, h, c, seed = EMIT_CASES[name]
+    W, coefs, bucket, pred, hist, vp, wp = _arrays(w, h, c, seed)
+    return emit_oracle.encode_image(W, coefs, bucket, pred, hist, vp, wp)
+
+
 if __name__ == "__main__":
     for name in CASES:
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **build(name))
+        print("wrote", name)
+    for name in EMIT_CASES:
+        with open(os.path.join(HERE, name + ".frv"), "wb") as f:
+            f.write(build_frv(name))
         print("wrote", name)

@@ -111,6 +111,19 @@ def test_frv_bytes_match_restatement_and_decode(shape):
         assert list(zip(sym.tolist(), bk.tolist())) == ref
 
 
+@pytest.mark.parametrize("name", ["emit_mixed_129x65_luma", "emit_mixed_96x257_rgb"])
+def test_frv_golden_files(name):
+    """committed .frv fixtures (tests/golden/make_golden.py): the product and the restatement both still produce them"""
+    from tests.golden.make_golden import EMIT_CASES, build_frv
+
+    w, h, c, seed = EMIT_CASES[name]
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".frv"), "rb") as f:
+        golden = f.read()
+    W, coefs, bucket, pred, hist, vp, wp = _arrays(w, h, c, seed)
+    assert emit.encode_image(w, h, W.centers(), coefs, bucket, pred, hist, vp, wp) == golden
+    assert build_frv(name) == golden
+
+
 def test_image_with_an_empty_context_is_reported_like_the_reference_panic():
     w, h, c = 64, 48, 1  # too few symbols for ten contexts
     W, coefs, bucket, pred, hist, vp, wp = _arrays(w, h, c, 7, kind="noise")
