@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--slots", type=int, default=8, help="distinct image/coefficient buffer pairs the steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also time K2 (predict+histogram), K3 (inverse) and RGB")
+    ap.add_argument("--extras", action="store_true", help="also time an 8-image batch launch of K1, K2 (predict+histogram) and K3 (inverse)")
     args = ap.parse_args()
 
     import numpy as np
@@ -164,8 +164,9 @@ def main():
     }
 
     # The same kernel with all slots in ONE launch (the batch entry point; BASELINE config 4 runs like this): the ramp and the
-    # tail of consecutive images overlap. Reported next to the single-image figures, never as `value`.
-    if rank == 0:
+    # tail of consecutive images overlap. Reported next to the single-image figures, never as `value`; only with --extras, so that
+    # the default command launches nothing but single-image kernels (its rocprofv3 kernel stats are then those of `roofline`).
+    if args.extras and rank == 0:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 20
         plan.transform_quant_dev(px0, co0, stream=stream, n_images=args.slots, pixel_stride=pstride, coef_stride=cstride)

@@ -6,8 +6,12 @@ TAG=$1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $GRAFT_REPO_ROOT/bench.py --extras > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --extras > $OUT/bench_traced.json 2> $OUT/trace.log
+python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
+python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --extras > $OUT/bench_extras.json 2> $OUT/bench_extras.err
+# the default command (single-image K1 launches only): its kernel stats are the ones roofline.kernel_us must agree with
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_traced.json 2> $OUT/trace.log
+# and once more with the extras (8-image launches of the same kernel, K2, K3)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_extras -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --extras > $OUT/bench_traced_extras.json 2> $OUT/trace_extras.log
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/tools/k1_run.py 40 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/tools/k1_run.py 40 > $OUT/pmc_write.log 2>&1
 cd $GRAFT_REPO_ROOT
@@ -16,9 +20,11 @@ python3 tools/pmc_summary.py $OUT/pmc_write fwd_transform >> $OUT/pmc_summary.tx
 python3 - <<PY
 import csv, glob
 rows = []
-for f in glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True):
+for tag, sub in (("", "trace"), ("_extras", "trace_extras")):
+  rows = []
+  for f in glob.glob("$OUT/" + sub + "/**/*kernel_stats.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
-with open("$OUT/kernel_stats_short.csv", "w") as o:
+  with open("$OUT/kernel_stats_short" + tag + ".csv", "w") as o:
     w = csv.writer(o)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
     for r in rows:
