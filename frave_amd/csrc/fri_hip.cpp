@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -189,6 +190,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
     tp.band_rows = env_int("FRI_HIP_BAND_ROWS");
     tp.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
     tp.cells_per_wg = env_int("FRI_HIP_CELLS_PER_WG");
+    tp.batch_share_tiles = env_int("FRI_HIP_BATCH_SHARE_TILES");
     // LDS budget of one forward tile buffer: 4 chunks of 16 bytes per thread for planes (the tuned variant), 6 for RGB
     tp.tile_buffer_bytes = (channels == 1 ? 4 : 6) * 256 * 16;
     if (env_int("FRI_HIP_TILE_BYTES") > 0) tp.tile_buffer_bytes = env_int("FRI_HIP_TILE_BYTES");
@@ -216,7 +218,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         probe.lds_pitch = p->geo.lds_pitch;
         probe.lds_rows = p->geo.lds_rows;
         probe.max_tile_cells = p->geo.max_tile_cells;
-        probe.max_wg_tiles = p->geo.max_wg_tiles;
+        probe.max_wg_tiles = std::max(p->geo.max_wg_tiles, p->geo.max_wg_tiles_batch);
         if (fwd_plan_fits(probe)) break;
         tp.band_rows = p->geo.band_rows;
         tp.cells_per_tile = p->geo.cells_per_tile - 1;
@@ -240,7 +242,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         std::vector<uint16_t> tab(&st.nbr_table[0][0], &st.nbr_table[0][0] + kCell * 6);
         std::vector<uint32_t> pred_off((size_t)kCell * 4);
         build_pred_offsets(tab.data(), pred_off.data());
-        if ((rc = upload(p, g.tiles, d.tiles)) || (rc = upload(p, g.tile_cells, d.tile_cells)) || (rc = upload(p, g.tile_meta, d.tile_meta)) || (rc = upload(p, g.wg_tiles, d.wg_tiles)) || (rc = upload(p, g.centers, d.centers)) ||
+        if ((rc = upload(p, g.tiles, d.tiles)) || (rc = upload(p, g.tile_cells, d.tile_cells)) || (rc = upload(p, g.tile_meta, d.tile_meta)) || (rc = upload(p, g.wg_tiles, d.wg_tiles)) || (rc = upload(p, g.wg_tiles_batch, d.wg_tiles_batch)) || (rc = upload(p, g.centers, d.centers)) ||
             (rc = upload(p, g.interior, d.interior)) || (rc = upload(p, g.valid_mask, d.valid_mask)) ||
             (rc = upload(p, g.nbr_cells, d.nbr_cells)) || (rc = upload(p, g.pred_slots, d.pred_slots)) || (rc = upload(p, tab, d.nbr_table)) || (rc = upload(p, pred_off, d.pred_off))) {
             fri_hip_plan_destroy(p);
@@ -257,7 +259,8 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.cells_per_tile = g.cells_per_tile;
         d.max_tile_cells = g.max_tile_cells;
         d.covers_image = g.n_valid_leaves == (uint64_t)g.width * g.height;
-        d.max_wg_tiles = g.max_wg_tiles;
+        d.max_wg_tiles = std::max(g.max_wg_tiles, g.max_wg_tiles_batch);
+        d.n_wg_batch = (uint32_t)g.wg_tiles_batch.size() - 1;
         d.max_wg_cells = g.max_wg_cells;
         d.n_wg = (uint32_t)g.wg_tiles.size() - 1;
         d.pred_blocks = (uint32_t)ctx->cu_count;
@@ -294,6 +297,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.k2_single_buffered = env_int("FRI_HIP_K2_V1") > 0;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
+        if (const char *e = std::getenv("FRI_HIP_K1_BATCH_SHARES")) d.k1_batch_shares = std::atoi(e) != 0;
         d.k3_ablate = env_int("FRI_HIP_K3_ABLATE");
         if (env_int("FRI_HIP_TRACE") > 0) {
             const size_t bytes = (size_t)d.n_wg * 16 * sizeof(unsigned long long);

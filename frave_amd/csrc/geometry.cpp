@@ -435,6 +435,14 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         g.max_wg_tiles = std::max(g.max_wg_tiles, (int32_t)g.tiles.size() - g.wg_tiles.back());
         g.wg_tiles.push_back((int32_t)g.tiles.size());
     }
+    {
+        const size_t cells_target = (size_t)(tp.batch_share_tiles > 0 ? tp.batch_share_tiles : 4) * cells_per_tile;
+        size_t merge = 1;
+        while (merge * (size_t)g.cells_per_wg < cells_target && merge < n_wg) merge++;
+        for (size_t sh = 0; sh < n_wg; sh += merge) g.wg_tiles_batch.push_back(g.wg_tiles[sh]);
+        g.wg_tiles_batch.push_back(g.wg_tiles[n_wg]);
+        for (size_t k = 0; k + 1 < g.wg_tiles_batch.size(); k++) g.max_wg_tiles_batch = std::max(g.max_wg_tiles_batch, g.wg_tiles_batch[k + 1] - g.wg_tiles_batch[k]);
+    }
     // A staged row starts at the 16-byte boundary at or below its first byte: up to 15 bytes of lead-in.
     // The pitch (in dwords) is kept = 8 or 24 mod 32: with the cell footprint that gives the fewest LDS bank
     // conflicts for the byte gather (2-way instead of 4-way at a multiple of 64 bytes).

@@ -65,6 +65,11 @@ struct Geometry {
     std::vector<int32_t> tile_cells;
     std::vector<TileCell> tile_meta;    // same order as tile_cells
     std::vector<int32_t> wg_tiles;      // [n_wg + 1] tile range of each workgroup share
+    // Shares for batch launches: runs of consecutive shares merged until a share holds >= 4 tiles' worth of cells. A small image
+    // is cut into one-tile shares to fill the machine on its own; with hundreds of frames in one launch that only multiplies the
+    // per-workgroup start-up cost.
+    std::vector<int32_t> wg_tiles_batch; // [n_wg_batch + 1]
+    int32_t max_wg_tiles_batch = 0;
     int32_t lds_pitch = 0;   // bytes per staged row (multiple of 16)
     int32_t lds_rows = 0;    // max rows per tile
     int32_t band_rows = 0, cells_per_tile = 0, cells_per_wg = 0;
@@ -93,6 +98,7 @@ struct TilingParams {
     // Bytes one LDS tile buffer may take (rows * pitch); tiles of sparse bands (the image's last rows) are cut narrower
     // instead of sizing every buffer for them. 0 = no cap.
     int tile_buffer_bytes = 0;
+    int batch_share_tiles = 0; // tiles' worth of cells per merged batch share (0 = 4)
 };
 
 // Returns "" on success, else an error string.

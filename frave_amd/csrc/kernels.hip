@@ -1590,8 +1590,10 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
     a.coef_stride = coef_stride;
     a.tiles = p.tiles;
     a.tile_meta = p.tile_meta;
-    a.wg_tiles = p.wg_tiles;
-    a.n_wg = p.n_wg;
+    // many images per launch: merged shares (the machine is full anyway; fewer, longer workgroups amortise their start-up)
+    const bool batch = n_images >= 8 && p.n_wg_batch > 0 && p.n_wg_batch < p.n_wg && p.k1_batch_shares;
+    a.wg_tiles = batch ? p.wg_tiles_batch : p.wg_tiles;
+    a.n_wg = batch ? p.n_wg_batch : p.n_wg;
     a.width = p.width;
     a.height = p.height;
     a.F = p.F;
@@ -1606,7 +1608,7 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
     a.ablate = p.k1_ablate;
     a.trace = p.trace;
     const size_t lds = fwd_lds_bytes(p);
-    const dim3 grid(p.n_wg, n_images), block(kFwdThreads);
+    const dim3 grid(a.n_wg, n_images), block(kFwdThreads);
     // EDGE variant only when a 16-byte chunk could straddle the ends of one of the caller's image buffers
     const size_t img_bytes = (size_t)p.width * p.height * p.channels;
     const bool edge = (reinterpret_cast<uintptr_t>(pixels) & 15) || (img_bytes & 15) || (n_images > 1 && (pixel_stride & 15));

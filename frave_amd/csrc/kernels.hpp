@@ -15,6 +15,8 @@ struct DevicePlan {
     const int32_t *tile_cells = nullptr;
     const TileCell *tile_meta = nullptr;  // [F] in tile order
     const int32_t *wg_tiles = nullptr;    // [n_wg + 1] tile range per workgroup share
+    const int32_t *wg_tiles_batch = nullptr; // [n_wg_batch + 1] merged shares for launches over many images
+    uint32_t n_wg_batch = 0;
     uint32_t n_wg = 0;
     int32_t max_tile_cells = 0;
     bool covers_image = false;            // every pixel of the image is a leaf of a retained cell
@@ -42,6 +44,7 @@ struct DevicePlan {
     uint32_t F = 0;
     int32_t width = 0, height = 0, channels = 0;
     int32_t lds_pitch = 0, lds_rows = 0, cells_per_tile = 0;
+    bool k1_batch_shares = true; // FRI_HIP_K1_BATCH_SHARES=0 disables the merged shares (A/B)
     int32_t k1_ablate = 0; // timing-only ablation flags, see FwdArgs::ablate
     unsigned long long *trace = nullptr; // [n_wg][16] diagnostic timeline (FRI_HIP_TRACE=1), else null
     int32_t k3_ablate = 0; // same for the inverse kernel, see InvArgs::ablate
