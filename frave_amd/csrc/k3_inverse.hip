@@ -1,0 +1,321 @@
+// k3_inverse.hip -- K3 inverse_transform: dequantisation + inverse residue transform + clamp
+// (stages/quantization.rs:27-45; stages/wavelet_transform.rs:358-381; images.rs:103-111).
+#include "device_common.hpp"
+
+namespace fri {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// K3: inverse transform. A workgroup walks the forward kernel's tiles of its share (<= cells_per_tile cells of one
+// band each), one wave per (cell, channel) item; mirror of fwd_wave. A cell's 512 pixels are scattered over ~50
+// rows, so byte stores straight from registers cost one L2 write request per pixel (measured: 41 us). Instead the
+// waves scatter into an LDS image of the tile's pixel rectangle -- 16 bit per byte: value | 0x100, the ninth bit
+// says "a cell of this tile owns the byte" -- and the workgroup then writes the rectangle out row by row: one
+// aligned dword store where all four bytes are owned (90 % of the bytes: the interior of the tile's footprint);
+// the dwords on its fractal rim are queued and written with byte stores from densely packed lanes afterwards
+// (a store instruction costs the same with 2 or 64 active lanes). Every pixel has exactly one owning cell, so no
+// byte is written twice and none is skipped. The coefficients of tile i + 1 are loaded while tile i is processed.
+// ------------------------------------------------------------------------------------------------
+constexpr int kInvThreads = 256;
+constexpr int kInvWaves = kInvThreads / 64;
+constexpr int kInvMaxItemsPerWave = 4; // (cell, channel) items of one tile per transform wave
+
+struct InvArgs {
+    const int32_t *coefs;
+    uint8_t *pixels;
+    const Tile *tiles;
+    const TileCell *tile_meta; // in tile order
+    const int32_t *wg_tiles;   // [n_wg + 1]
+    int32_t width, height, channels;
+    uint32_t F, n_wg;
+    int32_t buf_bytes;   // LDS pixel rectangle (16 bit per byte), multiple of 16
+    int32_t queue_bytes; // LDS rim queue per wave
+    int32_t max_wg_tiles;
+    int32_t q_identity;
+    int32_t ablate; // timing experiments only (FRI_HIP_K3_ABLATE): 1 = no global stores, 2 = no LDS scatter
+    unsigned long long *trace; // diagnostic timeline, null in production
+    QMatrix q;
+};
+
+__device__ __forceinline__ int dequant_ref(int v, int heap_index, const InvArgs &a) {
+    // quantization::decode divides like encode (quantization.rs:37); reproduced bit for bit.
+    if (a.q_identity || v == kNone) return v;
+    return v / a.q.q[quant_layer(heap_index)];
+}
+
+// The eight coefficient dwords a lane holds of one (cell, channel) item: heap nodes lane (levels 0-5 and the DC), 64 + lane,
+// 128 + 2 lane + {0, 1}, 256 + 4 lane + {0..3}.
+struct InvRegs {
+    int32_t d8[4], d7[2], d6, low;
+};
+
+__device__ __forceinline__ InvRegs inv_load(const int32_t *in, int lane) {
+    // read once: streaming loads keep the eight L2s for the pixel lines that neighbouring tiles complete
+    const i32x4 c8 = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(in + 256 + 4 * lane));
+    const i32x2 c7 = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(in + 128 + 2 * lane));
+    InvRegs r;
+    r.d8[0] = c8.x, r.d8[1] = c8.y, r.d8[2] = c8.z, r.d8[3] = c8.w;
+    r.d7[0] = c7.x, r.d7[1] = c7.y;
+    r.d6 = __builtin_nontemporal_load(in + 64 + lane);
+    r.low = __builtin_nontemporal_load(in + lane);
+    return r;
+}
+
+// extract_values for one item (wavelet_transform.rs:358-380) on the lane-distributed tree: six cross-lane levels top-down,
+// then levels 6-8 in registers. leaf[j] = value of leaf 8 lane + j (0 where the last difference is None: `if let Some(dif)`
+// at :365 leaves those pixels at the raster's initial 0).
+// SOME = the wave has checked that none of the item's 512 coefficients is None (every interior cell of an encoder's
+// output): the butterflies then need no None test. Wrapping arithmetic like a release build of the reference.
+template <bool SOME>
+__device__ __forceinline__ void unpair_t(int low, int d, int &left, int &right) {
+    if (!SOME && d == kNone) {
+        left = 0;
+        right = 0;
+    } else {
+        right = sub_w(low, d / 2);
+        left = add_w(d, right);
+    }
+}
+template <bool SOME>
+__device__ __forceinline__ void inv_wave(InvRegs c, int lane, const InvArgs &a, int (&leaf)[8]) {
+    if (!a.q_identity) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) c.d8[i] = dequant_ref(c.d8[i], 256 + 4 * lane + i, a);
+#pragma unroll
+        for (int i = 0; i < 2; i++) c.d7[i] = dequant_ref(c.d7[i], 128 + 2 * lane + i, a);
+        c.d6 = dequant_ref(c.d6, 64 + lane, a);
+        c.low = dequant_ref(c.low, lane, a);
+    }
+    int s = __shfl(c.low, 0); // low_pass_values[1] = coefficients[0].unwrap()  (:361)
+#pragma unroll
+    for (int j = 5; j >= 0; j--) { // levels 0..5
+        const int lv = 5 - j;
+        const int d = __shfl(c.low, (1 << lv) + (lane >> (j + 1)));
+        int l, r;
+        unpair_t<SOME>(s, d, l, r);
+        s = ((lane >> j) & 1) ? r : l;
+    }
+    int s7[2], s8[4];
+    unpair_t<SOME>(s, c.d6, s7[0], s7[1]);
+#pragma unroll
+    for (int i = 0; i < 2; i++) unpair_t<SOME>(s7[i], c.d7[i], s8[2 * i], s8[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) unpair_t<SOME>(s8[i], c.d8[i], leaf[2 * i], leaf[2 * i + 1]);
+}
+__device__ __forceinline__ bool inv_has_none(const InvRegs &c) {
+    const bool n = c.d8[0] == kNone || c.d8[1] == kNone || c.d8[2] == kNone || c.d8[3] == kNone || c.d7[0] == kNone || c.d7[1] == kNone ||
+                   c.d6 == kNone || c.low == kNone;
+    return __any(n);
+}
+
+// The loads of one tile's items for this wave. Slots past the tile's items re-load its last item (no conditional loads:
+// a load the compiler cannot prove executed costs an immediate wait).
+template <int NI>
+__device__ __forceinline__ void inv_prefetch(const InvArgs &a, const Tile &t, const TileCell *cells, int wave, int lane, InvRegs (&r)[NI]) {
+    const int C = a.channels, n_items = t.cell_count * C;
+#pragma unroll
+    for (int s = 0; s < NI; s++) {
+        const int item = min(wave + kInvWaves * s, n_items - 1);
+        const int cl = item / C, ch = item - cl * C;
+        r[s] = inv_load(a.coefs + ((size_t)ch * a.F + (uint32_t)cells[cl].cell) * kCell, lane);
+    }
+}
+
+template <int NI>
+__global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const InvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint16_t *img16 = reinterpret_cast<uint16_t *>(lds);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint16_t *queue = reinterpret_cast<uint16_t *>(lds + a.buf_bytes + wave * a.queue_bytes);
+    Tile *lds_tiles = reinterpret_cast<Tile *>(lds + a.buf_bytes + kInvWaves * a.queue_bytes);
+    TileCell *lds_cells = reinterpret_cast<TileCell *>(lds_tiles + a.max_wg_tiles);
+    // Blocks of one XCD take a contiguous range of shares: the rim bytes of neighbouring tiles complete their lines in ONE L2.
+    const uint32_t wg = xcd_contiguous_share(blockIdx.x, a.n_wg);
+    const int tb = a.wg_tiles[wg], te = a.wg_tiles[wg + 1];
+    const int C = a.channels;
+    const uint32_t base_lo = (uint32_t)reinterpret_cast<uintptr_t>(a.pixels);
+    const uint32_t wc = (uint32_t)a.width * (uint32_t)C;
+    trace_stamp(a.trace, wg, 0, tid);
+    {
+        const Tile first = a.tiles[tb], last = a.tiles[te - 1];
+        const int n_cells = last.cell_begin + last.cell_count - first.cell_begin;
+        if (tid < te - tb) lds_tiles[tid] = a.tiles[tb + tid];
+        for (int i = tid; i < n_cells; i += kInvThreads) {
+            TileCell tc = a.tile_meta[first.cell_begin + i];
+            lds_cells[i] = tc;
+        }
+        u32x4 *z = reinterpret_cast<u32x4 *>(lds);
+        for (int i = tid; i < a.buf_bytes / 16; i += kInvThreads) z[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    const int cell0 = lds_tiles[0].cell_begin;
+    trace_stamp(a.trace, wg, 1, tid);
+
+    InvRegs pre[NI];
+    inv_prefetch<NI>(a, lds_tiles[0], lds_cells, wave, lane, pre);
+    for (int ti = tb; ti < te; ti++) {
+        const Tile t = lds_tiles[ti - tb];
+        InvRegs cur[NI];
+#pragma unroll
+        for (int s = 0; s < NI; s++) cur[s] = pre[s];
+        {
+            const Tile tn = lds_tiles[min(ti + 1, te - 1) - tb];
+            inv_prefetch<NI>(a, tn, lds_cells + (tn.cell_begin - cell0), wave, lane, pre);
+        }
+        const int n_items = t.cell_count * C;
+        // Staged rows start at the 16-byte boundary at or below their first byte (lead-in 0..15), so every global quad is an
+        // aligned 16-byte store; rq quads (16 output bytes = 16 LDS halfwords each) per row.
+        const int rq = (t.width_px * C + 30) >> 4;
+        const int pitch16 = rq * 16; // LDS halfwords per staged row
+        int leaf[NI][8];
+#pragma unroll
+        for (int s = 0; s < NI; s++) {
+            if (inv_has_none(cur[s])) inv_wave<false>(cur[s], lane, a, leaf[s]);
+            else inv_wave<true>(cur[s], lane, a, leaf[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < NI; s++) {
+            const int item = wave + kInvWaves * s;
+            if (item < n_items && !(a.ablate & 2)) {
+                const int cl = item / C, ch = item - cl * C;
+                const TileCell tc = lds_cells[t.cell_begin - cell0 + cl];
+                const int x0 = tc.cx + lane_dx(lane), y0 = tc.cy + lane_dy(lane);
+                int rowbase[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) {
+                    const int y = y0 + dy;
+                    const uint32_t g = (uint32_t)y * wc + (uint32_t)(t.x_lo * C); // byte offset of the staged row (only bits 0-3 matter)
+                    rowbase[dy] = (y - t.y_lo) * pitch16 + (int)((base_lo + g) & 15u) + (x0 - t.x_lo) * C + ch;
+                }
+                if (__builtin_amdgcn_readfirstlane(tc.interior)) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) img16[rowbase[leaf_dy(j)] + leaf_dx(j) * C] = (uint16_t)(0x100 | min(max(leaf[s][j], 0), 255));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int x = x0 + leaf_dx(j), y = y0 + leaf_dy(j);
+                        if (x >= 0 && y >= 0 && x < a.width && y < a.height) // set_pixel, images.rs:104
+                            img16[rowbase[leaf_dy(j)] + leaf_dx(j) * C] = (uint16_t)(0x100 | min(max(leaf[s][j], 0), 255));
+                    }
+                }
+            }
+        }
+        lds_barrier(); // the rectangle is complete
+
+        // Quad pass over the flattened rectangle: a quad whose 16 bytes are all owned goes out as one store, a partly owned
+        // one is queued as (row << 8 | quad).
+        int qn = 0;
+        const int n_quads = t.n_rows * rq;
+        const float inv_rq = 1.0f / (float)rq;
+        for (int q0 = 0; q0 < n_quads; q0 += kInvThreads) {
+            const int qi = q0 + tid;
+            u32x4 lo = u32x4{0u, 0u, 0u, 0u}, hi = lo;
+            u32x4 *src = reinterpret_cast<u32x4 *>(img16) + 2 * qi;
+            int r = 0, k = 0;
+            if (qi < n_quads) {
+                lo = src[0], hi = src[1];
+                r = (int)(((float)qi + 0.5f) * inv_rq); // exact: qi < 2^16
+                k = qi - r * rq;
+            }
+            const uint32_t all = lo.x & lo.y & lo.z & lo.w & hi.x & hi.y & hi.z & hi.w & 0x01000100u;
+            const uint32_t any = (lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) & 0x01000100u;
+            const bool full = all == 0x01000100u, rim = any != 0 && !full;
+            if (full) {
+                src[0] = u32x4{0u, 0u, 0u, 0u};
+                src[1] = u32x4{0u, 0u, 0u, 0u};
+                const size_t g = ((size_t)(t.y_lo + r) * (size_t)a.width + (size_t)t.x_lo) * (size_t)C;
+                uint8_t *p = a.pixels + g - (int)((base_lo + (uint32_t)g) & 15u) + 16 * k; // 16-byte aligned
+                const u32x4 out{__builtin_amdgcn_perm(lo.y, lo.x, 0x06040200u), __builtin_amdgcn_perm(lo.w, lo.z, 0x06040200u),
+                                __builtin_amdgcn_perm(hi.y, hi.x, 0x06040200u), __builtin_amdgcn_perm(hi.w, hi.z, 0x06040200u)};
+                if (!(a.ablate & 1)) *reinterpret_cast<u32x4 *>(p) = out;
+            }
+            const unsigned long long m = __ballot(rim);
+            if (rim) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(r << 8 | k);
+            qn += __popcll(m);
+        }
+        // Rim pass: one queued quad per lane; owned dwords as dword stores, the rest byte by byte.
+        for (int e0 = 0; e0 < qn; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < qn) {
+                const int rk = queue[e], r = rk >> 8, k = rk & 255;
+                const size_t g = ((size_t)(t.y_lo + r) * (size_t)a.width + (size_t)t.x_lo) * (size_t)C;
+                uint8_t *p = a.pixels + g - (int)((base_lo + (uint32_t)g) & 15u) + 16 * k;
+                u32x4 *src = reinterpret_cast<u32x4 *>(img16 + r * pitch16) + 2 * k;
+                const u32x4 lo = src[0], hi = src[1];
+                src[0] = u32x4{0u, 0u, 0u, 0u};
+                src[1] = u32x4{0u, 0u, 0u, 0u};
+                const uint32_t u[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (!(a.ablate & 1)) {
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const uint32_t v0 = u[2 * d], v1 = u[2 * d + 1];
+                        const uint32_t own = (v0 & 0x01000100u) | ((v1 & 0x01000100u) << 1);
+                        if (own == 0x03000300u) {
+                            *reinterpret_cast<uint32_t *>(p + 4 * d) = __builtin_amdgcn_perm(v1, v0, 0x06040200u);
+                        } else if (own != 0) {
+                            if (v0 & 0x00000100u) p[4 * d + 0] = (uint8_t)v0;
+                            if (v0 & 0x01000000u) p[4 * d + 1] = (uint8_t)(v0 >> 16);
+                            if (v1 & 0x00000100u) p[4 * d + 2] = (uint8_t)v1;
+                            if (v1 & 0x01000000u) p[4 * d + 3] = (uint8_t)(v1 >> 16);
+                        }
+                    }
+                }
+            }
+        }
+        lds_barrier(); // the rectangle is all zero again
+        trace_stamp(a.trace, wg, 2 + ti - tb, tid);
+    }
+    trace_exit(a.trace, wg, tid);
+}
+
+
+} // namespace
+
+// 16 bit per staged byte; a staged row holds <= lds_pitch bytes including its lead-in (lds_pitch >= widest row + 15).
+static size_t inv_buf_bytes(const DevicePlan &p) { return (size_t)p.lds_rows * (size_t)p.lds_pitch * 2; }
+// worst case: every quad a wave looks at is a rim quad (2 bytes per entry), rounded to 16
+static size_t inv_queue_bytes(const DevicePlan &p) {
+    const size_t quads = (size_t)p.lds_rows * (size_t)(p.lds_pitch / 16);
+    return (((quads + kInvThreads - 1) / kInvThreads) * 64 * 2 + 15) & ~(size_t)15;
+}
+size_t inv_lds_bytes(const DevicePlan &p) { return inv_buf_bytes(p) + kInvWaves * inv_queue_bytes(p) + (size_t)p.max_wg_tiles * sizeof(Tile) + (size_t)p.max_wg_cells * sizeof(TileCell); }
+hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, const QMatrix &q, uint8_t *pixels, hipStream_t stream) {
+    // RasterImage::from_wavelet starts from an all-zero raster (wavelet_transform.rs:309-317). When every pixel belongs to a
+    // retained cell the kernel writes all of them (zeros included); only a lattice with holes (very thin images) needs the fill.
+    if (!p.covers_image) {
+        hipError_t e = hipMemsetAsync(pixels, 0, (size_t)p.width * p.height * p.channels, stream);
+        if (e != hipSuccess) return e;
+    }
+    InvArgs a{};
+    a.coefs = coefs;
+    a.pixels = pixels;
+    a.tiles = p.tiles;
+    a.tile_meta = p.tile_meta;
+    a.wg_tiles = p.wg_tiles;
+    a.width = p.width;
+    a.height = p.height;
+    a.channels = p.channels;
+    a.F = p.F;
+    a.n_wg = p.n_wg;
+    a.buf_bytes = (int32_t)inv_buf_bytes(p);
+    a.max_wg_tiles = p.max_wg_tiles;
+    a.ablate = p.k3_ablate;
+    a.trace = p.trace;
+    a.q = q;
+    a.q_identity = 1;
+    for (int i = 0; i <= 9; i++) a.q_identity &= (q.q[i] == 1);
+    a.queue_bytes = (int32_t)inv_queue_bytes(p);
+    const int items_per_wave = (p.max_tile_cells * p.channels + kInvWaves - 1) / kInvWaves;
+    if (items_per_wave > kInvMaxItemsPerWave || p.max_wg_tiles > kInvThreads || p.lds_rows > 256 || p.lds_pitch / 16 > 256) return hipErrorInvalidConfiguration;
+    const size_t lds = inv_lds_bytes(p);
+    void (*kern)(const InvArgs) = items_per_wave <= 1 ? inverse_transform_kernel<1> : items_per_wave == 2 ? inverse_transform_kernel<2> : inverse_transform_kernel<4>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.n_wg), dim3(kInvThreads), lds, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace fri

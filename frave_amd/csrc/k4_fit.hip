@@ -1,0 +1,239 @@
+// k4_fit.hip -- the normal-equation sums behind the context-model fit (next row 8f-3).
+#include "gather_common.hpp"
+
+namespace fri {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Fit accumulators: the sums behind ContextModeler::optimize_parameters
+// (context_modeling.rs:79-213), so that the host solves two 6 x 6 systems per layer group instead of running an SVD over
+// n x 6 f32 matrices (n = 8.5 M rows at 4096^2). Same tiles, staging and LDS gather as K2.
+//   MODE 0 (value fit, :175-202): per layer group g, the Gram matrix of u = [v0..v5, value] over the Some nodes of levels
+//           1..8: gram[g][28] (upper triangle, row major) -- A^T A, A^T b and b^T b in exact integers.
+//   MODE 1 (width fit, :144-173): with the value parameters x: r = |f32(value) - f32 prediction| (the same left-to-right f32
+//           evaluation as K2 / nalgebra's gemv), w = [1, |v0-v3|, |v1-v2|, |v4-v5|, |v1-v5|, |v2-v4|]:
+//           wtw[g][21] = sum w w^T (exact integers), wtr[g][6] = sum w r (f64).
+// Lanes are bound to layer groups so that a lane needs one set of accumulators: lanes 0..31 take the level-8 nodes
+// (group 0), 32..47 level 7 (group 1), 48..63 levels 0..6 (group 2; heap index 0, 1 are not part of the fit).
+// ------------------------------------------------------------------------------------------------
+struct FitArgs {
+    const int32_t *coefs;
+    const int32_t *pred_slots;
+    const uint16_t *nbr_table;
+    const uint8_t *interior;
+    const uint32_t *valid_mask;
+    uint32_t n_tiles;
+    PredictParams pp;
+    const uint32_t *pred_off;  // [512][4] packed neighbour offsets per node (build_pred_offsets)
+    unsigned long long *gram; // [3][28]   (MODE 0)
+    unsigned long long *wtw;  // [3][21]   (MODE 1)
+    double *wtr;              // [3][6]    (MODE 1)
+    unsigned long long *acc;  // plan scratch, all zero between launches: [kFitAccInt] integer sums, [18] f64 bit patterns, then the ticket
+};
+constexpr int kFitAccInt = 3 * 28, kFitAccDbl = kFitAccInt, kFitAccTicket = kFitAccInt + 18;
+static_assert(kFitAccTicket + 1 == (int)kFitAccWords, "fit accumulator layout");
+
+template <int MODE>
+__global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const FitArgs a) {
+    constexpr int NI = MODE == 0 ? 28 : 21;
+    __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
+    __shared__ int32_t s_slot_cell[kPredSlots];
+    __shared__ int32_t s_slot_interior[kPredSlots];
+    __shared__ uint32_t s_flag;
+    __shared__ unsigned long long s_int[3][28];
+    __shared__ double s_dbl[3][6];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 3 * 28) (&s_int[0][0])[tid] = 0;
+    if (tid < 18) (&s_dbl[0][0])[tid] = 0.0;
+
+    const int g = lane < 32 ? 0 : lane < 48 ? 1 : 2;
+    const int p0 = lane < 32 ? 256 + lane : lane < 48 ? 128 + (lane - 32) : lane - 48;
+    const int pstep = lane < 32 ? 32 : 16;
+    // The neighbour offsets of a lane's 8 nodes live in LDS here (not in registers as in K2): together with 21-28 accumulators
+    // they would not fit 128 VGPRs, and this kernel is not on the critical path. The map is per lane, identical in all waves.
+    __shared__ uint32_t s_off[8][64][3];
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const u32x4 o = reinterpret_cast<const u32x4 *>(a.pred_off)[p0 + pstep * i];
+            s_off[i][lane][0] = o.x;
+            s_off[i][lane][1] = o.y;
+            s_off[i][lane][2] = o.z;
+        }
+    }
+    float vp[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) vp[k] = a.pp.value[g][k];
+
+    int acc[NI];
+    double dacc[6];
+#pragma unroll
+    for (int k = 0; k < NI; k++) acc[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) dacc[k] = 0.0;
+    int cells_since_flush = 0;
+    auto flush = [&]() { // per-lane int32 sums -> workgroup int64 sums (sign-extended two's complement adds)
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            atomicAdd(&s_int[g][k], (unsigned long long)(long long)acc[k]);
+            acc[k] = 0;
+        }
+        cells_since_flush = 0;
+    };
+
+    const PredTileWalk walk(a.n_tiles);
+    for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step) {
+        __syncthreads();
+        if (tid < kPredSlots) {
+            const int raw = a.pred_slots[(size_t)tile * kPredSlots + tid];
+            s_slot_cell[tid] = pred_slot_cell(raw);
+            s_slot_interior[tid] = pred_slot_interior(raw) ? 1 : 0;
+        }
+        __syncthreads();
+        pred_stage_tile(a.coefs, s_slot_cell, s_cells, lane, wave);
+        __syncthreads();
+        for (int r = wave; r < kPredBlock * kPredBlock; r += kPredWaves) {
+            const int slot = (1 + r / kPredBlock) * kPredSide + 1 + (r % kPredBlock);
+            const int cell = s_slot_cell[slot];
+            if (cell < 0) continue;
+            const uint8_t *own = s_cells + slot * kSlotStride;
+            const bool boundary = __builtin_amdgcn_readfirstlane(s_slot_interior[slot]) == 0;
+#pragma unroll 1
+            for (int i = 0; i < 8; i++) {
+                const int p = p0 + pstep * i;
+                bool use = p >= 2; // heap index 0 and 1 are coded by the LF predictor and are not rows of the fit
+                if (boundary) use = use && ((a.valid_mask[(size_t)cell * 16 + (p >> 5)] >> (p & 31)) & 1u);
+                int u[7];
+                int v[6];
+                const uint32_t off_i[3] = {s_off[i][lane][0], s_off[i][lane][1], s_off[i][lane][2]};
+                pred_gather(own, off_i, v);
+                const int value = *reinterpret_cast<const short *>(own + 2 * p);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) u[k] = use ? v[k] : 0; // a None row is all zeros in the reference (:109-134)
+                    u[6] = use ? value : 0;
+                    int n = 0;
+#pragma unroll
+                    for (int r0 = 0; r0 < 7; r0++)
+#pragma unroll
+                        for (int c0 = r0; c0 < 7; c0++) acc[n++] += __mul24(u[r0], u[c0]);
+                } else {
+                    float pf = __fmul_rn((float)v[0], vp[0]);
+#pragma unroll
+                    for (int k = 1; k < 6; k++) pf = __fadd_rn(pf, __fmul_rn((float)v[k], vp[k]));
+                    const float res = fabsf(__fsub_rn((float)value, pf));
+                    int w[6] = {1, iabs_w(v[0] - v[3]), iabs_w(v[1] - v[2]), iabs_w(v[4] - v[5]), iabs_w(v[1] - v[5]), iabs_w(v[2] - v[4])};
+#pragma unroll
+                    for (int k = 0; k < 6; k++) w[k] = use ? w[k] : 0;
+                    int n = 0;
+#pragma unroll
+                    for (int r0 = 0; r0 < 6; r0++)
+#pragma unroll
+                        for (int c0 = r0; c0 < 6; c0++) acc[n++] += __mul24(w[r0], w[c0]);
+                    const double rd = (double)res;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) dacc[k] += (double)w[k] * rd;
+                }
+            }
+            if (++cells_since_flush >= 1024) flush(); // 8 nodes x 255^2 x 1024 cells < 2^31
+        }
+    }
+    // Final reduction through LDS scratch instead of atomics: all 32 (16) lanes of a layer group would add to ONE LDS address,
+    // which costs ~0.7 us per instruction (see K2), 28 + 6 times per wave. The cell image is free now: every lane parks its sums
+    // at its own address, then one thread per (wave, sum, group) adds a group's lanes up - in a fixed order, so the f64 sums of
+    // MODE 1 no longer depend on the arrival order of atomics.
+    __syncthreads();
+    {
+        constexpr int NS = NI + (MODE == 1 ? 12 : 0); // int sums + 6 doubles as 12 words
+        int32_t *scr = reinterpret_cast<int32_t *>(s_cells); // [4 waves][NS][64] words at a time: the 36-slot image holds 37 440 B
+        static_assert(4 * NS * 64 * 4 <= kPredSlots * kSlotStride, "scratch fits the cell image");
+        for (int half = 0; half < 2; half++) {
+            const bool mine = (wave >> 2) == half;
+            const int w4 = wave & 3;
+            if (mine) {
+#pragma unroll
+                for (int k = 0; k < NI; k++) scr[(w4 * NS + k) * 64 + lane] = acc[k];
+                if (MODE == 1) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const unsigned long long u = __builtin_bit_cast(unsigned long long, dacc[k]);
+                        scr[(w4 * NS + NI + 2 * k) * 64 + lane] = (int32_t)(uint32_t)u;
+                        scr[(w4 * NS + NI + 2 * k + 1) * 64 + lane] = (int32_t)(uint32_t)(u >> 32);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int t = tid; t < 4 * NI * 3; t += kPredThreads) { // integer sums: (wave of this half, k, group)
+                const int ww = t / (NI * 3), k = (t / 3) % NI, gg = t % 3;
+                const int l0 = gg == 0 ? 0 : gg == 1 ? 32 : 48, l1 = gg == 0 ? 32 : gg == 1 ? 48 : 64;
+                long long sum = 0;
+                for (int l = l0; l < l1; l++) sum += scr[(ww * NS + k) * 64 + l];
+                atomicAdd(&s_int[gg][k], (unsigned long long)sum); // <= 8 adds per address in the whole kernel
+            }
+            if (MODE == 1) {
+                for (int t = tid; t < 4 * 6 * 3; t += kPredThreads) {
+                    const int ww = t / 18, k = (t / 3) % 6, gg = t % 3;
+                    const int l0 = gg == 0 ? 0 : gg == 1 ? 32 : 48, l1 = gg == 0 ? 32 : gg == 1 ? 48 : 64;
+                    double sum = 0.0;
+                    for (int l = l0; l < l1; l++) {
+                        const unsigned long long u = (unsigned long long)(uint32_t)scr[(ww * NS + NI + 2 * k) * 64 + l] |
+                                                     (unsigned long long)(uint32_t)scr[(ww * NS + NI + 2 * k + 1) * 64 + l] << 32;
+                        sum += __builtin_bit_cast(double, u);
+                    }
+                    atomicAdd(&s_dbl[gg][k], sum);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // Hand-over like K2's: add into the plan accumulator, draw a ticket, the last workgroup moves the totals out and re-zeroes.
+    if (tid < 3 * NI) {
+        const int gg = tid / NI, k = tid % NI;
+        __hip_atomic_fetch_add(a.acc + tid, s_int[gg][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (MODE == 1 && tid < 18) __hip_atomic_fetch_add(reinterpret_cast<double *>(a.acc + kFitAccDbl) + tid, (&s_dbl[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads(); // vmcnt(0) in every wave: the adds are performed
+    if (tid == 0) s_flag = __hip_atomic_fetch_add(a.acc + kFitAccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_flag == 0) return;
+    if (tid < 3 * NI) {
+        (MODE == 0 ? a.gram : a.wtw)[tid] = __hip_atomic_load(a.acc + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.acc + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (MODE == 1 && tid < 18) {
+        const unsigned long long u = __hip_atomic_load(a.acc + kFitAccDbl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.wtr[tid] = __builtin_bit_cast(double, u);
+        __hip_atomic_store(a.acc + kFitAccDbl + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) __hip_atomic_store(a.acc + kFitAccTicket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
+} // namespace
+
+hipError_t launch_fit_accumulate(const DevicePlan &p, int mode, const int32_t *coefs_channel, const PredictParams &pp, unsigned long long *sums_int,
+                                 double *sums_dbl, hipStream_t stream) {
+    if (!p.fit_acc) return hipErrorInvalidValue;
+    FitArgs a{};
+    a.coefs = coefs_channel;
+    a.pred_slots = p.pred_slots;
+    a.nbr_table = p.nbr_table;
+    a.pred_off = p.pred_off;
+    a.interior = p.interior;
+    a.valid_mask = p.valid_mask;
+    a.n_tiles = p.n_pred_tiles;
+    a.pp = pp;
+    a.acc = p.fit_acc + (size_t)(p.fit_seq++ % kPredAccRing) * kFitAccWords;
+    a.gram = sums_int;
+    a.wtw = sums_int;
+    a.wtr = sums_dbl;
+    uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
+    if (!blocks) blocks = 1;
+    if (mode == 0)
+        hipLaunchKernelGGL(fit_accumulate_kernel<0>, dim3(blocks), dim3(kPredThreads), 0, stream, a);
+    else
+        hipLaunchKernelGGL(fit_accumulate_kernel<1>, dim3(blocks), dim3(kPredThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace fri

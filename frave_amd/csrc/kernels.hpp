@@ -1,4 +1,4 @@
-// kernels.hpp -- launch interface between the C ABI (fri_hip.cpp) and the gfx950 kernels (kernels.hip).
+// kernels.hpp -- launch interface between the C ABI (fri_hip.cpp) and the gfx950 kernels (k1_forward.hip, k2_predict.hip, k3_inverse.hip, k4_fit.hip).
 #pragma once
 #include <hip/hip_runtime_api.h>
 
