@@ -3,6 +3,8 @@
 //   fri_driver roundtrip <width> <height> <channels>         encode -> predict -> decode, checks the lossless identity
 //   fri_driver encode <width> <height> <channels> <out.frv>  the whole encode pipeline on a synthetic image: device stages, then
 //                                                            symbol order / ANS models / rANS / frif container on the host; self-checks the stream
+//   fri_driver encode-file <in.pgm|in.ppm> <out.frv>         the same pipeline on a binary PGM (P5, one plane) or PPM (P6, RGB) file,
+//                                                            8 bits per sample (fri-cli encode, crates/fri-cli/src/commands/encode.rs:8-54)
 //   fri_driver batch <width> <height> <channels> <n_images>  BASELINE config 3: host batch with H2D / kernel / D2H overlap
 #include <chrono>
 #include <cstdio>
@@ -27,9 +29,108 @@ static std::vector<uint8_t> noise_image(uint32_t w, uint32_t h, uint32_t c, uint
     return v;
 }
 
+// Binary PGM (P5) / PPM (P6) with maxval 255: the image I/O of fri-cli reduced to the two formats that need no library.
+static bool read_pnm(const char *path, std::vector<uint8_t> &data, uint32_t &w, uint32_t &h, uint32_t &c, std::string &err) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) {
+        err = std::string("cannot open ") + path;
+        return false;
+    }
+    auto token = [&](std::string &t) {
+        t.clear();
+        int ch = std::fgetc(f);
+        while (ch != EOF) {
+            if (ch == '#') {
+                while (ch != EOF && ch != '\n') ch = std::fgetc(f);
+            } else if (ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r') {
+                ch = std::fgetc(f);
+            } else {
+                break;
+            }
+        }
+        while (ch != EOF && ch != ' ' && ch != '\t' && ch != '\n' && ch != '\r') {
+            t.push_back((char)ch);
+            ch = std::fgetc(f);
+        }
+        return !t.empty();
+    };
+    std::string magic, sw, sh, smax;
+    bool ok = token(magic) && token(sw) && token(sh) && token(smax);
+    if (ok) ok = (magic == "P5" || magic == "P6") && std::atoi(smax.c_str()) == 255 && std::atoi(sw.c_str()) > 0 && std::atoi(sh.c_str()) > 0;
+    if (!ok) {
+        err = "not a binary PGM/PPM with maxval 255";
+        std::fclose(f);
+        return false;
+    }
+    w = (uint32_t)std::atoi(sw.c_str()), h = (uint32_t)std::atoi(sh.c_str()), c = magic == "P5" ? 1u : 3u;
+    data.resize((size_t)w * h * c);
+    ok = std::fread(data.data(), 1, data.size(), f) == data.size();
+    std::fclose(f);
+    if (!ok) err = "file shorter than its header says";
+    return ok;
+}
+
+static int encode_image_to_file(std::vector<uint8_t> img, uint32_t w, uint32_t h, uint32_t c, const libfri::EncoderOpts &opts, const char *out_path) {
+    const libfri::ColorSpace cs = c == 1 ? libfri::ColorSpace::Luma : libfri::ColorSpace::RGB;
+    libfri::FRIEncoder encoder(opts);
+    auto t0 = std::chrono::steady_clock::now();
+    auto st = encoder.encode(img, h, w, cs);
+    if (!st.ok) {
+        std::fprintf(stderr, "%s\n", st.error.c_str());
+        return 1;
+    }
+    const double t_dev = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    t0 = std::chrono::steady_clock::now();
+    auto comp = libfri::stages::entropy_coding::encode(st.value.image, st.value.contexts, encoder.opts());
+    if (!comp.ok) {
+        std::fprintf(stderr, "%s\n", comp.error.c_str());
+        return 1;
+    }
+    const std::vector<uint8_t> bytes = libfri::stages::serialize::encode(comp.value);
+    const double t_host = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // self-check: parse the container, rebuild the models from it, decode every symbol
+    libfri::emit::ParsedImage parsed;
+    std::string err = libfri::emit::deserialize(bytes, parsed);
+    const size_t plane = (size_t)st.value.image.num_cells * 512;
+    const libfri::emit::SymbolOrder order(st.value.image.centers.data(), st.value.image.num_cells);
+    for (uint32_t ch = 0; err.empty() && ch < c; ch++) {
+        std::vector<uint16_t> want, got;
+        std::vector<uint8_t> buckets;
+        libfri::emit::channel_symbols(order, st.value.image.coefficients.data() + ch * plane,
+                                      st.value.image.bucket[ch].data(), st.value.image.prediction[ch].data(), want, buckets);
+        err = libfri::emit::decode_symbols(parsed.channels[ch], buckets, got);
+        if (err.empty() && got != want) err = "decoded symbols differ";
+    }
+    if (!err.empty()) {
+        std::fprintf(stderr, "self-check failed: %s\n", err.c_str());
+        return 1;
+    }
+    if (FILE *f = std::fopen(out_path, "wb")) {
+        std::fwrite(bytes.data(), 1, bytes.size(), f);
+        std::fclose(f);
+    } else {
+        std::fprintf(stderr, "cannot write %s\n", out_path);
+        return 1;
+    }
+    std::printf("%ux%ux%u: %zu bytes, %.3f bits per pixel; device stages (incl. plan + PCIe) %.3f s, host emit %.3f s; stream self-check ok\n", w, h, c,
+                bytes.size(), 8.0 * bytes.size() / ((double)w * h), t_dev, t_host);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 4 && std::string(argv[1]) == "encode-file") {
+        std::vector<uint8_t> img;
+        uint32_t fw = 0, fh = 0, fc = 0;
+        std::string err;
+        if (!read_pnm(argv[2], img, fw, fh, fc, err)) {
+            std::fprintf(stderr, "%s\n", err.c_str());
+            return 1;
+        }
+        libfri::EncoderOpts file_opts; // parameters are fitted on the device sums (fit_parameters defaults to true)
+        return encode_image_to_file(std::move(img), fw, fh, fc, file_opts, argv[3]);
+    }
     if (argc < 5) {
-        std::fprintf(stderr, "usage: %s roundtrip|batch <width> <height> <channels> [n_images]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s roundtrip|encode|batch <width> <height> <channels> [n_images | out.frv]\n       %s encode-file <in.pgm|in.ppm> <out.frv>\n", argv[0], argv[0]);
         return 2;
     }
     const std::string cmd = argv[1];
@@ -72,49 +173,7 @@ int main(int argc, char **argv) {
         for (uint32_t y = 0; y < h; y++)
             for (uint32_t x = 0; x < w / 2; x++)
                 for (uint32_t k = 0; k < c; k++) img[((size_t)y * w + x) * c + k] = (uint8_t)((((x + 2 * y) >> 3) + (img[((size_t)y * w + x) * c + k] & 7)) & 0xFF);
-        libfri::FRIEncoder encoder(opts);
-        auto t0 = std::chrono::steady_clock::now();
-        auto st = encoder.encode(img, h, w, cs);
-        if (!st.ok) {
-            std::fprintf(stderr, "%s\n", st.error.c_str());
-            return 1;
-        }
-        const double t_dev = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        t0 = std::chrono::steady_clock::now();
-        auto comp = libfri::stages::entropy_coding::encode(st.value.image, st.value.contexts, encoder.opts());
-        if (!comp.ok) {
-            std::fprintf(stderr, "%s\n", comp.error.c_str());
-            return 1;
-        }
-        const std::vector<uint8_t> bytes = libfri::stages::serialize::encode(comp.value);
-        const double t_host = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        // self-check: parse the container, rebuild the models from it, decode every symbol
-        libfri::emit::ParsedImage parsed;
-        std::string err = libfri::emit::deserialize(bytes, parsed);
-        const size_t plane = (size_t)st.value.image.num_cells * 512;
-        const libfri::emit::SymbolOrder order(st.value.image.centers.data(), st.value.image.num_cells);
-        for (uint32_t ch = 0; err.empty() && ch < c; ch++) {
-            std::vector<uint16_t> want, got;
-            std::vector<uint8_t> buckets;
-            libfri::emit::channel_symbols(order, st.value.image.coefficients.data() + ch * plane,
-                                          st.value.image.bucket[ch].data(), st.value.image.prediction[ch].data(), want, buckets);
-            err = libfri::emit::decode_symbols(parsed.channels[ch], buckets, got);
-            if (err.empty() && got != want) err = "decoded symbols differ";
-        }
-        if (!err.empty()) {
-            std::fprintf(stderr, "self-check failed: %s\n", err.c_str());
-            return 1;
-        }
-        if (FILE *f = std::fopen(argv[5], "wb")) {
-            std::fwrite(bytes.data(), 1, bytes.size(), f);
-            std::fclose(f);
-        } else {
-            std::fprintf(stderr, "cannot write %s\n", argv[5]);
-            return 1;
-        }
-        std::printf("%ux%ux%u: %zu bytes, %.3f bits per pixel; device stages (incl. plan + PCIe) %.3f s, host emit %.3f s; stream self-check ok\n", w, h, c,
-                    bytes.size(), 8.0 * bytes.size() / ((double)w * h), t_dev, t_host);
-        return 0;
+        return encode_image_to_file(std::move(img), w, h, c, opts, argv[5]);
     }
     if (cmd == "batch") {
         const uint32_t n = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 16;

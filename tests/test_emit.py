@@ -162,3 +162,24 @@ def test_emit_from_device_arrays():
     frv = emit.encode_image(w, h, P.centers(), co, np.stack(bs), np.stack(ps), np.stack(hs), np.stack(vps), np.stack(wps))
     emit.check_image(frv, P.centers(), co, np.stack(bs), np.stack(ps))
     assert 0 < len(frv) < w * h * c * 2
+
+
+@pytest.mark.gpu
+def test_driver_encodes_pnm_files(tmp_path):
+    """fri_driver encode-file: PGM / PPM in, .frv out (device stages + host emit + stream self-check in one process)"""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    driver = os.path.join(root, "frave_amd", "host", "fri_driver")
+    if not os.path.exists(driver):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "frave_amd", "host")])
+    for c, magic in ((1, b"P5"), (3, b"P6")):
+        w, h = 320, 200
+        img = _mixed_image(w, h, c, 11)
+        src, dst = tmp_path / f"in{c}.pnm", tmp_path / f"out{c}.frv"
+        src.write_bytes(magic + b"\n# a comment\n%d %d\n255\n" % (w, h) + img.tobytes())
+        out = subprocess.run([driver, "encode-file", str(src), str(dst)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert "stream self-check ok" in out.stdout
+        frv = dst.read_bytes()
+        assert frv[:4] == b"frif" and struct.unpack("<II", frv[4:12]) == (h, w) and frv[-2:] == b"\xff\xdf"

@@ -170,6 +170,15 @@ def test_inverse_roundtrip_and_oracle(ctx, oracle, shape):
     assert np.array_equal(P.inverse_transform(rnd), W.to_raster())
 
 
+def test_trace_is_off_in_the_product_build(ctx):
+    """the diagnostic timeline needs FRI_HIP_TRACE=1 at plan creation (and the instrumented build to hold anything)"""
+    import frave_amd
+
+    P = _plan(ctx, 64, 64, 1)
+    with pytest.raises(frave_amd.api.FriHipError):
+        P.read_trace()
+
+
 def test_batch_entry_points(ctx, oracle):
     w, h, c = 320, 200, 3
     imgs = [gen_image("noise", w, h, c, i) for i in range(7)]
