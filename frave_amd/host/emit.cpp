@@ -262,6 +262,21 @@ std::string encode_channel(const SymbolOrder &order, const int32_t *coefs, const
     return "";
 }
 
+std::string encode_channels(const SymbolOrder &order, uint32_t channels, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction,
+                            const uint32_t *hist, std::vector<ChannelStream> &out) {
+    out.assign(channels, ChannelStream{});
+    const size_t plane = order.level[0].size() * kNodes;
+    std::vector<std::string> errs(channels);
+    std::vector<std::thread> workers;
+    for (uint32_t ch = 1; ch < channels; ch++)
+        workers.emplace_back([&, ch] { errs[ch] = encode_channel(order, coefs + ch * plane, bucket + ch * plane, prediction + ch * plane, hist + (size_t)ch * kContexts * kAlphabet, out[ch]); });
+    if (channels) errs[0] = encode_channel(order, coefs, bucket, prediction, hist, out[0]);
+    for (std::thread &t : workers) t.join();
+    for (uint32_t ch = 0; ch < channels; ch++)
+        if (!errs[ch].empty()) return "channel " + std::to_string(ch) + ": " + errs[ch];
+    return "";
+}
+
 std::string decode_symbols(const ChannelStream &s, const std::vector<uint8_t> &buckets, std::vector<uint16_t> &symbols) {
     RansDecoderMulti dec(s.data);
     symbols.resize(buckets.size());

@@ -86,6 +86,10 @@ struct ChannelStream {
 // Returns "" or an error (conditions under which the reference panics).
 std::string encode_channel(const SymbolOrder &order, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction, const uint32_t *hist,
                            ChannelStream &out);
+// All channels of an image, one thread per channel (they only share the read-only order). planes: [channels][n_cells][512],
+// hist: [channels][10][1024]. Returns "" or "channel c: reason".
+std::string encode_channels(const SymbolOrder &order, uint32_t channels, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction,
+                            const uint32_t *hist, std::vector<ChannelStream> &out);
 // The (symbol, bucket) sequence in stream order (what encode_channel feeds to the coder); for self-checks.
 void channel_symbols(const SymbolOrder &order, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction, std::vector<uint16_t> &symbols,
                      std::vector<uint8_t> &buckets);

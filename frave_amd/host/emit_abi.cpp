@@ -68,14 +68,12 @@ int fri_emit_encode_image(uint32_t width, uint32_t height, uint32_t channels, co
                           size_t cap, size_t *len, char *err, size_t err_cap) {
     if (!centers_re_im || !coefs || !bucket || !prediction || !hist || !value_params || !width_params || !len || (channels != 1 && channels != 3))
         return fail(err, err_cap, "invalid argument");
-    std::vector<ChannelStream> streams(channels);
+    std::vector<ChannelStream> streams;
     std::vector<ChannelParams> params(channels);
-    const size_t plane = (size_t)n_cells * kNodes;
     const SymbolOrder order(centers_re_im, n_cells); // geometry only: once for all channels
+    const std::string e = encode_channels(order, channels, coefs, bucket, prediction, hist, streams);
+    if (!e.empty()) return fail(err, err_cap, e, -2);
     for (uint32_t ch = 0; ch < channels; ch++) {
-        const std::string e = encode_channel(order, coefs + ch * plane, bucket + ch * plane, prediction + ch * plane,
-                                             hist + (size_t)ch * kContexts * kAlphabet, streams[ch]);
-        if (!e.empty()) return fail(err, err_cap, "channel " + std::to_string(ch) + ": " + e, -2);
         std::memcpy(params[ch].value, value_params + (size_t)ch * 18, sizeof(params[ch].value));
         std::memcpy(params[ch].width, width_params + (size_t)ch * 18, sizeof(params[ch].width));
     }

@@ -269,27 +269,30 @@ Result<CompressedImage> stages::entropy_coding::encode(const WaveletImage &image
     const uint32_t channels = num_channels(image.metadata.colorspace);
     const size_t plane = (size_t)image.num_cells * 512;
     r.value.metadata = image.metadata;
-    r.value.channel_data.resize(channels);
     r.value.params.resize(channels);
-    const emit::SymbolOrder order(image.centers.data(), image.num_cells);
+    std::vector<uint32_t> hist((size_t)channels * CONTEXT_AMOUNT * ALPHABET_SIZE);
+    std::vector<uint8_t> bucket(channels * plane);
+    std::vector<int32_t> prediction(channels * plane);
     for (uint32_t ch = 0; ch < channels; ch++) {
         if (contexts[ch].size() != (size_t)CONTEXT_AMOUNT) {
             r.error = "missing contexts";
             return r;
         }
-        std::vector<uint32_t> hist((size_t)CONTEXT_AMOUNT * ALPHABET_SIZE);
-        for (int b = 0; b < CONTEXT_AMOUNT; b++) std::copy(contexts[ch][b].freqs.begin(), contexts[ch][b].freqs.end(), hist.begin() + (size_t)b * ALPHABET_SIZE);
-        const std::string err = emit::encode_channel(order, image.coefficients.data() + ch * plane, image.bucket[ch].data(),
-                                                     image.prediction[ch].data(), hist.data(), r.value.channel_data[ch]);
-        if (!err.empty()) {
-            r.error = "channel " + std::to_string(ch) + ": " + err;
-            return r;
-        }
+        for (int b = 0; b < CONTEXT_AMOUNT; b++)
+            std::copy(contexts[ch][b].freqs.begin(), contexts[ch][b].freqs.end(), hist.begin() + ((size_t)ch * CONTEXT_AMOUNT + b) * ALPHABET_SIZE);
+        std::copy(image.bucket[ch].begin(), image.bucket[ch].end(), bucket.begin() + ch * plane);
+        std::copy(image.prediction[ch].begin(), image.prediction[ch].end(), prediction.begin() + ch * plane);
         for (int g = 0; g < 3; g++)
             for (int k = 0; k < 6; k++) {
                 r.value.params[ch].value[g][k] = opts.value_prediction_params[ch][g][k];
                 r.value.params[ch].width[g][k] = opts.width_prediction_params[ch][g][k];
             }
+    }
+    const emit::SymbolOrder order(image.centers.data(), image.num_cells);
+    const std::string err = emit::encode_channels(order, channels, image.coefficients.data(), bucket.data(), prediction.data(), hist.data(), r.value.channel_data);
+    if (!err.empty()) {
+        r.error = err;
+        return r;
     }
     r.ok = true;
     return r;
