@@ -108,24 +108,17 @@ def main():
         k = i % args.slots
         plan.transform_quant_dev(px0 + k * pstride, co0 + k * cstride * 4, stream=stream)
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    from frave_amd.dist import timed_region
 
     for i in range(args.warmup):
         step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def timed_steps():
+        for i in range(args.steps):
+            step(i)
+
+    # barrier + device synchronisation on both sides, MAX over ranks (the protocol tests/test_multi_gloo.py exercises on gloo)
+    elapsed = timed_region(timed_steps, dist=dist, device_sync=torch.cuda.synchronize, device="cuda")
 
     # dominant kernel, timed with HIP events on the launch stream (same stream as above)
     kernel_us = plan.time_transform_quant_dev(args.slots, px0, pstride, co0, cstride, max(args.steps, 50), stream=stream)
