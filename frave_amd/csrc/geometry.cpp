@@ -270,6 +270,8 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
     if (kept.empty()) return "empty lattice";
     std::sort(kept.begin(), kept.end(), [](const Cand &l, const Cand &r) { return l.c.y != r.c.y ? l.c.y < r.c.y : l.c.x < r.c.x; }); // utils.rs:17-32
     const size_t F = kept.size();
+    // the kernels index coefficients with 32-bit element offsets ((channel * F + cell) * 512)
+    if ((uint64_t)F * kCell * channels >= (1ull << 32)) return "image too large: more than 2^32 coefficient slots";
     g.centers.resize(F);
     g.interior.assign(F, 0);
     g.valid_mask.assign(F * 16, 0);
