@@ -20,7 +20,7 @@ SYMBOLS = [
     "fri_hip_transform_quant_batch_dev", "fri_hip_transform_quant_batch", "fri_hip_predict_histogram",
     "fri_hip_predict_histogram_dev", "fri_hip_fit_value_sums", "fri_hip_fit_value_sums_dev", "fri_hip_fit_width_sums",
     "fri_hip_fit_width_sums_dev", "fri_hip_inverse_transform", "fri_hip_inverse_transform_dev",
-    "fri_hip_time_transform_quant_dev", "fri_hip_plan_read_trace",
+    "fri_hip_time_transform_quant_dev", "fri_hip_plan_read_trace", "fri_hip_plan_inverse_lists",
 ]
 
 
@@ -100,6 +100,7 @@ def load_library():
     L.fri_hip_inverse_transform.argtypes = [vp, vp, vp, vp]
     L.fri_hip_inverse_transform_dev.argtypes = [vp, vp, vp, vp, vp]
     L.fri_hip_plan_read_trace.argtypes = [vp, vp]
+    L.fri_hip_plan_inverse_lists.argtypes = [vp, vp]
     L.fri_hip_time_transform_quant_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, u32, vp, C.POINTER(C.c_double)]
     _lib = L
     return L
@@ -224,6 +225,11 @@ class Plan:
         out = np.empty(8, np.int32)
         _check(load_library().fri_hip_plan_tiling(self._h, _p(out)), "fri_hip_plan_tiling")
         return dict(zip(("n_wg", "n_tiles", "lds_pitch", "lds_rows", "max_tile_cells", "band_rows", "cells_per_tile", "cells_per_wg"), (int(v) for v in out)))
+
+    def inverse_lists(self):
+        out = np.zeros(5, np.uint64)
+        _check(load_library().fri_hip_plan_inverse_lists(self._h, _p(out)), "fri_hip_plan_inverse_lists")
+        return dict(zip(("built", "quads", "dwords", "part_bytes", "rect_bytes"), (int(v) for v in out)))
 
     def read_trace(self):
         """[n_wg, 16] uint64 time stamps (100 MHz ticks) of the last forward/inverse launch; needs FRI_HIP_TRACE=1 at plan creation."""

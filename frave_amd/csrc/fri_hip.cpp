@@ -231,6 +231,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             }
         }
     }
+    build_inverse_lists(p->geo, (size_t)256 << 20); // 6 MB at 4096^2; beyond 256 MB the inverse kernel scans the rectangle instead
     if (ctx) {
         if (hipSetDevice(ctx->device) != hipSuccess) {
             delete p;
@@ -299,6 +300,15 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
         if (const char *e = std::getenv("FRI_HIP_K1_BATCH_SHARES")) d.k1_batch_shares = std::atoi(e) != 0;
         d.k3_ablate = env_int("FRI_HIP_K3_ABLATE");
+        d.k3_scan = env_int("FRI_HIP_K3_SCAN") > 0;
+        if (!g.inv_lists.empty()) {
+            if ((rc = upload(p, g.inv_lists, d.inv_lists)) || (rc = upload(p, g.inv_quads, d.inv_quads)) || (rc = upload(p, g.inv_dwords, d.inv_dwords)) ||
+                (rc = upload(p, g.inv_parts, d.inv_parts))) {
+                fri_hip_plan_destroy(p);
+                return rc;
+            }
+            d.inv_rect_bytes = g.inv_rect_bytes;
+        }
         if (env_int("FRI_HIP_TRACE") > 0) {
             const size_t bytes = (size_t)d.n_wg * 16 * sizeof(unsigned long long);
             void *t = nullptr;
@@ -362,6 +372,18 @@ int fri_hip_plan_tiling(const fri_hip_plan *p, int32_t out[8]) {
     const Geometry &g = p->geo;
     const int32_t v[8] = {(int32_t)g.wg_tiles.size() - 1, (int32_t)g.tiles.size(), g.lds_pitch, g.lds_rows, g.max_tile_cells, g.band_rows, g.cells_per_tile, g.cells_per_wg};
     std::memcpy(out, v, sizeof(v));
+    return FRI_HIP_OK;
+}
+int fri_hip_plan_inverse_lists(const fri_hip_plan *p, uint64_t out[5]) {
+    if (!p || !out) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    const Geometry &g = p->geo;
+    uint64_t bits = 0;
+    for (uint32_t e : g.inv_parts) bits += (uint64_t)__builtin_popcount(e & 15u);
+    out[0] = g.inv_lists.empty() ? 0 : 1;
+    out[1] = g.inv_quads.size();
+    out[2] = g.inv_dwords.size();
+    out[3] = bits;
+    out[4] = (uint64_t)g.inv_rect_bytes;
     return FRI_HIP_OK;
 }
 int fri_hip_plan_read_trace(fri_hip_plan *p, uint64_t *out) {

@@ -455,4 +455,63 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
     return "";
 }
 
+void build_inverse_lists(Geometry &g, size_t max_bytes) {
+    const StaticTables &st = static_tables();
+    const int W = (int)g.width, H = (int)g.height, C = (int)g.channels;
+    g.inv_lists.clear();
+    g.inv_quads.clear();
+    g.inv_dwords.clear();
+    g.inv_parts.clear();
+    g.inv_rect_bytes = 0;
+    auto give_up = [&]() {
+        g.inv_quads.clear();
+        g.inv_dwords.clear();
+        g.inv_parts.clear();
+    };
+    std::vector<InvTileLists> lists(g.tiles.size());
+    std::vector<uint16_t> bitmap;
+    for (size_t ti = 0; ti < g.tiles.size(); ti++) {
+        const Tile &t = g.tiles[ti];
+        const int a0 = (t.x_lo * C) & ~15;
+        const int rq = ((t.x_lo + t.width_px) * C - 1 - a0) / 16 + 1;
+        if (t.n_rows > 256 || rq > 64) return give_up(); // entries hold the row and the dword column in 8 bits each
+        g.inv_rect_bytes = std::max(g.inv_rect_bytes, t.n_rows * rq * 16);
+        bitmap.assign((size_t)t.n_rows * rq, 0);
+        for (int c = 0; c < t.cell_count; c++) {
+            const Int2 cen = g.centers[g.tile_cells[t.cell_begin + c]];
+            for (int s2 = 0; s2 < kCell; s2++) {
+                const int x = cen.x + st.leaf_off[s2].x, y = cen.y + st.leaf_off[s2].y;
+                if (x < 0 || y < 0 || x >= W || y >= H) continue; // set_pixel, images.rs:104
+                for (int ch = 0; ch < C; ch++) {
+                    const int col = x * C + ch - a0;
+                    bitmap[(size_t)(y - t.y_lo) * rq + (col >> 4)] |= (uint16_t)(1u << (col & 15));
+                }
+            }
+        }
+        lists[ti].quad_begin = (uint32_t)g.inv_quads.size();
+        lists[ti].dword_begin = (uint32_t)g.inv_dwords.size();
+        lists[ti].part_begin = (uint32_t)g.inv_parts.size();
+        for (int r = 0; r < t.n_rows; r++)
+            for (int k = 0; k < rq; k++) {
+                const uint16_t m = bitmap[(size_t)r * rq + k];
+                if (m == 0xFFFFu) {
+                    g.inv_quads.push_back((uint16_t)(r << 8 | k));
+                } else if (m) {
+                    for (int d = 0; d < 4; d++) {
+                        const uint32_t nib = (m >> (4 * d)) & 15u;
+                        if (nib == 15u)
+                            g.inv_dwords.push_back((uint16_t)(r << 8 | (4 * k + d)));
+                        else if (nib)
+                            g.inv_parts.push_back((uint32_t)(r << 8 | (4 * k + d)) << 4 | nib);
+                    }
+                }
+            }
+        lists[ti].quad_count = (uint32_t)g.inv_quads.size() - lists[ti].quad_begin;
+        lists[ti].dword_count = (uint32_t)g.inv_dwords.size() - lists[ti].dword_begin;
+        lists[ti].part_count = (uint32_t)g.inv_parts.size() - lists[ti].part_begin;
+        if ((g.inv_quads.size() + g.inv_dwords.size()) * 2 + g.inv_parts.size() * 4 > max_bytes) return give_up();
+    }
+    g.inv_lists.swap(lists);
+}
+
 } // namespace fri

@@ -42,6 +42,20 @@ struct Tile {
     int32_t cell_begin, cell_count; // range in tile_cells
 };
 
+// Write-out lists of the inverse kernel (geometry only). A tile's pixels are staged in LDS as rows of 16-byte quads; image row
+// y_lo + r occupies LDS row r, byte column c of the LDS row is image byte a0 + c of that row, a0 = (x_lo * C) rounded down to 16.
+// Which bytes the tile's own cells write is known at plan creation, so the kernel neither tracks ownership nor scans the
+// rectangle. Three lists per tile, each walked with densely packed lanes (a store instruction costs the same with 2 or 64
+// active lanes, so the shapes are kept apart instead of branching per lane):
+//   quads : 16-byte quads written whole                       entry r << 8 | quad
+//   dwords: whole dwords inside partly owned quads              entry r << 8 | dword   (dword = column / 4 < 256)
+//   parts : partly owned dwords with their 4-bit byte mask      entry (r << 8 | dword) << 4 | mask
+struct InvTileLists {
+    uint32_t quad_begin, quad_count;
+    uint32_t dword_begin, dword_count;
+    uint32_t part_begin, part_count;
+};
+
 // One cell of a tile as the forward/inverse kernels see it (16 bytes, staged into LDS per workgroup).
 struct TileCell {
     int32_t cx, cy, cell, interior;
@@ -70,6 +84,10 @@ struct Geometry {
     // per-workgroup start-up cost.
     std::vector<int32_t> wg_tiles_batch; // [n_wg_batch + 1]
     int32_t max_wg_tiles_batch = 0;
+    std::vector<InvTileLists> inv_lists; // [n_tiles]; empty if the lists were not built (budget)
+    std::vector<uint16_t> inv_quads, inv_dwords;
+    std::vector<uint32_t> inv_parts;
+    int32_t inv_rect_bytes = 0; // largest n_rows * quads-per-row * 16 over all tiles
     int32_t lds_pitch = 0;   // bytes per staged row (multiple of 16)
     int32_t lds_rows = 0;    // max rows per tile
     int32_t band_rows = 0, cells_per_tile = 0, cells_per_wg = 0;
@@ -103,5 +121,7 @@ struct TilingParams {
 
 // Returns "" on success, else an error string.
 std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, const TilingParams &tp, Geometry &out);
+// Fills g.inv_* (call after build_geometry); skipped (lists stay empty) if they would exceed max_bytes.
+void build_inverse_lists(Geometry &g, size_t max_bytes);
 
 } // namespace fri

@@ -34,6 +34,11 @@ struct InvArgs {
     int32_t q_identity;
     int32_t ablate; // timing experiments only (FRI_HIP_K3_ABLATE): 1 = no global stores, 2 = no LDS scatter
     unsigned long long *trace; // diagnostic timeline, null in production
+    // static write-out lists (geometry.hpp: InvTileLists), used by inverse_transform_lists_kernel
+    const InvTileLists *lists;
+    const uint16_t *quads, *dwords;
+    const uint32_t *parts;
+    int32_t rect_bytes; // LDS bytes of the largest tile rectangle (1 byte per byte)
     QMatrix q;
 };
 
@@ -269,6 +274,127 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
     trace_exit(a.trace, wg, tid);
 }
 
+// K3 with static write-out lists. Which bytes of a tile's rectangle its own cells write is geometry, so the plan holds, per
+// tile, the quads that are written whole, the whole dwords inside partly owned quads and the partly owned dwords with their byte
+// masks (build_inverse_lists, geometry.hpp). The kernel then only scatters plain bytes into LDS and walks the two lists: no ownership bits, no scan
+// of the (55 % empty) rectangle, no zeroing, no queue. Needs every image row to start 16-byte aligned (base pointer and
+// width * channels multiples of 16): the launcher falls back to inverse_transform_kernel otherwise.
+constexpr int kInvListPre = 3; // list entries a thread holds in flight per list and tile (more are loaded on demand)
+template <int NI>
+__global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(const InvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *img = lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Tile *lds_tiles = reinterpret_cast<Tile *>(lds + a.rect_bytes);
+    InvTileLists *lds_lists = reinterpret_cast<InvTileLists *>(lds_tiles + a.max_wg_tiles);
+    TileCell *lds_cells = reinterpret_cast<TileCell *>(lds_lists + a.max_wg_tiles);
+    const uint32_t wg = xcd_contiguous_share(blockIdx.x, a.n_wg);
+    const int tb = a.wg_tiles[wg], te = a.wg_tiles[wg + 1];
+    const int C = a.channels;
+    const size_t wc = (size_t)a.width * (size_t)C;
+    trace_stamp(a.trace, wg, 0, tid);
+    {
+        const Tile first = a.tiles[tb], last = a.tiles[te - 1];
+        const int n_cells = last.cell_begin + last.cell_count - first.cell_begin;
+        if (tid < te - tb) {
+            lds_tiles[tid] = a.tiles[tb + tid];
+            lds_lists[tid] = a.lists[tb + tid];
+        }
+        for (int i = tid; i < n_cells; i += kInvThreads) {
+            TileCell tc = a.tile_meta[first.cell_begin + i];
+            lds_cells[i] = tc;
+        }
+    }
+    __syncthreads();
+    const int cell0 = lds_tiles[0].cell_begin;
+    trace_stamp(a.trace, wg, 1, tid);
+
+    InvRegs pre[NI];
+    inv_prefetch<NI>(a, lds_tiles[0], lds_cells, wave, lane, pre);
+    for (int ti = tb; ti < te; ti++) {
+        const Tile t = lds_tiles[ti - tb];
+        const InvTileLists L = lds_lists[ti - tb];
+        InvRegs cur[NI];
+#pragma unroll
+        for (int s = 0; s < NI; s++) cur[s] = pre[s];
+        {
+            const Tile tn = lds_tiles[min(ti + 1, te - 1) - tb];
+            inv_prefetch<NI>(a, tn, lds_cells + (tn.cell_begin - cell0), wave, lane, pre);
+        }
+        // this thread's first entries of the three lists, in flight across the transform (indices clamped: the loads must be
+        // unconditional; a tile without entries of one kind re-reads entry 0 of the array, which always exists)
+        auto clamp_idx = [](uint32_t begin, uint32_t count, uint32_t i) { return count ? begin + min(i, count - 1u) : 0u; };
+        uint16_t qe[kInvListPre], de[kInvListPre];
+        uint32_t pe[kInvListPre];
+#pragma unroll
+        for (int m = 0; m < kInvListPre; m++) {
+            qe[m] = a.quads[clamp_idx(L.quad_begin, L.quad_count, (uint32_t)(tid + kInvThreads * m))];
+            de[m] = a.dwords[clamp_idx(L.dword_begin, L.dword_count, (uint32_t)(tid + kInvThreads * m))];
+            pe[m] = a.parts[clamp_idx(L.part_begin, L.part_count, (uint32_t)(tid + kInvThreads * m))];
+        }
+        const int n_items = t.cell_count * C;
+        const int a0 = (t.x_lo * C) & ~15;                         // first image byte column of the staged rows
+        const int pitch = (((t.x_lo + t.width_px) * C - 1 - a0) / 16 + 1) * 16; // LDS bytes per staged row
+        int leaf[NI][8];
+#pragma unroll
+        for (int s = 0; s < NI; s++) {
+            if (inv_has_none(cur[s])) inv_wave<false>(cur[s], lane, a, leaf[s]);
+            else inv_wave<true>(cur[s], lane, a, leaf[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < NI; s++) {
+            const int item = wave + kInvWaves * s;
+            if (item < n_items && !(a.ablate & 2)) {
+                const int cl = item / C, ch = item - cl * C;
+                const TileCell tc = lds_cells[t.cell_begin - cell0 + cl];
+                const int x0 = tc.cx + lane_dx(lane), y0 = tc.cy + lane_dy(lane);
+                const int at = (y0 - t.y_lo) * pitch + x0 * C + ch - a0;
+                if (__builtin_amdgcn_readfirstlane(tc.interior)) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) img[at + leaf_dy(j) * pitch + leaf_dx(j) * C] = (uint8_t)min(max(leaf[s][j], 0), 255);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int x = x0 + leaf_dx(j), y = y0 + leaf_dy(j);
+                        if (x >= 0 && y >= 0 && x < a.width && y < a.height) // set_pixel, images.rs:104
+                            img[at + leaf_dy(j) * pitch + leaf_dx(j) * C] = (uint8_t)min(max(leaf[s][j], 0), 255);
+                    }
+                }
+            }
+        }
+        lds_barrier(); // the rectangle holds every byte this tile owns
+        uint8_t *out0 = a.pixels + (size_t)t.y_lo * wc + (size_t)a0; // quad (r, k) -> out0 + r * wc + 16 k, 16-byte aligned
+        for (uint32_t e = tid, m = 0; e < L.quad_count; e += kInvThreads, m++) { // whole quads
+            const uint32_t rk = m < kInvListPre ? (m == 0 ? qe[0] : m == 1 ? qe[1] : qe[2]) : a.quads[L.quad_begin + e];
+            const uint32_t r = rk >> 8, k = rk & 255u;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(img + r * pitch + 16 * k);
+            if (!(a.ablate & 1)) *reinterpret_cast<u32x4 *>(out0 + (size_t)r * wc + 16 * k) = v;
+        }
+        for (uint32_t e = tid, m = 0; e < L.dword_count; e += kInvThreads, m++) { // whole dwords of partly owned quads
+            const uint32_t rd = m < kInvListPre ? (m == 0 ? de[0] : m == 1 ? de[1] : de[2]) : a.dwords[L.dword_begin + e];
+            const uint32_t r = rd >> 8, d = rd & 255u;
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(img + r * pitch + 4 * d);
+            if (!(a.ablate & 1)) *reinterpret_cast<uint32_t *>(out0 + (size_t)r * wc + 4 * d) = v;
+        }
+        for (uint32_t e = tid, m = 0; e < L.part_count; e += kInvThreads, m++) { // the fractal rim proper: byte stores
+            const uint32_t ent = m < kInvListPre ? (m == 0 ? pe[0] : m == 1 ? pe[1] : pe[2]) : a.parts[L.part_begin + e];
+            const uint32_t r = ent >> 12, d = (ent >> 4) & 255u, nib = ent & 15u;
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(img + r * pitch + 4 * d);
+            uint8_t *p = out0 + (size_t)r * wc + 4 * d;
+            if (!(a.ablate & 1)) {
+                if (nib & 1u) p[0] = (uint8_t)v;
+                if (nib & 2u) p[1] = (uint8_t)(v >> 8);
+                if (nib & 4u) p[2] = (uint8_t)(v >> 16);
+                if (nib & 8u) p[3] = (uint8_t)(v >> 24);
+            }
+        }
+        lds_barrier(); // everyone is done reading before the next tile scatters
+        trace_stamp(a.trace, wg, 2 + ti - tb, tid);
+    }
+    trace_exit(a.trace, wg, tid);
+}
+
 
 } // namespace
 
@@ -308,6 +434,23 @@ hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, c
     a.queue_bytes = (int32_t)inv_queue_bytes(p);
     const int items_per_wave = (p.max_tile_cells * p.channels + kInvWaves - 1) / kInvWaves;
     if (items_per_wave > kInvMaxItemsPerWave || p.max_wg_tiles > kInvThreads || p.lds_rows > 256 || p.lds_pitch / 16 > 256) return hipErrorInvalidConfiguration;
+    // static write-out lists when every image row starts 16-byte aligned
+    const bool lists = p.inv_lists && !p.k3_scan && (reinterpret_cast<uintptr_t>(pixels) & 15) == 0 && (((size_t)p.width * p.channels) & 15) == 0;
+    if (lists) {
+        a.lists = p.inv_lists;
+        a.quads = p.inv_quads;
+        a.dwords = p.inv_dwords;
+        a.parts = p.inv_parts;
+        a.rect_bytes = p.inv_rect_bytes;
+        const size_t lds2 = (size_t)p.inv_rect_bytes + (size_t)p.max_wg_tiles * (sizeof(Tile) + sizeof(InvTileLists)) + (size_t)p.max_wg_cells * sizeof(TileCell);
+        void (*k2)(const InvArgs) = items_per_wave <= 1 ? inverse_transform_lists_kernel<1> : items_per_wave == 2 ? inverse_transform_lists_kernel<2> : inverse_transform_lists_kernel<4>;
+        if (lds2 > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k2, dim3(p.n_wg), dim3(kInvThreads), lds2, stream, a);
+        return hipGetLastError();
+    }
     const size_t lds = inv_lds_bytes(p);
     void (*kern)(const InvArgs) = items_per_wave <= 1 ? inverse_transform_kernel<1> : items_per_wave == 2 ? inverse_transform_kernel<2> : inverse_transform_kernel<4>;
     if (lds > 48 * 1024) {

@@ -47,6 +47,12 @@ struct DevicePlan {
     bool k1_batch_shares = true; // FRI_HIP_K1_BATCH_SHARES=0 disables the merged shares (A/B)
     int32_t k1_ablate = 0; // timing-only ablation flags, see FwdArgs::ablate
     unsigned long long *trace = nullptr; // [n_wg][16] diagnostic timeline (FRI_HIP_TRACE=1), else null
+    // K3's static write-out lists (null = not built: the kernel scans the rectangle)
+    const InvTileLists *inv_lists = nullptr;
+    const uint16_t *inv_quads = nullptr, *inv_dwords = nullptr;
+    const uint32_t *inv_parts = nullptr;
+    int32_t inv_rect_bytes = 0;
+    bool k3_scan = false; // FRI_HIP_K3_SCAN=1: always use the scanning kernel (A/B)
     int32_t k3_ablate = 0; // same for the inverse kernel, see InvArgs::ablate
 };
 

@@ -15,6 +15,7 @@ int fail(char *err, size_t cap, const std::string &msg, int code = -1) {
 } // namespace
 
 extern "C" {
+#pragma GCC visibility push(default)
 
 // out[n_cells << level] = cell << 9 | heap index, in stream order (level 0: heap index 1)
 int fri_emit_symbol_order(const int32_t *centers_re_im, uint32_t n_cells, uint32_t level, uint32_t *out) {
@@ -106,4 +107,5 @@ int fri_emit_check_image(const uint8_t *frv, size_t len, uint32_t channels, cons
     return 0;
 }
 
+#pragma GCC visibility pop
 } // extern "C"

@@ -37,6 +37,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what this header declares is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define FRI_HIP_NONE INT32_MIN
 #define FRI_HIP_CELL_SIZE 512     /* 1 << BASE_FRAC_DEPTH, stages/wavelet_transform.rs:39 */
@@ -182,11 +186,19 @@ int fri_hip_time_transform_quant_dev(fri_hip_plan *plan, uint32_t n_images, cons
                                      const int32_t qmatrix[32], int32_t *d_coefs, size_t coef_stride, uint32_t iters, void *stream,
                                      double *mean_us);
 
+/* The inverse kernel's static write-out lists (diagnostics / tests): out[5] = {built (0/1), whole 16-byte quads, whole dwords inside
+ * partly owned quads, bytes owned inside partly owned dwords, LDS bytes of the largest tile rectangle}.
+ * 16 * out[1] + 4 * out[2] + out[3] equals the number of bytes of the image that belong to a retained cell. */
+int fri_hip_plan_inverse_lists(const fri_hip_plan *plan, uint64_t out[5]);
+
 /* Diagnostic timeline (plans created with FRI_HIP_TRACE=1 in the environment; INVALID_ARGUMENT otherwise): copies the
  * record of the most recent forward or inverse launch, out[n_wg][16] = {entry, prologue done, tile 0 done, ... (12 slots),
  * hardware id, exit}, time stamps in ticks of the GPU's constant 100 MHz clock. Synchronises the device. */
 int fri_hip_plan_read_trace(fri_hip_plan *plan, uint64_t *out);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif
