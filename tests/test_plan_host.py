@@ -106,3 +106,17 @@ def test_survey_size_table():
     assert (lambda p: (p.num_bfs_cells, p.num_cells, p.num_interior_cells))(plan(4096, 4096, 1)) == (33559, 33289, 32249)
     assert (lambda p: (p.num_bfs_cells, p.num_cells))(plan(1920, 1080, 3)) == (4317, 4221)
     assert (lambda p: (p.num_bfs_cells, p.num_cells))(plan(512, 512, 3)) == (617, 578)
+
+
+@pytest.mark.parametrize("shape", [(10, 10, 1), (64, 48, 3), (100, 37, 3), (512, 512, 1), (777, 333, 3), (1920, 1080, 1), (1, 300, 1), (300, 1, 3)])
+def test_inverse_write_out_lists_cover_every_owned_byte_once(shape):
+    """K3's static lists (whole quads, whole dwords, masked dwords) partition exactly the bytes that belong to retained cells:
+    all of the image when the lattice covers it, fewer for images thinner than a cell (the reference's BFS leaves holes there)"""
+    w, h, c = shape
+    L = plan(w, h, c).inverse_lists()
+    assert L["built"] == 1
+    owned = 16 * L["quads"] + 4 * L["dwords"] + L["part_bytes"]
+    if min(w, h) >= 46:
+        assert owned == w * h * c
+    else:
+        assert 0 < owned <= w * h * c and owned % c == 0
