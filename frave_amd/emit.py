@@ -28,6 +28,7 @@ def load_library():
         L.fri_emit_channel_symbols.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
         L.fri_emit_encode_image.argtypes = [u32, u32, u32, vp, u32, vp, vp, vp, vp, vp, vp, vp, sz, vp, C.c_char_p, sz]
         L.fri_emit_check_image.argtypes = [vp, sz, u32, vp, u32, vp, vp, vp, C.c_char_p, sz]
+        L.fri_emit_decode_image.argtypes = [vp, sz, vp, vp, sz, vp, C.c_char_p, sz]
         _lib = L
     return _lib
 
@@ -100,3 +101,22 @@ def check_image(frv, centers, coefs, bucket, prediction):
     rc = load_library().fri_emit_check_image(_p(data), data.size, channels, _p(c), len(c), _p(co), _p(b), _p(p), err, 256)
     if rc != 0:
         raise EmitError(err.value.decode() or f"fri_emit_check_image: {rc}")
+
+
+def decode_image(frv):
+    """A .frv back to coefficient planes (serialize::decode + entropy_coding::decode of the reference, host only).
+    Returns (width, height, channels, centers [F][2] int32, coefs [channels][F][512] int32 with None = INT32_MIN)."""
+    data = np.frombuffer(frv, np.uint8)
+    info = np.zeros(4, np.uint32)
+    err = C.create_string_buffer(256)
+    L = load_library()
+    rc = L.fri_emit_decode_image(_p(data), data.size, _p(info), None, 0, None, err, 256)
+    if rc != -3:
+        raise EmitError(err.value.decode() or f"fri_emit_decode_image: {rc}")
+    w, h, c, f = (int(x) for x in info)
+    coefs = np.empty((c, f, 512), np.int32)
+    centers = np.empty((f, 2), np.int32)
+    rc = L.fri_emit_decode_image(_p(data), data.size, _p(info), _p(coefs), coefs.size, _p(centers), err, 256)
+    if rc != 0:
+        raise EmitError(err.value.decode() or f"fri_emit_decode_image: {rc}")
+    return w, h, c, centers, coefs

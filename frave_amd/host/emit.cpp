@@ -296,6 +296,148 @@ std::string decode_symbols(const ChannelStream &s, const std::vector<uint8_t> &b
     return "";
 }
 
+// ---- decoder (entropy_coding::decode, :352-443) ------------------------------------------------------------------------------
+namespace {
+// Rust `f32 as i32`: truncating, saturating, NaN -> 0
+int32_t f32_as_i32(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v;
+}
+int bucket_of(uint32_t w) { // assign_bucket, prediction.rs:55-68
+    return w < 3 ? 0 : w < 5 ? 1 : w < 6 ? 2 : w < 8 ? 3 : w < 12 ? 4 : w < 16 ? 5 : w < 20 ? 6 : w < 25 ? 7 : w < 30 ? 8 : 9;
+}
+int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); } // release-build wrapping
+int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+int32_t wabs(int32_t a) { return a < 0 ? (int32_t)(0u - (uint32_t)a) : a; }
+} // namespace
+
+std::string decode_channel(const fri::Geometry &g, const SymbolOrder &order, const ChannelStream &s, const ChannelParams &prm, int32_t *coefs) {
+    const fri::StaticTables &st = fri::static_tables();
+    const size_t F = g.centers.size();
+    if (order.level[0].size() != F) return "symbol order does not match the geometry";
+    // WaveletImage::from_metadata (wavelet_transform.rs:392-404): the transform of an all-zero image, i.e. Some(0) wherever the
+    // geometry has a node and None elsewhere. Values not decoded yet are read as that 0 by the context of later symbols.
+    for (size_t c = 0; c < F; c++)
+        for (int p = 0; p < kNodes; p++) coefs[c * kNodes + p] = (g.valid_mask[c * 16 + (p >> 5)] >> (p & 31) & 1u) ? 0 : kNone;
+    RansDecoderMulti dec(s.data);
+    if (!dec.ok()) return "stream truncated";
+    const char *failure = nullptr;
+    auto gather = [&](uint32_t cell, uint32_t heap, int n, int32_t *v) { // context_modeling.rs:25-77 through the plan's static neighbour table
+        for (int k = 0; k < n; k++) {
+            const uint16_t e = st.nbr_table[heap][k];
+            v[k] = 0;
+            if (e & 0x8000u) continue; // not a node of that level anywhere
+            const int slot = (e >> 9) & 7;
+            const int32_t nc = g.nbr_cells[(size_t)cell * fri::kNbr + slot];
+            if (nc < 0) continue; // no retained cell there
+            const int32_t x = coefs[(size_t)nc * kNodes + (e & 511u)];
+            v[k] = x == kNone ? 0 : x; // .unwrap_or(0)
+        }
+    };
+    auto decode_one = [&](uint32_t cell, uint32_t heap, int bucket, int32_t prediction) { // decode_symbol, :205-264
+        const AnsContext &c = s.contexts[bucket];
+        const int state = kContexts - bucket - 1; // :239
+        const uint32_t v = dec.get_at(state, c.max_freq_bits);
+        const int sym = (int)(std::upper_bound(c.cdf.begin(), c.cdf.end(), v) - c.cdf.begin()) - 1; // :243-256, see decode_symbols
+        if (sym < 0 || c.freqs[sym] == 0) {
+            failure = "stream does not match the model";
+            return;
+        }
+        dec.advance_at(state, c.cdf[sym], c.freqs[sym], c.max_freq_bits);
+        if (!dec.ok()) {
+            failure = "stream truncated";
+            return;
+        }
+        coefs[(size_t)cell * kNodes + heap] = wadd(unpack_signed((uint32_t)sym), prediction); // :263
+    };
+    auto lf = [&](uint32_t cell, uint32_t heap) { // get_lf_context_bucket, prediction.rs:86-149
+        int32_t v[3];
+        gather(cell, heap, 3, v);
+        const uint32_t width = (uint32_t)wabs(wsub(v[0], v[2]));
+        const int32_t mx = std::max(v[0], v[2]), mn = std::min(v[0], v[2]);
+        const int32_t pred = v[1] >= mx ? mx : v[1] <= mn ? mn : wsub(wadd(v[0], v[2]), v[1]);
+        decode_one(cell, heap, bucket_of(f32_as_u32((float)width)), pred);
+    };
+    for (uint32_t e : order.level[0]) { // first scan: DC (:369-388). Every retained cell has a root, hence a DC.
+        lf(e >> 9, 0);
+        if (failure) return failure;
+    }
+    for (uint32_t e : order.level[0]) { // second scan: root (:391-410)
+        lf(e >> 9, 1);
+        if (failure) return failure;
+    }
+    for (int level = 1; level < kDepth; level++) { // :413-443
+        const int grp = level < kDepth - 2 ? 2 : level == kDepth - 2 ? 1 : 0; // prediction.rs:165-179
+        const float *wp = prm.width[grp], *vp = prm.value[grp];
+        for (uint32_t e : order.level[level]) {
+            const uint32_t cell = e >> 9, heap = e & 511u;
+            if (coefs[(size_t)cell * kNodes + heap] == kNone) continue; // :421-425
+            int32_t v[6];
+            gather(cell, heap, 6, v);
+            // get_hf_context_bucket, prediction.rs:190-206: f32, left to right, one rounding per operation (this file is built with
+            // -ffp-contract=off)
+            float width = wp[0];
+            width = width + wp[1] * (float)wabs(wsub(v[0], v[3]));
+            width = width + wp[2] * (float)wabs(wsub(v[1], v[2]));
+            width = width + wp[3] * (float)wabs(wsub(v[4], v[5]));
+            width = width + wp[4] * (float)wabs(wsub(v[1], v[5]));
+            width = width + wp[5] * (float)wabs(wsub(v[2], v[4]));
+            float pf = (float)v[0] * vp[0];
+            pf = pf + (float)v[1] * vp[1];
+            pf = pf + (float)v[2] * vp[2];
+            pf = pf + (float)v[3] * vp[3];
+            pf = pf + (float)v[4] * vp[4];
+            pf = pf + (float)v[5] * vp[5];
+            decode_one(cell, heap, bucket_of(f32_as_u32(width)), f32_as_i32(pf));
+            if (failure) return failure;
+        }
+    }
+    return "";
+}
+
+std::string count_cells(uint32_t width, uint32_t height, uint32_t channels, uint32_t &n_cells) {
+    fri::Geometry g;
+    const std::string err = fri::build_geometry(width, height, channels, fri::TilingParams{}, g);
+    n_cells = (uint32_t)g.centers.size();
+    return err;
+}
+
+std::string decode_image(const std::vector<uint8_t> &frv, DecodedImage &out) {
+    ParsedImage img;
+    const std::string err = deserialize(frv, img);
+    return err.empty() ? decode_parsed(img, out) : err;
+}
+
+std::string decode_parsed(const ParsedImage &img, DecodedImage &out) {
+    std::string err;
+    const uint32_t channels = img.colorspace == kLuma ? 1u : 3u; // ColorSpace::num_channels, images.rs:31-38
+    if (img.channels.size() != channels) return "Malformed image bytes";
+    for (const ChannelStream &c : img.channels)
+        for (const AnsContext &a : c.contexts)
+            if (a.max_freq_bits == 0) return "Malformed image bytes"; // fewer than ten EHD segments
+    fri::Geometry g;
+    err = fri::build_geometry(img.width, img.height, channels, fri::TilingParams{}, g);
+    if (!err.empty()) return err;
+    const size_t F = g.centers.size(), plane = F * kNodes;
+    out.height = img.height, out.width = img.width, out.colorspace = img.colorspace, out.channels = channels, out.n_cells = (uint32_t)F;
+    out.centers.resize(F * 2);
+    for (size_t c = 0; c < F; c++) out.centers[2 * c] = g.centers[c].x, out.centers[2 * c + 1] = g.centers[c].y;
+    out.coefs.assign(channels * plane, 0);
+    out.params = img.params;
+    const SymbolOrder order(out.centers.data(), (uint32_t)F);
+    std::vector<std::string> errs(channels);
+    std::vector<std::thread> workers;
+    for (uint32_t ch = 1; ch < channels; ch++)
+        workers.emplace_back([&, ch] { errs[ch] = decode_channel(g, order, img.channels[ch], img.params[ch], out.coefs.data() + ch * plane); });
+    errs[0] = decode_channel(g, order, img.channels[0], img.params[0], out.coefs.data());
+    for (std::thread &t : workers) t.join();
+    for (uint32_t ch = 0; ch < channels; ch++)
+        if (!errs[ch].empty()) return "channel " + std::to_string(ch) + ": " + errs[ch];
+    return "";
+}
+
 // ---- container ---------------------------------------------------------------------------------------------------------
 namespace {
 void put_u16(std::vector<uint8_t> &v, uint16_t x) { v.push_back((uint8_t)x), v.push_back((uint8_t)(x >> 8)); }

@@ -16,6 +16,10 @@
 #include <string>
 #include <vector>
 
+namespace fri {
+struct Geometry;
+}
+
 namespace libfri {
 namespace emit {
 
@@ -110,6 +114,24 @@ struct ParsedImage {
     std::vector<ChannelParams> params;
 };
 std::string deserialize(const std::vector<uint8_t> &bytes, ParsedImage &out);
+
+// ---- decoder -------------------------------------------------------------------------------------------------------
+// entropy_coding::decode (:352-443) for one channel: the symbols come back in stream order, each one's context (bucket and
+// prediction) computed from the coefficients decoded before it, exactly as prediction.rs:86-207 computes them on the encoder
+// side from the complete image - which is the same thing iff the stream order is causal (left / up_left / up_right of a node
+// precede it, the level above is complete). Inherently sequential per channel; the channels run on threads of their own.
+// coefs: [n_cells][512] output in heap order, None = INT32_MIN.
+std::string decode_channel(const fri::Geometry &g, const SymbolOrder &order, const ChannelStream &s, const ChannelParams &p, int32_t *coefs);
+struct DecodedImage {
+    uint32_t height = 0, width = 0, colorspace = 0, channels = 0, n_cells = 0;
+    std::vector<int32_t> centers;     // [n_cells][2], canonical order (the one fri_hip_plan_centers reports)
+    std::vector<int32_t> coefs;       // [channels][n_cells][512]: what fri_hip_inverse_transform takes
+    std::vector<ChannelParams> params;
+};
+// serialize::decode + entropy_coding::decode: a .frv back to the coefficient planes (the geometry is rebuilt from width x height)
+std::string decode_image(const std::vector<uint8_t> &frv, DecodedImage &out);
+std::string decode_parsed(const ParsedImage &img, DecodedImage &out); // the entropy_coding::decode half of it
+std::string count_cells(uint32_t width, uint32_t height, uint32_t channels, uint32_t &n_cells); // retained cells of a width x height image
 
 } // namespace emit
 } // namespace libfri

@@ -107,5 +107,30 @@ int fri_emit_check_image(const uint8_t *frv, size_t len, uint32_t channels, cons
     return 0;
 }
 
+// A .frv back to coefficient planes. info = {width, height, channels, n_cells}; coefs: [channels][n_cells][512] (None = INT32_MIN),
+// centers: [n_cells][2] or null. Returns -3 with `info` filled if coef_cap (in elements) is too small: call once with coef_cap = 0.
+int fri_emit_decode_image(const uint8_t *frv, size_t len, uint32_t info[4], int32_t *coefs, size_t coef_cap, int32_t *centers, char *err, size_t err_cap) {
+    if (!frv || !info) return fail(err, err_cap, "invalid argument");
+    if (!coefs || coef_cap == 0) { // size query: header + geometry only
+        ParsedImage img;
+        const std::string e = deserialize(std::vector<uint8_t>(frv, frv + len), img);
+        if (!e.empty()) return fail(err, err_cap, e, -2);
+        const uint32_t channels = img.colorspace == kLuma ? 1u : 3u;
+        uint32_t n_cells = 0;
+        const std::string ge = count_cells(img.width, img.height, channels, n_cells);
+        if (!ge.empty()) return fail(err, err_cap, ge, -2);
+        info[0] = img.width, info[1] = img.height, info[2] = channels, info[3] = n_cells;
+        return -3;
+    }
+    DecodedImage d;
+    const std::string e = decode_image(std::vector<uint8_t>(frv, frv + len), d);
+    if (!e.empty()) return fail(err, err_cap, e, -2);
+    info[0] = d.width, info[1] = d.height, info[2] = d.channels, info[3] = d.n_cells;
+    if (coef_cap < d.coefs.size()) return -3;
+    std::memcpy(coefs, d.coefs.data(), d.coefs.size() * sizeof(int32_t));
+    if (centers) std::memcpy(centers, d.centers.data(), d.centers.size() * sizeof(int32_t));
+    return 0;
+}
+
 #pragma GCC visibility pop
 } // extern "C"

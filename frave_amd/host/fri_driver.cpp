@@ -5,6 +5,8 @@
 //                                                            symbol order / ANS models / rANS / frif container on the host; self-checks the stream
 //   fri_driver encode-file <in.pgm|in.ppm> <out.frv>         the same pipeline on a binary PGM (P5, one plane) or PPM (P6, RGB) file,
 //                                                            8 bits per sample (fri-cli encode, crates/fri-cli/src/commands/encode.rs:8-54)
+//   fri_driver decode-file <in.frv> <out.pgm|out.ppm>       container -> rANS / context decoding on the host -> dequantisation + inverse
+//                                                            transform on the device (fri-cli decode, crates/fri-cli/src/commands/decode.rs)
 //   fri_driver batch <width> <height> <channels> <n_images>  BASELINE config 3: host batch with H2D / kernel / D2H overlap
 #include <chrono>
 #include <cstdio>
@@ -105,6 +107,14 @@ static int encode_image_to_file(std::vector<uint8_t> img, uint32_t w, uint32_t h
         std::fprintf(stderr, "self-check failed: %s\n", err.c_str());
         return 1;
     }
+    // and the whole way back like FRIDecoder::decode (decoder.rs:47-59): every context recomputed from the symbols decoded so far
+    t0 = std::chrono::steady_clock::now();
+    auto back = libfri::FRIDecoder().decode(bytes, opts);
+    const double t_dec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!back.ok || back.value.data != img) {
+        std::fprintf(stderr, "self-check failed: %s\n", back.ok ? "decoded image differs from the input" : back.error.c_str());
+        return 1;
+    }
     if (FILE *f = std::fopen(out_path, "wb")) {
         std::fwrite(bytes.data(), 1, bytes.size(), f);
         std::fclose(f);
@@ -112,8 +122,8 @@ static int encode_image_to_file(std::vector<uint8_t> img, uint32_t w, uint32_t h
         std::fprintf(stderr, "cannot write %s\n", out_path);
         return 1;
     }
-    std::printf("%ux%ux%u: %zu bytes, %.3f bits per pixel; device stages (incl. plan + PCIe) %.3f s, host emit %.3f s; stream self-check ok\n", w, h, c,
-                bytes.size(), 8.0 * bytes.size() / ((double)w * h), t_dev, t_host);
+    std::printf("%ux%ux%u: %zu bytes, %.3f bits per pixel; device stages (incl. plan + PCIe) %.3f s, host emit %.3f s; decoded back in %.3f s: lossless\n", w, h, c,
+                bytes.size(), 8.0 * bytes.size() / ((double)w * h), t_dev, t_host, t_dec);
     return 0;
 }
 
@@ -129,8 +139,35 @@ int main(int argc, char **argv) {
         libfri::EncoderOpts file_opts; // parameters are fitted on the device sums (fit_parameters defaults to true)
         return encode_image_to_file(std::move(img), fw, fh, fc, file_opts, argv[3]);
     }
+    if (argc >= 4 && std::string(argv[1]) == "decode-file") {
+        std::vector<uint8_t> bytes;
+        if (FILE *f = std::fopen(argv[2], "rb")) {
+            uint8_t buf[1 << 16];
+            for (size_t n; (n = std::fread(buf, 1, sizeof buf, f)) > 0;) bytes.insert(bytes.end(), buf, buf + n);
+            std::fclose(f);
+        } else {
+            std::fprintf(stderr, "cannot open %s\n", argv[2]);
+            return 1;
+        }
+        auto img = libfri::FRIDecoder().decode(bytes);
+        if (!img.ok) {
+            std::fprintf(stderr, "%s\n", img.error.c_str());
+            return 1;
+        }
+        const uint32_t ch = libfri::num_channels(img.value.metadata.colorspace);
+        FILE *f = std::fopen(argv[3], "wb");
+        if (!f) {
+            std::fprintf(stderr, "cannot write %s\n", argv[3]);
+            return 1;
+        }
+        std::fprintf(f, "%s\n%u %u\n255\n", ch == 1 ? "P5" : "P6", img.value.metadata.width, img.value.metadata.height);
+        std::fwrite(img.value.data.data(), 1, img.value.data.size(), f);
+        std::fclose(f);
+        std::printf("%ux%ux%u decoded\n", img.value.metadata.width, img.value.metadata.height, ch);
+        return 0;
+    }
     if (argc < 5) {
-        std::fprintf(stderr, "usage: %s roundtrip|encode|batch <width> <height> <channels> [n_images | out.frv]\n       %s encode-file <in.pgm|in.ppm> <out.frv>\n", argv[0], argv[0]);
+        std::fprintf(stderr, "usage: %s roundtrip|encode|batch <width> <height> <channels> [n_images | out.frv]\n       %s encode-file <in.pgm|in.ppm> <out.frv>\n       %s decode-file <in.frv> <out.pgm|out.ppm>\n", argv[0], argv[0], argv[0]);
         return 2;
     }
     const std::string cmd = argv[1];

@@ -303,6 +303,55 @@ std::vector<uint8_t> stages::serialize::encode(const CompressedImage &image) {
     return emit::serialize(image.metadata.height, image.metadata.width, cs, image.channel_data, image.params);
 }
 
+Result<CompressedImage> stages::serialize::decode(const std::vector<uint8_t> &bytes) {
+    Result<CompressedImage> r;
+    emit::ParsedImage p;
+    r.error = emit::deserialize(bytes, p);
+    if (!r.error.empty()) return r;
+    r.value.metadata.height = p.height;
+    r.value.metadata.width = p.width;
+    r.value.metadata.colorspace = p.colorspace == emit::kLuma ? ColorSpace::Luma : p.colorspace == emit::kRGB ? ColorSpace::RGB : ColorSpace::YCbCr;
+    r.value.variant = p.variant;
+    r.value.channel_data = std::move(p.channels);
+    r.value.params = std::move(p.params);
+    r.ok = true;
+    return r;
+}
+
+Result<WaveletImage> stages::entropy_coding::decode(const CompressedImage &image) {
+    Result<WaveletImage> r;
+    emit::ParsedImage p;
+    p.height = image.metadata.height, p.width = image.metadata.width, p.variant = image.variant;
+    p.colorspace = image.metadata.colorspace == ColorSpace::Luma ? emit::kLuma : image.metadata.colorspace == ColorSpace::RGB ? emit::kRGB : emit::kYCbCr;
+    p.channels = image.channel_data;
+    p.params = image.params;
+    emit::DecodedImage d;
+    r.error = emit::decode_parsed(p, d);
+    if (!r.error.empty()) return r;
+    r.value.metadata = image.metadata;
+    r.value.num_cells = d.n_cells;
+    r.value.centers = std::move(d.centers);
+    r.value.coefficients = std::move(d.coefs);
+    r.value.quantized = true;
+    r.ok = true;
+    return r;
+}
+
+Result<RasterImage> FRIDecoder::decode(const std::vector<uint8_t> &data, const EncoderOpts &opts) {
+    Result<RasterImage> r;
+    auto c = stages::serialize::decode(data);
+    if (!c.ok) {
+        r.error = "Failed to decode: " + c.error; // decoder.rs:56
+        return r;
+    }
+    auto w = stages::entropy_coding::decode(c.value);
+    if (!w.ok) {
+        r.error = "Failed to decode: " + w.error;
+        return r;
+    }
+    return decode(w.value, opts); // quantization::decode + wavelet_transform::decode: one kernel (fri_hip_inverse_transform)
+}
+
 Result<std::vector<uint8_t>> FRIEncoder::encode_bytes(std::vector<uint8_t> data, uint32_t height, uint32_t width, ColorSpace colorspace) {
     Result<std::vector<uint8_t>> r;
     auto st = encode(std::move(data), height, width, colorspace);

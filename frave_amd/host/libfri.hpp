@@ -123,6 +123,7 @@ struct CompressedImage {
     ImageMetadata metadata;
     std::vector<emit::ChannelStream> channel_data;
     std::vector<emit::ChannelParams> params;
+    uint32_t variant = 1; // FractalVariant::TameTwindragon, images.rs:49-55
 };
 namespace stages {
 namespace entropy_coding {
@@ -131,7 +132,12 @@ Result<CompressedImage> encode(const WaveletImage &image, const std::array<std::
 } // namespace entropy_coding
 namespace serialize {
 std::vector<uint8_t> encode(const CompressedImage &image); // serialize.rs:49-117
+Result<CompressedImage> decode(const std::vector<uint8_t> &bytes); // serialize.rs:119-268
 } // namespace serialize
+namespace entropy_coding {
+// entropy_coding::decode (:352-443): sequential per channel on the host (every symbol's context depends on the ones before it)
+Result<WaveletImage> decode(const CompressedImage &image);
+} // namespace entropy_coding
 } // namespace stages
 
 struct EncodedStages { // EncoderStage::EntropyEncoding(WaveletImage, [Vec<AnsContext>; 3]), encoder.rs:12
@@ -151,8 +157,12 @@ class FRIEncoder { // encoder.rs:66-109
     EncoderOpts opts_;
 };
 
-class FRIDecoder { // decoder.rs:44-59, from the WaveletTransform stage on
+class FRIDecoder { // decoder.rs:44-59
   public:
+    // the whole pipeline of decoder.rs:16-40: EncodedImage -> EntropyDecoding -> Dequantization -> WaveletTransform -> RawImage.
+    // Container parsing and entropy decoding run on the host, dequantisation + inverse transform on the device.
+    Result<RasterImage> decode(const std::vector<uint8_t> &data, const EncoderOpts &opts = EncoderOpts());
+    // from the WaveletTransform stage on
     Result<RasterImage> decode(const WaveletImage &image, const EncoderOpts &opts = EncoderOpts());
 };
 
