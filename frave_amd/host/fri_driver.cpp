@@ -3,9 +3,9 @@
 //   fri_driver roundtrip <width> <height> <channels>         encode -> predict -> decode, checks the lossless identity
 //   fri_driver encode <width> <height> <channels> <out.frv>  the whole encode pipeline on a synthetic image: device stages, then
 //                                                            symbol order / ANS models / rANS / frif container on the host; self-checks the stream
-//   fri_driver encode-file <in.pgm|in.ppm> <out.frv>         the same pipeline on a binary PGM (P5, one plane) or PPM (P6, RGB) file,
-//                                                            8 bits per sample (fri-cli encode, crates/fri-cli/src/commands/encode.rs:8-54)
-//   fri_driver decode-file <in.frv> <out.pgm|out.ppm>       container -> rANS / context decoding on the host -> dequantisation + inverse
+//   fri_driver encode-file <in.pgm|in.ppm|in.bmp> <out.frv>  the same pipeline on a binary PGM (P5, one plane), PPM (P6, RGB) or uncompressed
+//                                                            24-bit BMP file, 8 bits per sample (fri-cli encode, crates/fri-cli/src/commands/encode.rs:8-54)
+//   fri_driver decode-file <in.frv> <out.pgm|.ppm|.bmp>     container -> rANS / context decoding on the host -> dequantisation + inverse
 //                                                            transform on the device (fri-cli decode, crates/fri-cli/src/commands/decode.rs)
 //   fri_driver batch <width> <height> <channels> <n_images>  BASELINE config 3: host batch with H2D / kernel / D2H overlap
 #include <chrono>
@@ -72,6 +72,59 @@ static bool read_pnm(const char *path, std::vector<uint8_t> &data, uint32_t &w, 
     return ok;
 }
 
+// Uncompressed 24-bit BMP (BITMAPINFOHEADER, BI_RGB): rows bottom-up (top-down if the height is negative), BGR, padded to 4 bytes.
+static bool read_bmp(const char *path, std::vector<uint8_t> &data, uint32_t &w, uint32_t &h, uint32_t &c, std::string &err) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) {
+        err = std::string("cannot open ") + path;
+        return false;
+    }
+    uint8_t hd[54];
+    auto u32 = [&](int o) { return (uint32_t)hd[o] | (uint32_t)hd[o + 1] << 8 | (uint32_t)hd[o + 2] << 16 | (uint32_t)hd[o + 3] << 24; };
+    bool ok = std::fread(hd, 1, 54, f) == 54 && hd[0] == 'B' && hd[1] == 'M';
+    const int32_t sw = ok ? (int32_t)u32(18) : 0, sh = ok ? (int32_t)u32(22) : 0;
+    ok = ok && u32(14) >= 40 && (hd[28] | hd[29] << 8) == 24 && u32(30) == 0 && sw > 0 && sh != 0;
+    if (!ok) {
+        err = "not an uncompressed 24-bit BMP";
+        std::fclose(f);
+        return false;
+    }
+    w = (uint32_t)sw, h = (uint32_t)(sh < 0 ? -(int64_t)sh : sh), c = 3;
+    const size_t stride = ((size_t)w * 3 + 3) & ~(size_t)3;
+    std::vector<uint8_t> row(stride);
+    data.resize((size_t)w * h * 3);
+    ok = std::fseek(f, (long)u32(10), SEEK_SET) == 0;
+    for (uint32_t r = 0; ok && r < h; r++) {
+        ok = std::fread(row.data(), 1, stride, f) == stride;
+        uint8_t *dst = data.data() + (size_t)(sh < 0 ? r : h - 1 - r) * w * 3;
+        for (uint32_t x = 0; x < w; x++) dst[3 * x] = row[3 * x + 2], dst[3 * x + 1] = row[3 * x + 1], dst[3 * x + 2] = row[3 * x];
+    }
+    std::fclose(f);
+    if (!ok) err = "file shorter than its header says";
+    return ok;
+}
+static bool write_bmp(const char *path, const std::vector<uint8_t> &rgb, uint32_t w, uint32_t h) {
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return false;
+    const size_t stride = ((size_t)w * 3 + 3) & ~(size_t)3;
+    uint8_t hd[54] = {'B', 'M'};
+    auto put = [&](int o, uint32_t v) { hd[o] = (uint8_t)v, hd[o + 1] = (uint8_t)(v >> 8), hd[o + 2] = (uint8_t)(v >> 16), hd[o + 3] = (uint8_t)(v >> 24); };
+    put(2, (uint32_t)(54 + stride * h)), put(10, 54), put(14, 40), put(18, w), put(22, h), put(34, (uint32_t)(stride * h));
+    hd[26] = 1, hd[28] = 24;
+    std::fwrite(hd, 1, 54, f);
+    std::vector<uint8_t> row(stride, 0);
+    for (uint32_t r = 0; r < h; r++) {
+        const uint8_t *src = rgb.data() + (size_t)(h - 1 - r) * w * 3;
+        for (uint32_t x = 0; x < w; x++) row[3 * x] = src[3 * x + 2], row[3 * x + 1] = src[3 * x + 1], row[3 * x + 2] = src[3 * x];
+        std::fwrite(row.data(), 1, stride, f);
+    }
+    return std::fclose(f) == 0;
+}
+static bool has_suffix(const char *path, const char *suffix) {
+    const size_t n = std::strlen(path), m = std::strlen(suffix);
+    return n >= m && std::strcmp(path + n - m, suffix) == 0;
+}
+
 static int encode_image_to_file(std::vector<uint8_t> img, uint32_t w, uint32_t h, uint32_t c, const libfri::EncoderOpts &opts, const char *out_path) {
     const libfri::ColorSpace cs = c == 1 ? libfri::ColorSpace::Luma : libfri::ColorSpace::RGB;
     libfri::FRIEncoder encoder(opts);
@@ -132,7 +185,7 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> img;
         uint32_t fw = 0, fh = 0, fc = 0;
         std::string err;
-        if (!read_pnm(argv[2], img, fw, fh, fc, err)) {
+        if (!(has_suffix(argv[2], ".bmp") ? read_bmp(argv[2], img, fw, fh, fc, err) : read_pnm(argv[2], img, fw, fh, fc, err))) {
             std::fprintf(stderr, "%s\n", err.c_str());
             return 1;
         }
@@ -155,6 +208,14 @@ int main(int argc, char **argv) {
             return 1;
         }
         const uint32_t ch = libfri::num_channels(img.value.metadata.colorspace);
+        if (has_suffix(argv[3], ".bmp")) {
+            if (ch != 3 || !write_bmp(argv[3], img.value.data, img.value.metadata.width, img.value.metadata.height)) {
+                std::fprintf(stderr, "cannot write %s%s\n", argv[3], ch != 3 ? " (a BMP takes an RGB image)" : "");
+                return 1;
+            }
+            std::printf("%ux%ux%u decoded\n", img.value.metadata.width, img.value.metadata.height, ch);
+            return 0;
+        }
         FILE *f = std::fopen(argv[3], "wb");
         if (!f) {
             std::fprintf(stderr, "cannot write %s\n", argv[3]);
@@ -167,7 +228,7 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (argc < 5) {
-        std::fprintf(stderr, "usage: %s roundtrip|encode|batch <width> <height> <channels> [n_images | out.frv]\n       %s encode-file <in.pgm|in.ppm> <out.frv>\n       %s decode-file <in.frv> <out.pgm|out.ppm>\n", argv[0], argv[0], argv[0]);
+        std::fprintf(stderr, "usage: %s roundtrip|encode|batch <width> <height> <channels> [n_images | out.frv]\n       %s encode-file <in.pgm|in.ppm|in.bmp> <out.frv>\n       %s decode-file <in.frv> <out.pgm|out.ppm|out.bmp>\n", argv[0], argv[0], argv[0]);
         return 2;
     }
     const std::string cmd = argv[1];

@@ -254,6 +254,22 @@ def test_driver_encodes_pnm_files(tmp_path):
         out = subprocess.run([driver, "decode-file", str(dst), str(back)], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr
         assert back.read_bytes() == magic + b"\n%d %d\n255\n" % (w, h) + img.tobytes()
+        if c == 3:  # 24-bit BMP in and out (rows bottom-up, BGR, padded to 4 bytes - 322 * 3 = 966 -> 968)
+            bw, bh = 322, 150
+            bimg = _mixed_image(bw, bh, 3, 12)
+            stride = (bw * 3 + 3) & ~3
+            rows = np.zeros((bh, stride), np.uint8)
+            rows[:, : bw * 3] = bimg.reshape(bh, bw, 3)[::-1, :, ::-1].reshape(bh, bw * 3)
+            head = b"BM" + struct.pack("<IHHI", 54 + stride * bh, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, bw, bh, 1, 24, 0, stride * bh, 0, 0, 0, 0)
+            bmp, frv2, bmp2, ppm2 = tmp_path / "in.bmp", tmp_path / "bmp.frv", tmp_path / "back.bmp", tmp_path / "back_bmp.ppm"
+            bmp.write_bytes(head + rows.tobytes())
+            out = subprocess.run([driver, "encode-file", str(bmp), str(frv2)], capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0, out.stderr
+            out = subprocess.run([driver, "decode-file", str(frv2), str(bmp2)], capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0, out.stderr
+            assert bmp2.read_bytes() == bmp.read_bytes()
+            out = subprocess.run([driver, "decode-file", str(frv2), str(ppm2)], capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0 and ppm2.read_bytes() == b"P6\n%d %d\n255\n" % (bw, bh) + bimg.tobytes()
         # the same stream through the Python binding: decoded planes are the ones the device produced
         import frave_amd
 
