@@ -255,12 +255,14 @@ __device__ __forceinline__ void stage_commit(const FwdArgs &a, const Tile &t, ui
 }
 
 // ---- leaf fetch for single-channel planes ----------------------------------------------------------------------------
-// rb[dy] = LDS byte offset of pixel (x0, y0 + dy). w[0] = pixels x0..x0+3 of row 0, w[1], w[2] = pixels x0-1..x0+2 of rows 1, 2.
-__device__ __forceinline__ void fetch_windows(const uint8_t *cur, const int (&rb)[3], uint32_t (&w)[3]) {
+// wb[row] = byte offset (in LDS address space) of the row's 4-byte window: w[0] = pixels x0..x0+3 of row 0,
+// w[1], w[2] = pixels x0-1..x0+2 of rows 1, 2.
+typedef const uint32_t __attribute__((address_space(3))) *LdsDwordPtr;
+__device__ __forceinline__ void fetch_windows(const int (&wb)[3], uint32_t (&w)[3]) {
 #pragma unroll
     for (int row = 0; row < 3; row++) {
-        const uint32_t b = (uint32_t)(rb[row] - (row ? 1 : 0));
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(cur + (b & ~3u));
+        const uint32_t b = (uint32_t)wb[row];
+        const LdsDwordPtr p = (LdsDwordPtr)(uintptr_t)(b & ~3u); // the address is complete: nothing left to add per window
         w[row] = __builtin_amdgcn_alignbyte(p[1], p[0], b & 3u);
     }
 }
@@ -279,14 +281,15 @@ __device__ __forceinline__ u16x2 pair_bytes(uint32_t a, uint32_t b) {
 
 // One item of a pair: where its 8 leaves sit in the staged rectangle, and which of them are inside the image.
 struct ItemAddr {
-    int rb[3];          // LDS byte offset of (x0, y0 + dy, ch)
+    int rb[3];          // C = 3: byte offset of (x0, y0 + dy, ch) in the tile buffer. C = 1: offsets of the three leaf windows
+                        // (fetch_windows) as LDS addresses: buffer address and the rows' -1 already folded in
     uint32_t leaf_mask; // bit j = leaf j inside the image (0xFF for interior cells)
     uint32_t elem_off;  // (ch * F + cell) * 512
 };
 
 template <int C, bool FAST>
-__device__ __forceinline__ ItemAddr item_addr(const FwdArgs &a, const Tile &t, const TileCell *meta, int it, int ldx, int ldy, uint32_t sh_base,
-                                               uint32_t wc16) {
+__device__ __forceinline__ ItemAddr item_addr(const FwdArgs &a, const Tile &t, const TileCell *meta, int it, int ldx, int ldy, int lane_rb, int buf_off,
+                                               uint32_t sh_base, uint32_t wc16) {
     const int cl = it / C, ch = it - cl * C;
     const TileCell m = meta[cl];
     ItemAddr r;
@@ -295,15 +298,17 @@ __device__ __forceinline__ ItemAddr item_addr(const FwdArgs &a, const Tile &t, c
     // row y of the staged rectangle starts (a16 + (y * width + x_lo) * C) & 15 bytes into its LDS row
     const int col = __mul24(x0 - t.x_lo, C) + ch;
     if (FAST) { // width * C is a multiple of 16: the same lead-in for every row
-        r.rb[0] = __mul24(y0 - t.y_lo, a.pitch) + col + (int)(sh_base & 15u);
-        r.rb[1] = r.rb[0] + a.pitch;
-        r.rb[2] = r.rb[1] + a.pitch;
+        // = (cell part, wave-uniform: scalar ALU) + (lane part ldy * pitch + ldx * C, loop invariant): one vector add per item
+        const int cell_base = (__builtin_amdgcn_readfirstlane(m.cy) - t.y_lo) * a.pitch + (__builtin_amdgcn_readfirstlane(m.cx) - t.x_lo) * C + ch + (int)(sh_base & 15u);
+        r.rb[0] = cell_base + lane_rb + (C == 1 ? buf_off : 0);
+        r.rb[1] = r.rb[0] + (C == 1 ? a.pitch - 1 : a.pitch);
+        r.rb[2] = r.rb[0] + (C == 1 ? 2 * a.pitch - 1 : 2 * a.pitch);
     } else {
 #pragma unroll
         for (int dy = 0; dy < 3; dy++) {
             const int y = y0 + dy;
             const uint32_t sh = (sh_base + __umul24((uint32_t)y & 15u, wc16)) & 15u;
-            r.rb[dy] = __mul24(y - t.y_lo, a.pitch) + (int)sh + col;
+            r.rb[dy] = __mul24(y - t.y_lo, a.pitch) + (int)sh + col + (C == 1 ? buf_off - (dy ? 1 : 0) : 0);
         }
     }
     r.leaf_mask = 0xFFu;
@@ -337,6 +342,7 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
     const uint8_t *img = a.pixels + (size_t)blockIdx.y * a.pixel_stride;
     int32_t *coefs = a.coefs + (size_t)blockIdx.y * a.coef_stride;
     const int ldx = lane_dx(lane), ldy = lane_dy(lane);
+    const int lane_rb = ldy * a.pitch + ldx * C; // the lane's share of a leaf window's LDS offset (item_addr)
     const uint32_t a16 = (uint32_t)reinterpret_cast<uintptr_t>(img);
     const uint32_t wc = (uint32_t)a.width * C, wc16 = wc & 15u;
 
@@ -359,6 +365,7 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
 
     for (int ti = tb; ti < te; ti++) {
         const uint8_t *cur = lds + ((ti - tb) & 1) * a.buf_bytes;
+        const int buf_off = (int)(uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)cur; // LDS address of the buffer
         uint8_t *nxt = lds + (((ti - tb) & 1) ^ 1) * a.buf_bytes;
         const bool more = ti + 1 < te;
         Tile tn = t;
@@ -385,8 +392,8 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
             valid[c] = 0xFFFFFFFFu;
             if (itA < n_items) {
                 const int itB = itA + 1 < n_items ? itA + 1 : itA; // odd tail: item B mirrors A and is not stored
-                const ItemAddr A = item_addr<C, FAST>(a, t, meta, itA, ldx, ldy, sh_base, wc16);
-                const ItemAddr B = item_addr<C, FAST>(a, t, meta, itB, ldx, ldy, sh_base, wc16);
+                const ItemAddr A = item_addr<C, FAST>(a, t, meta, itA, ldx, ldy, lane_rb, buf_off, sh_base, wc16);
+                const ItemAddr B = item_addr<C, FAST>(a, t, meta, itB, ldx, ldy, lane_rb, buf_off, sh_base, wc16);
                 offA[c] = A.elem_off;
                 offB[c] = B.elem_off;
                 u16x2 leaf[8];
@@ -395,8 +402,8 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
                     // lane's 8 leaves sit in three 4-byte windows: row 0 = x..x+3, rows 1 and 2 = x-1..x+2. Fetch each window
                     // as two aligned dwords + v_alignbyte, then v_perm pairs item A's and item B's bytes into 16-bit halves.
                     uint32_t wA[3], wB[3];
-                    fetch_windows(cur, A.rb, wA);
-                    fetch_windows(cur, B.rb, wB);
+                    fetch_windows(A.rb, wA);
+                    fetch_windows(B.rb, wB);
                     if ((A.leaf_mask & B.leaf_mask) != 0xFFu) { // leaves outside the image enter as 0
                         mask_windows(A.leaf_mask, wA);
                         mask_windows(B.leaf_mask, wB);
