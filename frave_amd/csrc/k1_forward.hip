@@ -329,7 +329,10 @@ __device__ __forceinline__ ItemAddr item_addr(const FwdArgs &a, const Tile &t, c
 template <int C, bool EDGE, bool FAST, int NCH>
 __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // scalar: the per-pair branches become uniform and the items' store bases stay in SGPRs (global_store ... s[base:base+1]) instead
+    // of 64-bit vector address arithmetic per store: 117 -> 108 VGPRs, ~16 fewer vector instructions per pair
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wg = xcd_contiguous_share(blockIdx.x, a.n_wg);
     const int tb = a.wg_tiles[wg], te = a.wg_tiles[wg + 1];
     trace_stamp(a.trace, wg, 0, tid);
