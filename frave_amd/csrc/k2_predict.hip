@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(cons
     __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
     __shared__ int32_t s_slot_cell[kPredSlots];
     __shared__ uint32_t s_flag;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < kHistBins + 2; i += kPredThreads) s_hist[i] = 0;
 
     uint32_t off[8][3]; // neighbour halfword offsets relative to the own slot, loop invariant

@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
     __shared__ uint32_t s_flag;
     __shared__ unsigned long long s_int[3][28];
     __shared__ double s_dbl[3][6];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: slot, cell and the own-slot address become wave-uniform
     if (tid < 3 * 28) (&s_int[0][0])[tid] = 0;
     if (tid < 18) (&s_dbl[0][0])[tid] = 0.0;
 
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
         __syncthreads();
         for (int r = wave; r < kPredBlock * kPredBlock; r += kPredWaves) {
             const int slot = (1 + r / kPredBlock) * kPredSide + 1 + (r % kPredBlock);
-            const int cell = s_slot_cell[slot];
+            const int cell = __builtin_amdgcn_readfirstlane(s_slot_cell[slot]);
             if (cell < 0) continue;
             const uint8_t *own = s_cells + slot * kSlotStride;
             const bool boundary = __builtin_amdgcn_readfirstlane(s_slot_interior[slot]) == 0;
