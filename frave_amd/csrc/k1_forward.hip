@@ -58,7 +58,9 @@ template <int J>
 __device__ __forceinline__ void xlane_children(int lane, int v, int &l, int &r) {
     if constexpr (J < 4) {
         constexpr int ctrl = J == 0 ? 0xB1 : J == 1 ? 0x4E : J == 2 ? 0x141 : 0x140;
-        const int other = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xF, 0xF, false);
+        // every lane has a source under these controls, so the `old` operand is never used: mov_dpp leaves it undefined and the
+        // compiler needs no copy of v in front of each v_mov_b32_dpp
+        const int other = __builtin_amdgcn_mov_dpp(v, ctrl, 0xF, 0xF, true);
         const bool hi = (lane >> J) & 1;
         l = hi ? other : v;
         r = hi ? v : other;

@@ -126,6 +126,29 @@ __device__ __forceinline__ void inv_prefetch(const InvArgs &a, const Tile &t, co
     }
 }
 
+// Descriptors come out of LDS into vector registers; every lane reads the same entry, so they are moved to scalar registers
+// (uniform branches, scalar address arithmetic) - the compiler cannot prove the uniformity of an LDS load by itself.
+__device__ __forceinline__ Tile scalar_tile(const Tile &l) {
+    Tile t;
+    t.x_lo = __builtin_amdgcn_readfirstlane(l.x_lo);
+    t.y_lo = __builtin_amdgcn_readfirstlane(l.y_lo);
+    t.width_px = __builtin_amdgcn_readfirstlane(l.width_px);
+    t.n_rows = __builtin_amdgcn_readfirstlane(l.n_rows);
+    t.cell_begin = __builtin_amdgcn_readfirstlane(l.cell_begin);
+    t.cell_count = __builtin_amdgcn_readfirstlane(l.cell_count);
+    return t;
+}
+__device__ __forceinline__ InvTileLists scalar_lists(const InvTileLists &l) {
+    InvTileLists r;
+    r.quad_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.quad_begin);
+    r.quad_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.quad_count);
+    r.dword_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.dword_begin);
+    r.dword_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.dword_count);
+    r.part_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.part_begin);
+    r.part_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.part_count);
+    return r;
+}
+
 template <int NI>
 __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const InvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -154,18 +177,18 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
         for (int i = tid; i < a.buf_bytes / 16; i += kInvThreads) z[i] = u32x4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
-    const int cell0 = lds_tiles[0].cell_begin;
+    const int cell0 = __builtin_amdgcn_readfirstlane(lds_tiles[0].cell_begin);
     trace_stamp(a.trace, wg, 1, tid);
 
     InvRegs pre[NI];
-    inv_prefetch<NI>(a, lds_tiles[0], lds_cells, wave, lane, pre);
+    inv_prefetch<NI>(a, scalar_tile(lds_tiles[0]), lds_cells, wave, lane, pre);
     for (int ti = tb; ti < te; ti++) {
-        const Tile t = lds_tiles[ti - tb];
+        const Tile t = scalar_tile(lds_tiles[ti - tb]);
         InvRegs cur[NI];
 #pragma unroll
         for (int s = 0; s < NI; s++) cur[s] = pre[s];
         {
-            const Tile tn = lds_tiles[min(ti + 1, te - 1) - tb];
+            const Tile tn = scalar_tile(lds_tiles[min(ti + 1, te - 1) - tb]);
             inv_prefetch<NI>(a, tn, lds_cells + (tn.cell_begin - cell0), wave, lane, pre);
         }
         const int n_items = t.cell_count * C;
@@ -307,19 +330,19 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(co
         }
     }
     __syncthreads();
-    const int cell0 = lds_tiles[0].cell_begin;
+    const int cell0 = __builtin_amdgcn_readfirstlane(lds_tiles[0].cell_begin);
     trace_stamp(a.trace, wg, 1, tid);
 
     InvRegs pre[NI];
-    inv_prefetch<NI>(a, lds_tiles[0], lds_cells, wave, lane, pre);
+    inv_prefetch<NI>(a, scalar_tile(lds_tiles[0]), lds_cells, wave, lane, pre);
     for (int ti = tb; ti < te; ti++) {
-        const Tile t = lds_tiles[ti - tb];
-        const InvTileLists L = lds_lists[ti - tb];
+        const Tile t = scalar_tile(lds_tiles[ti - tb]);
+        const InvTileLists L = scalar_lists(lds_lists[ti - tb]);
         InvRegs cur[NI];
 #pragma unroll
         for (int s = 0; s < NI; s++) cur[s] = pre[s];
         {
-            const Tile tn = lds_tiles[min(ti + 1, te - 1) - tb];
+            const Tile tn = scalar_tile(lds_tiles[min(ti + 1, te - 1) - tb]);
             inv_prefetch<NI>(a, tn, lds_cells + (tn.cell_begin - cell0), wave, lane, pre);
         }
         // this thread's first entries of the three lists, in flight across the transform (indices clamped: the loads must be
@@ -349,7 +372,9 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(co
                 const int cl = item / C, ch = item - cl * C;
                 const TileCell tc = lds_cells[t.cell_begin - cell0 + cl];
                 const int x0 = tc.cx + lane_dx(lane), y0 = tc.cy + lane_dy(lane);
-                const int at = (y0 - t.y_lo) * pitch + x0 * C + ch - a0;
+                // (cell part: scalar) + (lane part): one vector multiply-add per item
+                const int at = (__builtin_amdgcn_readfirstlane(tc.cy) - t.y_lo) * pitch + __builtin_amdgcn_readfirstlane(tc.cx) * C + ch - a0 +
+                               lane_dy(lane) * pitch + lane_dx(lane) * C;
                 if (__builtin_amdgcn_readfirstlane(tc.interior)) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) img[at + leaf_dy(j) * pitch + leaf_dx(j) * C] = (uint8_t)min(max(leaf[s][j], 0), 255);
