@@ -100,40 +100,54 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
             const uint8_t *own = s_cells + slot * kSlotStride;
             const bool boundary = __builtin_amdgcn_readfirstlane(s_slot_interior[slot]) == 0;
 #pragma unroll 1
-            for (int i = 0; i < 8; i++) {
-                const int p = p0 + pstep * i;
-                bool use = p >= 2; // heap index 0 and 1 are coded by the LF predictor and are not rows of the fit
-                if (boundary) use = use && ((a.valid_mask[(size_t)cell * 16 + (p >> 5)] >> (p & 31)) & 1u);
-                int u[7];
-                int v[6];
-                const uint32_t off_i[3] = {s_off[i][lane][0], s_off[i][lane][1], s_off[i][lane][2]};
-                pred_gather(own, off_i, v);
-                const int value = *reinterpret_cast<const short *>(own + 2 * p);
+            for (int ip = 0; ip < 4; ip++) { // two nodes of the lane per step, packed as int16 pairs: one v_dot2 = two multiply-adds
+                const int pa = p0 + pstep * (2 * ip), pb = pa + pstep;
+                bool use_a = pa >= 2, use_b = true; // heap index 0 and 1 are coded by the LF predictor and are not rows of the fit
+                if (boundary) {
+                    use_a = use_a && ((a.valid_mask[(size_t)cell * 16 + (pa >> 5)] >> (pa & 31)) & 1u);
+                    use_b = ((a.valid_mask[(size_t)cell * 16 + (pb >> 5)] >> (pb & 31)) & 1u) != 0;
+                }
+                const uint32_t mask = (use_a ? 0x0000FFFFu : 0u) | (use_b ? 0xFFFF0000u : 0u); // a None row is all zeros in the reference (:109-134)
+                const uint32_t offa[3] = {s_off[2 * ip][lane][0], s_off[2 * ip][lane][1], s_off[2 * ip][lane][2]};
+                const uint32_t offb[3] = {s_off[2 * ip + 1][lane][0], s_off[2 * ip + 1][lane][1], s_off[2 * ip + 1][lane][2]};
+                int va[6], vb[6];
+                pred_gather(own, offa, va);
+                pred_gather(own, offb, vb);
+                const int value_a = *reinterpret_cast<const short *>(own + 2 * pa), value_b = *reinterpret_cast<const short *>(own + 2 * pb);
+                auto pack = [](int lo, int hi) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u)); };
+                auto masked = [&](s16x2 x) { return __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, x) & mask); };
                 if (MODE == 0) {
+                    s16x2 u[7], um[7];
 #pragma unroll
-                    for (int k = 0; k < 6; k++) u[k] = use ? v[k] : 0; // a None row is all zeros in the reference (:109-134)
-                    u[6] = use ? value : 0;
+                    for (int k = 0; k < 6; k++) u[k] = pack(va[k], vb[k]);
+                    u[6] = pack(value_a, value_b);
+#pragma unroll
+                    for (int k = 0; k < 7; k++) um[k] = masked(u[k]);
                     int n = 0;
 #pragma unroll
                     for (int r0 = 0; r0 < 7; r0++)
 #pragma unroll
-                        for (int c0 = r0; c0 < 7; c0++) acc[n++] += __mul24(u[r0], u[c0]);
+                        for (int c0 = r0; c0 < 7; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(um[r0], u[c0], acc[n], false);
                 } else {
-                    float pf = __fmul_rn((float)v[0], vp[0]);
+                    auto residual = [&](const int (&v)[6], int value) {
+                        float pf = __fmul_rn((float)v[0], vp[0]);
 #pragma unroll
-                    for (int k = 1; k < 6; k++) pf = __fadd_rn(pf, __fmul_rn((float)v[k], vp[k]));
-                    const float res = fabsf(__fsub_rn((float)value, pf));
-                    int w[6] = {1, iabs_w(v[0] - v[3]), iabs_w(v[1] - v[2]), iabs_w(v[4] - v[5]), iabs_w(v[1] - v[5]), iabs_w(v[2] - v[4])};
-#pragma unroll
-                    for (int k = 0; k < 6; k++) w[k] = use ? w[k] : 0;
+                        for (int k = 1; k < 6; k++) pf = __fadd_rn(pf, __fmul_rn((float)v[k], vp[k]));
+                        return (double)fabsf(__fsub_rn((float)value, pf));
+                    };
+                    const double rda = residual(va, value_a), rdb = residual(vb, value_b);
+                    auto absdiff = [&](int k0, int k1) { // |v[k0] - v[k1]| of both nodes: every Some coefficient is within [-255, 255]
+                        const s16x2 d = pack(va[k0], vb[k0]) - pack(va[k1], vb[k1]);
+                        return masked(__builtin_elementwise_max(d, -d));
+                    };
+                    const s16x2 w[6] = {masked(s16x2{1, 1}), absdiff(0, 3), absdiff(1, 2), absdiff(4, 5), absdiff(1, 5), absdiff(2, 4)};
                     int n = 0;
 #pragma unroll
                     for (int r0 = 0; r0 < 6; r0++)
 #pragma unroll
-                        for (int c0 = r0; c0 < 6; c0++) acc[n++] += __mul24(w[r0], w[c0]);
-                    const double rd = (double)res;
+                        for (int c0 = r0; c0 < 6; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(w[r0], w[c0], acc[n], false);
 #pragma unroll
-                    for (int k = 0; k < 6; k++) dacc[k] += (double)w[k] * rd;
+                    for (int k = 0; k < 6; k++) dacc[k] += (double)w[k].x * rda, dacc[k] += (double)w[k].y * rdb;
                 }
             }
             if (++cells_since_flush >= 1024) flush(); // 8 nodes x 255^2 x 1024 cells < 2^31

@@ -152,9 +152,11 @@ int fri_hip_predict_histogram_dev(fri_hip_plan *plan, const int32_t *d_coefs, ui
  * heap index >= 2 only; None rows are all zero in the reference (:109-134).
  * gram[g][28] = upper triangle (row major) of sum u u^T with u = [v0..v5, value], v = get_neighbour_values:
  *              A^T A = rows/columns 0..5, A^T b = column 6, b^T b = entry (6,6). Exact integers.
- * Precondition (both fit entry points): Some coefficients lie in [-32768, 32767], as every output of
- * fri_hip_transform_quant does; the kernels stage them as int16 like fri_hip_predict_histogram, whose
- * n_out_of_alphabet reports a violation. */
+ * Precondition (both fit entry points): Some coefficients lie in [-255, 255], as every output of
+ * fri_hip_transform_quant does (differences of 8-bit pixels, divided by a quantiser >= 1). The kernels stage them as
+ * int16 and accumulate products of pairs of rows in 32-bit partial sums (v_dot2) that are widened every 1024 cells;
+ * larger magnitudes overflow those partial sums silently. fri_hip_predict_histogram's n_out_of_alphabet reports
+ * values outside the int16 range. */
 int fri_hip_fit_value_sums(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, int64_t gram[3][28]);
 int fri_hip_fit_value_sums_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint32_t channel, int64_t *d_gram, void *stream);
 /* Width fit (optimize_width_prediction, :144-173) for given value parameters x: residual r = |f32(value) - A x| in f32
