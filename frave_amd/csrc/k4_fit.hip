@@ -117,17 +117,15 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
                 auto pack = [](int lo, int hi) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u)); };
                 auto masked = [&](s16x2 x) { return __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, x) & mask); };
                 if (MODE == 0) {
-                    s16x2 u[7], um[7];
+                    s16x2 u[7];
 #pragma unroll
-                    for (int k = 0; k < 6; k++) u[k] = pack(va[k], vb[k]);
-                    u[6] = pack(value_a, value_b);
-#pragma unroll
-                    for (int k = 0; k < 7; k++) um[k] = masked(u[k]);
+                    for (int k = 0; k < 6; k++) u[k] = masked(pack(va[k], vb[k]));
+                    u[6] = masked(pack(value_a, value_b));
                     int n = 0;
 #pragma unroll
                     for (int r0 = 0; r0 < 7; r0++)
 #pragma unroll
-                        for (int c0 = r0; c0 < 7; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(um[r0], u[c0], acc[n], false);
+                        for (int c0 = r0; c0 < 7; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(u[r0], u[c0], acc[n], false);
                 } else {
                     auto residual = [&](const int (&v)[6], int value) {
                         float pf = __fmul_rn((float)v[0], vp[0]);
