@@ -55,9 +55,12 @@ def kernels(w, h, c, slots, label):
     d_h = torch.empty(10 * 1024, dtype=torch.int32, device="cuda")
     d_o = torch.empty(1, dtype=torch.int64, device="cuda")
     d_back = torch.empty(P.pixel_bytes, dtype=torch.uint8, device="cuda")
-    k2 = timed(lambda: P.predict_histogram_dev(d_co[0].data_ptr(), 0, KAT_VALUE_PARAMS, KAT_WIDTH_PARAMS, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=s), 10)
+    vp, wp = np.asarray(KAT_VALUE_PARAMS, np.float32).reshape(3, 6), np.asarray(KAT_WIDTH_PARAMS, np.float32).reshape(3, 6)
+    co0, pb, pp, ph, po = d_co[0].data_ptr(), d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr()  # keep the host side of a call short: the loop is timed by events
+    k2 = timed(lambda: P.predict_histogram_dev(co0, 0, vp, wp, pb, pp, ph, po, stream=s), 30)
     line("K2 predict+histogram (per channel)", k2, w * h, F * 512 * 9 + 40960)
-    k3 = timed(lambda: P.inverse_transform_dev(d_co[0].data_ptr(), d_back.data_ptr(), stream=s), 10)
+    pk = d_back.data_ptr()
+    k3 = timed(lambda: P.inverse_transform_dev(co0, pk, stream=s), 30)
     line("K3 inverse (all channels)", k3, w * h, alg1)
     ok = bool(torch.equal(d_back, d_px[0]))
     tot = int(d_h.sum()) + int(d_o.item())
