@@ -7,6 +7,7 @@ Follows the reference step by step (citations relative to /root/reference/crates
   rANS              = entropy_coding.rs:332-336 over ryg_rans' published rans64 coder (the `rans` crate the reference
                       links is not part of the tree: PARITY UNPINNED for the byte stream, see frave_amd/host/emit.hpp)
   container         = stages/serialize.rs:49-117
+  decoder           = stages/serialize.rs:119-268 + stages/entropy_coding.rs:205-264, :352-443 (decode_image)
 Pure Python / numpy loops: small images only. f32 `exp` goes through the platform libm (ctypes), as it does for the
 reference and for the product.
 """
@@ -202,3 +203,78 @@ def encode_image(W, coefs, bucket, prediction, hist, value_params, width_params)
         out += b"\xff\xb4" + struct.pack("<Q", len(data)) + data + b"\xff\xb8"
     out += b"\xff\xdf"
     return bytes(out)
+
+
+def stream_nodes(W):
+    """(cell, heap) of every node in stream order, None nodes included (entropy_coding.rs:369-443 walks sorted_lattice)."""
+    centers = [tuple(int(v) for v in c) for c in W.centers()]
+    cell_of = {c: i for i, c in enumerate(centers)}
+    lvl0 = [cell_of[tuple(int(v) for v in p)] for p in W.sorted_level(0)]
+    out = [(k, 0) for k in lvl0] + [(k, 1) for k in lvl0]
+    for level in range(1, 9):
+        where = {}
+        for k, c in enumerate(centers):
+            for pos, heap in heap_positions(c, level).items():
+                where[pos] = (k, heap)
+        out += [where[(int(p[0]), int(p[1]))] for p in W.sorted_level(level)]
+    return out
+
+
+def decode_image(frv):
+    """serialize::decode + entropy_coding::decode, literally: a Wavelet of the all-zero image (WaveletImage::from_metadata), then
+    symbol by symbol the context from the coefficients decoded so far (fri_oracle_context_at = get_lf / get_hf_context_bucket on
+    the oracle's hash maps), the symbol from rANS state CONTEXT_AMOUNT - bucket - 1, and the coefficient written back.
+    Returns (width, height, channels, coefs [C][F][512])."""
+    assert frv[:4] == b"frif", "Invalid signature for FRIF image."
+    h, w, meta = struct.unpack("<III", frv[4:16])
+    C = 1 if (meta >> 30) & 3 == 1 else 3
+    W = fri_oracle.Wavelet(np.zeros(h * w * C, np.uint8), h, w, C)
+    nodes = stream_nodes(W)
+    o, ch = 16, 0
+    vp = wp = None
+    contexts, data = [], b""
+    while True:
+        seg = frv[o : o + 2]
+        o += 2
+        if seg == b"\xff\xbb":
+            prm = np.frombuffer(frv[o : o + 144], "<f4").astype(np.float32)
+            vp, wp = np.ascontiguousarray(prm[:18].reshape(3, 6)), np.ascontiguousarray(prm[18:].reshape(3, 6))
+            o += 144
+        elif seg == b"\xff\xb2":
+            c = Context()
+            c.max_freq_bits, n = struct.unpack("<IQ", frv[o : o + 12])
+            o += 12
+            c.off = list(struct.unpack("<%dH" % n, frv[o : o + 2 * n]))
+            o += 2 * n
+            c.finalize(len(contexts))  # serialize.rs:232: rebuilt from the two fields
+            contexts.append(c)
+        elif seg == b"\xff\xb4":
+            (n,) = struct.unpack("<Q", frv[o : o + 8])
+            data = frv[o + 8 : o + 8 + n]
+            o += 8 + n
+        elif seg == b"\xff\xb8":
+            words = list(struct.unpack("<%dI" % (len(data) // 4), data))
+            x = [words[2 * i] | words[2 * i + 1] << 32 for i in range(CONTEXTS)]
+            pos = 2 * CONTEXTS
+            for cell, heap in nodes:
+                ctx = W.context_at(ch, cell, heap, vp, wp)
+                if ctx is None:  # entropy_coding.rs:421-425
+                    continue
+                b, pred = ctx
+                c, s = contexts[b], CONTEXTS - b - 1  # :239
+                bits = c.max_freq_bits
+                v = x[s] & ((1 << bits) - 1)
+                sym = max(i for i in range(ALPHABET) if c.cdf[i] <= v and c.freqs[i] > 0)  # :243-256
+                x[s] = c.freqs[sym] * (x[s] >> bits) + v - c.cdf[sym]
+                if x[s] < L:
+                    x[s] = (x[s] << 32) | words[pos]
+                    pos += 1
+                value = unpack_signed(sym) + pred  # :263
+                W.set_coefficient(ch, cell, heap, int(np.int32(np.uint32(value & 0xFFFFFFFF))))
+            ch += 1
+            contexts, data = [], b""
+        elif seg == b"\xff\xdf":
+            assert ch == C
+            return w, h, C, W.coefficients()
+        else:
+            raise ValueError("Malformed image bytes")

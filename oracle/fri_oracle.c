@@ -722,6 +722,30 @@ int fri_oracle_predict(fri_oracle_wavelet *w, uint32_t channel, const float valu
     return 0;
 }
 
+/* decode_symbol's context, entropy_coding.rs:205-236: (bucket, prediction) of ONE node from the coefficients as they are now.
+ * cell = index in canonical order, heap = heap index (0 = DC, 1 = root: the low-frequency predictor). Returns -1 for a None node. */
+int fri_oracle_context_at(const fri_oracle_wavelet *w, uint32_t channel, uint32_t cell, uint32_t heap, const float value_params[3][6],
+                          const float width_params[3][6], uint32_t *bucket, int32_t *prediction) {
+    if (channel >= w->channels || cell >= w->n_retained || heap >= NODES) return -2;
+    const fractal *f = w->cells[w->order[cell]];
+    if (!f->coefficients[channel][heap].some) return -1;
+    if (heap < 2) {
+        get_lf_context_bucket(w, heap, 0, f->center, channel, bucket, prediction);
+    } else {
+        int level = 0;
+        while ((2u << level) <= heap) level++;
+        get_hf_context_bucket(w, f->image_positions[heap], (uint8_t)level, f->center, value_params, width_params, channel, bucket, prediction);
+    }
+    return 0;
+}
+
+/* fractal.coefficients[channel][haar_tree_pos] = Some(symbol), entropy_coding.rs:387, :409, :440 */
+int fri_oracle_set_coefficient(fri_oracle_wavelet *w, uint32_t channel, uint32_t cell, uint32_t heap, int32_t value) {
+    if (channel >= w->channels || cell >= w->n_retained || heap >= NODES) return -2;
+    w->cells[w->order[cell]]->coefficients[channel][heap] = some_i32(value);
+    return 0;
+}
+
 void fri_oracle_predictors(const fri_oracle_wavelet *w, uint32_t channel, uint8_t *bucket, int32_t *prediction) {
     for (uint32_t k = 0; k < w->n_retained; k++) {
         const fractal *f = w->cells[w->order[k]];

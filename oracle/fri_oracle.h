@@ -57,6 +57,12 @@ int fri_oracle_predict(fri_oracle_wavelet *w, uint32_t channel, const float valu
  * (0,0 where never written, as initialised at wavelet_transform.rs:60-64). */
 void fri_oracle_predictors(const fri_oracle_wavelet *w, uint32_t channel, uint8_t *bucket,
                            int32_t *prediction);
+/* The decoder's view (entropy_coding::decode_symbol, entropy_coding.rs:205-236): (bucket, prediction) of one node computed from
+ * the coefficients as they are at the time of the call; cell = index in canonical order. Returns -1 if the node is None. */
+int fri_oracle_context_at(const fri_oracle_wavelet *w, uint32_t channel, uint32_t cell, uint32_t heap, const float value_params[3][6],
+                          const float width_params[3][6], uint32_t *bucket, int32_t *prediction);
+/* coefficients[channel][heap] = Some(value) of one cell (entropy_coding.rs:387, :409, :440) */
+int fri_oracle_set_coefficient(fri_oracle_wavelet *w, uint32_t channel, uint32_t cell, uint32_t heap, int32_t value);
 /* ContextModeler::get_neighbour_values (context_modeling.rs:25-77) for every level>=1 node:
  * out[F][512][6]; rows for heap index 0,1 are zero. */
 void fri_oracle_neighbour_values(const fri_oracle_wavelet *w, uint32_t channel, int32_t *out);

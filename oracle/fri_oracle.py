@@ -27,8 +27,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        build()  # no-op unless the library is missing or older than its sources
         L = C.CDLL(_SO)
         vp = C.c_void_p
         L.fri_oracle_from_raster.restype = vp
@@ -47,6 +46,10 @@ def lib():
         L.fri_oracle_predict.restype = C.c_int
         L.fri_oracle_predictors.argtypes = [vp, C.c_uint32, vp, vp]
         L.fri_oracle_neighbour_values.argtypes = [vp, C.c_uint32, vp]
+        L.fri_oracle_context_at.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
+        L.fri_oracle_context_at.restype = C.c_int
+        L.fri_oracle_set_coefficient.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32]
+        L.fri_oracle_set_coefficient.restype = C.c_int
         L.fri_oracle_to_raster.argtypes = [vp, vp]
         L.fri_oracle_sorted_level.argtypes = [vp, C.c_uint32, vp]
         L.fri_oracle_sorted_level.restype = C.c_int64
@@ -131,6 +134,16 @@ class Wavelet:
         pred = np.empty((self.num_cells, 512), np.int32)
         lib().fri_oracle_predictors(self._h, channel, _p(bucket), _p(pred))
         return bucket, pred, hist, oob.value
+
+    def context_at(self, channel, cell, heap, vp, wp):
+        """(bucket, prediction) of one node from the coefficients as they are now, or None for a None node; vp / wp: float32 [3][6]"""
+        b, p = C.c_uint32(0), C.c_int32(0)
+        rc = lib().fri_oracle_context_at(self._h, channel, cell, heap, _p(vp), _p(wp), C.addressof(b), C.addressof(p))
+        assert rc in (0, -1)
+        return None if rc else (b.value, p.value)
+
+    def set_coefficient(self, channel, cell, heap, value):
+        assert lib().fri_oracle_set_coefficient(self._h, channel, cell, heap, value) == 0
 
     def neighbour_values(self, channel):
         out = np.empty((self.num_cells, 512, 6), np.int32)

@@ -158,6 +158,20 @@ def test_full_decode_recovers_the_coefficients(shape):
     assert np.array_equal(np.asarray(W.to_raster()).reshape(-1), _mixed_image(w, h, c, 21))
 
 
+@pytest.mark.parametrize("shape", [(129, 65, 1), (96, 120, 3)])
+def test_literal_decoder_of_the_restatement_reads_the_product_stream(shape):
+    """oracle/emit_oracle.decode_image walks the reference's decoder literally (hash-map lattice, get_lf / get_hf_context_bucket
+    per symbol on the coefficients decoded so far); it must read the product's .frv back to the planes the stream was made from,
+    and agree with the product's own decoder."""
+    w, h, c = shape
+    W, coefs, bucket, pred, hist, vp, wp = _arrays(w, h, c, 31)
+    frv = emit.encode_image(w, h, W.centers(), coefs, bucket, pred, hist, vp, wp)
+    ow, oh, oc, got = emit_oracle.decode_image(frv)
+    assert (ow, oh, oc) == (w, h, c)
+    assert np.array_equal(got.reshape(-1), np.asarray(coefs).reshape(-1))
+    assert np.array_equal(emit.decode_image(frv)[4].reshape(-1), got.reshape(-1))
+
+
 def test_full_decode_with_fitted_looking_parameters():
     """non-dyadic f32 parameters: the rounding order of the predictor matters now (prediction.rs:190-206)"""
     w, h, c = 200, 150, 3
