@@ -81,13 +81,16 @@ def encode_image(width, height, centers, coefs, bucket, prediction, hist, value_
     n = C.c_size_t(0)
     err = C.create_string_buffer(256)
     L = load_library()
-    rc = L.fri_emit_encode_image(width, height, channels, _p(c), len(c), _p(co), _p(b), _p(p), _p(h), _p(vp), _p(wp), None, 0, C.addressof(n), err, 256)
-    if rc != -3:
-        raise EmitError(err.value.decode() or f"fri_emit_encode_image: {rc}")
-    out = np.empty(n.value, np.uint8)
+    # one call in the common case: a symbol costs at most max_freq_bits (< 32) bits, so 4 bytes per coefficient + the container
+    # overhead always suffice; the library reports the needed size (-3) if they should not
+    out = np.empty(co.size * 4 + channels * (10 * 2070 + 256) + 64, np.uint8)
     rc = L.fri_emit_encode_image(width, height, channels, _p(c), len(c), _p(co), _p(b), _p(p), _p(h), _p(vp), _p(wp), _p(out), out.size, C.addressof(n), err, 256)
+    if rc == -3:
+        out = np.empty(n.value, np.uint8)
+        rc = L.fri_emit_encode_image(width, height, channels, _p(c), len(c), _p(co), _p(b), _p(p), _p(h), _p(vp), _p(wp), _p(out), out.size, C.addressof(n), err, 256)
     if rc != 0:
         raise EmitError(err.value.decode() or f"fri_emit_encode_image: {rc}")
+    out = out[: n.value]
     return out.tobytes()
 
 
