@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Runs the five BASELINE.json configs on one MI355X and prints a report: kernel-only Mpixels/s and
 algorithmic GB/s per kernel, fraction of the 8 TB/s HBM roofline, CPU-oracle Mpixels/s where it is run, parity verdicts.
-    python tools/report_configs.py [--quick]
+    python tests/tools/report_configs.py [--quick]
 """
 import os
 import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
