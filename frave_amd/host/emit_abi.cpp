@@ -1,9 +1,10 @@
-// emit_abi.cpp -- C entry points over emit.hpp (libfri_emit.so): what the CPU test-suite and a foreign-language host
-// bind. Plain pointers and sizes; every function returns 0 or a negative code and writes a message into `err`.
+// emit_abi.cpp -- the C entry points include/fri_emit.h declares, over emit.hpp (libfri_emit.so): what the CPU test-suite and a
+// foreign-language host bind. Plain pointers and sizes; every function returns 0 or a negative code and writes a message into `err`.
 #include <cstdio>
 #include <cstring>
 
 #include "emit.hpp"
+#include "fri_emit.h"
 
 using namespace libfri::emit;
 

@@ -1,4 +1,4 @@
-"""The C ABI library loads on a machine without a GPU and exports every symbol include/fri_hip.h declares."""
+"""The C ABI libraries load on a machine without a GPU and export every symbol include/*.h declares."""
 import ctypes
 import os
 import re
@@ -8,10 +8,25 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "fri_hip.h")).read()
+def declared_symbols(header="fri_hip.h", prefix="fri_hip_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fri_hip_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_header_under_include_is_covered():
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["fri_emit.h", "fri_hip.h"]
+
+
+def test_emit_library_exports_every_declared_symbol():
+    import frave_amd.emit as emit
+
+    lib = emit.load_library()
+    names = declared_symbols("fri_emit.h", "fri_emit_")
+    assert len(names) == 6
+    for name in names:
+        assert hasattr(lib, name), name
+        assert ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
 
 
 def test_header_and_binding_agree():
