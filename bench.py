@@ -152,7 +152,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": measured_traffic(),
-            "kernel": "fwd_transform_quant_kernel<1,false,true,4>",
+            "kernel": "fwd_transform_quant_kernel<1,false,true,4,true>",
             "kernel_us": round(kernel_us, 3),
             "algorithmic_bytes_per_launch": alg_bytes,
         },

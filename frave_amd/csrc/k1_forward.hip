@@ -138,12 +138,12 @@ __device__ __forceinline__ uint32_t validity_tree_pk(uint32_t m, int lane) {
 }
 
 __device__ __forceinline__ int quant_one(int v, int heap_index, const FwdArgs &a) { // quantization.rs:13-17, None untouched
-    return (a.q_identity || v == kNone) ? v : v / a.q.q[quant_layer(heap_index)];
+    return v == kNone ? v : v / a.q.q[quant_layer(heap_index)];
 }
 
 // Unpacks one item (HALF = 0: low halves, 1: high halves), applies the None mask and the quantiser, and stores the
 // cell's 512 int32 coefficients as four fully coalesced store instructions (1 KiB + 512 B + 256 B + 256 B).
-template <int HALF, bool MASKED>
+template <int HALF, bool MASKED, bool QID>
 __device__ __forceinline__ void store_item(int32_t *__restrict__ coefs, uint32_t elem_off, int lane, const int (&res)[8], uint32_t valid,
                                            const FwdArgs &a) {
     int v[8];
@@ -152,7 +152,7 @@ __device__ __forceinline__ void store_item(int32_t *__restrict__ coefs, uint32_t
         v[i] = HALF ? (res[i] >> 16) : (int)(short)(res[i] & 0xFFFF);
         if (MASKED && !((valid >> (16 * HALF + i)) & 1u)) v[i] = kNone;
     }
-    if (!a.q_identity) {
+    if (!QID) { // QID: the all-ones matrix of today's reference (quantization.rs:3-5) - no division code in that kernel at all
 #pragma unroll
         for (int i = 0; i < 4; i++) v[i] = quant_one(v[i], 256 + 4 * lane + i, a);
         v[4] = quant_one(v[4], 128 + 2 * lane, a);
@@ -328,7 +328,7 @@ __device__ __forceinline__ ItemAddr item_addr(const FwdArgs &a, const Tile &t, c
 // K1. grid = (workgroup shares, images), block = 256 (4 waves). Each workgroup walks the tiles of its share:
 // while tile i is being transformed out of one LDS buffer (and its coefficient stores drain), the pixel
 // rectangle of tile i+1 is already in flight from HBM/L2 into registers and is committed to the other buffer.
-template <int C, bool EDGE, bool FAST, int NCH>
+template <int C, bool EDGE, bool FAST, int NCH, bool QID>
 __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -449,11 +449,11 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
                 if (!go) go = (res[c][0] ^ res[c][1] ^ res[c][2] ^ res[c][3] ^ res[c][4] ^ res[c][5] ^ res[c][6] ^ res[c][7]) == 0x12345678; // keeps the arithmetic alive
                 if (go) {
                     if (__builtin_amdgcn_readfirstlane(valid[c] == 0xFFFFFFFFu ? 1 : 0) && __all(valid[c] == 0xFFFFFFFFu)) { // no None anywhere in the pair
-                        store_item<0, false>(coefs, offA[c], lane, res[c], valid[c], a);
-                        if (itA + 1 < n_items) store_item<1, false>(coefs, offB[c], lane, res[c], valid[c], a);
+                        store_item<0, false, QID>(coefs, offA[c], lane, res[c], valid[c], a);
+                        if (itA + 1 < n_items) store_item<1, false, QID>(coefs, offB[c], lane, res[c], valid[c], a);
                     } else {
-                        store_item<0, true>(coefs, offA[c], lane, res[c], valid[c], a);
-                        if (itA + 1 < n_items) store_item<1, true>(coefs, offB[c], lane, res[c], valid[c], a);
+                        store_item<0, true, QID>(coefs, offA[c], lane, res[c], valid[c], a);
+                        if (itA + 1 < n_items) store_item<1, true, QID>(coefs, offB[c], lane, res[c], valid[c], a);
                     }
                 }
             }
@@ -523,11 +523,13 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
     const bool fast = !edge && (((size_t)p.width * p.channels) & 15) == 0; // every image row starts at the same offset mod 16
     const bool small = fwd_chunks(p) <= 4 * (size_t)kFwdThreads;           // 4 chunks per thread suffice (the common, tuned case)
     void (*kern)(FwdArgs);
-#define FRI_PICK_N(CH, E, FA) (small ? fwd_transform_quant_kernel<CH, E, FA, 4> : fwd_transform_quant_kernel<CH, E, FA, kMaxChunksPerThread>)
+#define FRI_PICK_Q(CH, E, FA, N) (a.q_identity ? fwd_transform_quant_kernel<CH, E, FA, N, true> : fwd_transform_quant_kernel<CH, E, FA, N, false>)
+#define FRI_PICK_N(CH, E, FA) (small ? FRI_PICK_Q(CH, E, FA, 4) : FRI_PICK_Q(CH, E, FA, kMaxChunksPerThread))
 #define FRI_PICK(CH) (edge ? FRI_PICK_N(CH, true, false) : fast ? FRI_PICK_N(CH, false, true) : FRI_PICK_N(CH, false, false))
     kern = p.channels == 1 ? FRI_PICK(1) : FRI_PICK(3);
 #undef FRI_PICK
 #undef FRI_PICK_N
+#undef FRI_PICK_Q
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
