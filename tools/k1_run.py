@@ -15,5 +15,8 @@ slots = 8
 d_px = torch.randint(0, 256, (slots, plan.pixel_bytes), dtype=torch.uint8, device="cuda")
 d_co = torch.empty((slots, plan.coef_count), dtype=torch.int32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
+spin = int(os.environ.get("K1_SPIN_UP", "3000"))  # untimed: a fresh GPU needs tens of ms of work to reach steady clocks (bench.py does the same)
+if spin:
+    plan.time_transform_quant_dev(slots, d_px.data_ptr(), plan.pixel_bytes, d_co.data_ptr(), plan.coef_count, spin, stream=s)
 us = plan.time_transform_quant_dev(slots, d_px.data_ptr(), plan.pixel_bytes, d_co.data_ptr(), plan.coef_count, n, stream=s)
 print(f"K1 {us:.2f} us/launch over {n} launches")

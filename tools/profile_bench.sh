@@ -12,8 +12,8 @@ python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --extras > $OUT/bench_extras
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_traced.json 2> $OUT/trace.log
 # and once more with the extras (8-image launches of the same kernel, K2, K3)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_extras -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --extras > $OUT/bench_traced_extras.json 2> $OUT/trace_extras.log
-rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/tools/k1_run.py 40 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/tools/k1_run.py 40 > $OUT/pmc_write.log 2>&1
+K1_SPIN_UP=0 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/tools/k1_run.py 40 > $OUT/pmc_fetch.log 2>&1
+K1_SPIN_UP=0 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/tools/k1_run.py 40 > $OUT/pmc_write.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 tools/pmc_summary.py $OUT/pmc_fetch fwd_transform > $OUT/pmc_summary.txt
 python3 tools/pmc_summary.py $OUT/pmc_write fwd_transform >> $OUT/pmc_summary.txt
