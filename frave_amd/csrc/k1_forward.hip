@@ -29,7 +29,7 @@ struct FwdArgs {
     int32_t buf_bytes; // bytes of one LDS buffer (pixel rows + cell records)
     uint32_t cpr, cpr_magic;
     int32_t q_identity;
-    int32_t ablate; // timing-only ablation (FRI_HIP_K1_ABLATE): 1 = skip staging, 2 = skip the cell loop, 4 = skip stores. 0 in production.
+    int32_t ablate; // timing-only ablation (FRI_HIP_K1_ABLATE): 1 = skip staging, 2 = skip the cell loop, 4 = skip stores, 8 = return at entry. 0 in production.
     unsigned long long *trace; // diagnostic timeline, null in production
     QMatrix q;
 };
@@ -331,6 +331,7 @@ __device__ __forceinline__ ItemAddr item_addr(const FwdArgs &a, const Tile &t, c
 template <int C, bool EDGE, bool FAST, int NCH, bool QID>
 __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if (a.ablate & 8) return; // timing only: what dispatching the grid alone costs
     const int tid = threadIdx.x, lane = tid & 63;
     // scalar: the per-pair branches become uniform and the items' store bases stay in SGPRs (global_store ... s[base:base+1]) instead
     // of 64-bit vector address arithmetic per store: 117 -> 108 VGPRs, ~16 fewer vector instructions per pair
