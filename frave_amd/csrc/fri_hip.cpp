@@ -196,14 +196,22 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
     if (env_int("FRI_HIP_TILE_BYTES") > 0) tp.tile_buffer_bytes = env_int("FRI_HIP_TILE_BYTES");
     // Shares by dispatch rank, measured on MI355X at 4096^2 (tools/sweep_rank_weights.sh): equal shares 22.3-23.4 us,
     // these weights 20.5-21.7 us; steeper is worse again. Host-only plans keep equal shares.
-    if (ctx) tp.rank_weight[0] = 1.3f, tp.rank_weight[1] = 1.1f, tp.rank_weight[2] = 0.9f, tp.rank_weight[3] = 0.7f;
-    if (const char *w = std::getenv("FRI_HIP_RANK_WEIGHTS")) { // "w0,w1,w2,w3" (tuning; "1,1,1,1" = equal shares)
-        float v[4];
-        if (std::sscanf(w, "%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3]) == 4)
-            for (int i = 0; i < 4; i++) tp.rank_weight[i] = v[i];
-    }
-    tp.target_wgs = env_int("FRI_HIP_TARGET_WGS");
-    if (tp.target_wgs <= 0 && ctx) tp.target_wgs = ctx->cu_count * 4; // 4 resident workgroups per CU (register budget of K1)
+    // Resident K1 workgroups per CU: 4 by registers; fewer when the LDS of one workgroup (two tile buffers) does not fit four times:
+    // RGB tiles need ~47 KB, so three. One share per resident workgroup, sized by dispatch rank.
+    auto set_ranks = [&](int ranks) {
+        tp.ranks = ranks;
+        static const float w4[4] = {1.3f, 1.1f, 0.9f, 0.7f}, w3[4] = {1.3f, 1.1f, 0.6f, 0.f}, w2[4] = {1.15f, 0.85f, 0.f, 0.f}, w1[4] = {1.f, 0.f, 0.f, 0.f};
+        const float *w = ranks >= 4 ? w4 : ranks == 3 ? w3 : ranks == 2 ? w2 : w1;
+        for (int i = 0; i < 4; i++) tp.rank_weight[i] = ctx ? w[i] : 0.f;
+        if (const char *e = std::getenv("FRI_HIP_RANK_WEIGHTS")) { // "w0,w1,w2,w3" (tuning; "1,1,1,1" = equal shares)
+            float v[4];
+            if (std::sscanf(e, "%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3]) == 4)
+                for (int i = 0; i < 4; i++) tp.rank_weight[i] = v[i];
+        }
+        tp.target_wgs = env_int("FRI_HIP_TARGET_WGS");
+        if (tp.target_wgs <= 0 && ctx) tp.target_wgs = ctx->cu_count * ranks;
+    };
+    set_ranks(env_int("FRI_HIP_RANKS") > 0 ? std::min(env_int("FRI_HIP_RANKS"), 4) : 4);
     // Shrink the tiles until they fit the forward kernel's static register / LDS budget (irregular centre spacing
     // makes a few tiles wider than the average; RGB triples the bytes per pixel).
     for (;;) {
@@ -219,7 +227,14 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         probe.lds_rows = p->geo.lds_rows;
         probe.max_tile_cells = p->geo.max_tile_cells;
         probe.max_wg_tiles = std::max(p->geo.max_wg_tiles, p->geo.max_wg_tiles_batch);
-        if (fwd_plan_fits(probe)) break;
+        if (fwd_plan_fits(probe)) {
+            const int resident = (int)std::min<size_t>(4, (160 * 1024) / fwd_lds_bytes(probe));
+            if (ctx && env_int("FRI_HIP_RANKS") <= 0 && resident >= 1 && resident < tp.ranks) { // e.g. RGB: three workgroups per CU
+                set_ranks(resident);
+                continue;
+            }
+            break;
+        }
         tp.band_rows = p->geo.band_rows;
         tp.cells_per_tile = p->geo.cells_per_tile - 1;
         if (tp.cells_per_tile < 1) {

@@ -379,17 +379,19 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         g.tiles.push_back(t);
     };
     // Share boundaries. Equal shares (+-1 cell) unless rank weights are given: share sh is run by workgroup b(sh) (the inverse
-    // of the kernels' XCD-contiguous block -> share map), whose dispatch rank is b / (target_wgs / 4).
+    // of the kernels' XCD-contiguous block -> share map), whose dispatch rank is b / (target_wgs / ranks).
     std::vector<size_t> bound(n_wg + 1);
     {
-        const bool weighted = tp.rank_weight[0] > 0 && tp.rank_weight[1] > 0 && tp.rank_weight[2] > 0 && tp.rank_weight[3] > 0;
+        const int ranks = std::min(std::max(tp.ranks, 1), 4);
+        bool weighted = true;
+        for (int i = 0; i < ranks; i++) weighted = weighted && tp.rank_weight[i] > 0;
         std::vector<double> cum(n_wg + 1, 0.0);
-        const size_t q = n_wg >> 3, r = n_wg & 7, per_rank = std::max<size_t>(1, (size_t)target_wgs / 4);
+        const size_t q = n_wg >> 3, r = n_wg & 7, per_rank = std::max<size_t>(1, (size_t)target_wgs / ranks);
         for (size_t x = 0, sh = 0; x < 8; x++) {
             const size_t n_x = q + (x < r ? 1 : 0);
             for (size_t idx = 0; idx < n_x; idx++, sh++) {
                 const size_t b = idx * 8 + x;
-                cum[sh + 1] = cum[sh] + (weighted ? (double)tp.rank_weight[std::min<size_t>(b / per_rank, 3)] : 1.0);
+                cum[sh + 1] = cum[sh] + (weighted ? (double)tp.rank_weight[std::min<size_t>(b / per_rank, ranks - 1)] : 1.0);
             }
         }
         for (size_t sh = 0; sh <= n_wg; sh++) bound[sh] = (size_t)((double)F * cum[sh] / cum[n_wg] + 0.5);

@@ -110,9 +110,11 @@ struct TilingParams {
     int band_rows = 0, cells_per_tile = 0; // 0 = default
     int target_wgs = 0;   // workgroup shares to aim for (resident workgroups of the device); 0 = 1024
     int cells_per_wg = 0; // if > 0 overrides target_wgs
-    // Relative share size by dispatch rank (workgroup b has rank min(4 b / target_wgs, 3): the r-th workgroup placed on its CU).
-    // The CU's arbiter favours older waves, so later workgroups progress more slowly and get fewer cells. {0,..} = equal shares.
+    // Relative share size by dispatch rank (workgroup b has rank min(ranks * b / target_wgs, ranks - 1): the r-th workgroup placed
+    // on its CU). The CU's arbiter favours older waves, so later workgroups progress more slowly and get fewer cells.
+    // {0,..} = equal shares.
     float rank_weight[4] = {0, 0, 0, 0};
+    int ranks = 4; // resident workgroups per CU (<= 4)
     // Bytes one LDS tile buffer may take (rows * pitch); tiles of sparse bands (the image's last rows) are cut narrower
     // instead of sizing every buffer for them. 0 = no cap.
     int tile_buffer_bytes = 0;
