@@ -378,9 +378,47 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         g.max_tile_cells = std::max(g.max_tile_cells, t.cell_count);
         g.tiles.push_back(t);
     };
-    // Share boundaries. Equal shares (+-1 cell) unless rank weights are given: share sh is run by workgroup b(sh) (the inverse
-    // of the kernels' XCD-contiguous block -> share map), whose dispatch rank is b / (target_wgs / ranks).
-    std::vector<size_t> bound(n_wg + 1);
+    // Widest tile the LDS budget allows: the largest pitch = 8 or 24 (mod 32 dwords) with rows * pitch <= budget, minus the
+    // 30 bytes of lead-in / round-up. Cells of a run are sorted by x.
+    int width_cap = INT_MAX;
+    if (tp.tile_buffer_bytes > 0) {
+        int pitch = (tp.tile_buffer_bytes / (band_rows + 20)) / 16 * 16;
+        while (pitch > 0 && ((pitch / 4) % 32) != 8 && ((pitch / 4) % 32) != 24) pitch -= 16;
+        width_cap = std::max(46, (pitch - 30) / (int)channels); // a single cell (46 px) must always fit
+    }
+    auto width_of = [&](size_t a, size_t b2) {
+        const int x0 = std::max(g.centers[order[a]].x - 15, 0), x1 = std::min(g.centers[order[b2 - 1]].x + 30, W - 1);
+        return x1 - x0 + 1;
+    };
+    // Tiles first: every band (a maximal run of the ordered cells) is cut evenly into tiles of <= cells_per_tile cells, so all
+    // but a few tiles are full or one cell short. A tile costs a workgroup one iteration whatever it holds: cutting the bands
+    // *after* dealing cells to the shares (as an earlier version did) left 6- and 7-cell tiles everywhere (4672 tiles for the 33 289
+    // cells of a 4096^2 plane instead of 4290).
+    for (size_t i = 0; i < F;) {
+        size_t j = i;
+        const int b = band(order[i]);
+        while (j < F && band(order[j]) == b) j++;
+        const size_t m = j - i, n_t = (m + cells_per_tile - 1) / cells_per_tile;
+        bool fits = true;
+        for (size_t t = 0; t < n_t && fits; t++) fits = width_of(i + m * t / n_t, i + m * (t + 1) / n_t) <= width_cap;
+        if (fits) {
+            for (size_t t = 0; t < n_t; t++) emit_tile(i + m * t / n_t, i + m * (t + 1) / n_t);
+        } else { // a sparse band: greedy, as many cells as the width cap allows (always at least one)
+            for (size_t a = i; a < j;) {
+                size_t b2 = a + 1;
+                while (b2 < j && b2 - a < (size_t)cells_per_tile && width_of(a, b2 + 1) <= width_cap) b2++;
+                emit_tile(a, b2);
+                a = b2;
+            }
+        }
+        i = j;
+    }
+    // Then whole tiles to shares. Equal tile counts (+-1) unless rank weights are given: share sh is run by workgroup b(sh) (the
+    // inverse of the kernels' XCD-contiguous block -> share map), whose dispatch rank is b / (target_wgs / ranks).
+    const size_t T = g.tiles.size();
+    if (tp.cells_per_wg <= 0) n_wg = (size_t)target_wgs; // one share per resident workgroup, or one per tile if there are fewer tiles
+    n_wg = std::max<size_t>(1, std::min(n_wg, T));
+    g.cells_per_wg = (int32_t)((F + n_wg - 1) / n_wg);
     {
         const int ranks = std::min(std::max(tp.ranks, 1), 4);
         bool weighted = true;
@@ -394,50 +432,17 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
                 cum[sh + 1] = cum[sh] + (weighted ? (double)tp.rank_weight[std::min<size_t>(b / per_rank, ranks - 1)] : 1.0);
             }
         }
-        for (size_t sh = 0; sh <= n_wg; sh++) bound[sh] = (size_t)((double)F * cum[sh] / cum[n_wg] + 0.5);
-        bound[0] = 0;
-        bound[n_wg] = F;
-        for (size_t sh = 1; sh <= n_wg; sh++) // every share keeps at least one cell (n_wg <= F)
-            bound[sh] = std::min(std::max(bound[sh], bound[sh - 1] + 1), F - (n_wg - sh));
-    }
-    // Widest tile the LDS budget allows: the largest pitch = 8 or 24 (mod 32 dwords) with rows * pitch <= budget, minus the
-    // 30 bytes of lead-in / round-up. Cells of a run are sorted by x.
-    int width_cap = INT_MAX;
-    if (tp.tile_buffer_bytes > 0) {
-        int pitch = (tp.tile_buffer_bytes / (band_rows + 20)) / 16 * 16;
-        while (pitch > 0 && ((pitch / 4) % 32) != 8 && ((pitch / 4) % 32) != 24) pitch -= 16;
-        width_cap = std::max(46, (pitch - 30) / (int)channels); // a single cell (46 px) must always fit
-    }
-    auto width_of = [&](size_t a, size_t b2) {
-        const int x0 = std::max(g.centers[order[a]].x - 15, 0), x1 = std::min(g.centers[order[b2 - 1]].x + 30, W - 1);
-        return x1 - x0 + 1;
-    };
-    g.wg_tiles.push_back(0);
-    for (size_t sh = 0; sh < n_wg; sh++) {
-        const size_t s0 = bound[sh], s1 = bound[sh + 1];
-        g.max_wg_cells = std::max(g.max_wg_cells, (int32_t)(s1 - s0));
-        size_t i = s0;
-        while (i < s1) { // maximal run inside one band, cut evenly into tiles of <= cells_per_tile cells
-            size_t j = i;
-            const int b = band(order[i]);
-            while (j < s1 && band(order[j]) == b) j++;
-            const size_t m = j - i, n_t = (m + cells_per_tile - 1) / cells_per_tile;
-            bool fits = true;
-            for (size_t t = 0; t < n_t && fits; t++) fits = width_of(i + m * t / n_t, i + m * (t + 1) / n_t) <= width_cap;
-            if (fits) {
-                for (size_t t = 0; t < n_t; t++) emit_tile(i + m * t / n_t, i + m * (t + 1) / n_t);
-            } else { // a sparse band: greedy, as many cells as the width cap allows (always at least one)
-                for (size_t a = i; a < j;) {
-                    size_t b2 = a + 1;
-                    while (b2 < j && b2 - a < (size_t)cells_per_tile && width_of(a, b2 + 1) <= width_cap) b2++;
-                    emit_tile(a, b2);
-                    a = b2;
-                }
-            }
-            i = j;
+        g.wg_tiles.assign(n_wg + 1, 0);
+        for (size_t sh = 0; sh <= n_wg; sh++) g.wg_tiles[sh] = (int32_t)((double)T * cum[sh] / cum[n_wg] + 0.5);
+        g.wg_tiles[0] = 0;
+        g.wg_tiles[n_wg] = (int32_t)T;
+        for (size_t sh = 1; sh <= n_wg; sh++) // every share keeps at least one tile (n_wg <= T)
+            g.wg_tiles[sh] = (int32_t)std::min<size_t>(std::max<size_t>((size_t)g.wg_tiles[sh], (size_t)g.wg_tiles[sh - 1] + 1), T - (n_wg - sh));
+        for (size_t sh = 0; sh < n_wg; sh++) {
+            const Tile &first = g.tiles[g.wg_tiles[sh]], &last = g.tiles[g.wg_tiles[sh + 1] - 1];
+            g.max_wg_cells = std::max(g.max_wg_cells, last.cell_begin + last.cell_count - first.cell_begin);
+            g.max_wg_tiles = std::max(g.max_wg_tiles, g.wg_tiles[sh + 1] - g.wg_tiles[sh]);
         }
-        g.max_wg_tiles = std::max(g.max_wg_tiles, (int32_t)g.tiles.size() - g.wg_tiles.back());
-        g.wg_tiles.push_back((int32_t)g.tiles.size());
     }
     {
         const size_t cells_target = (size_t)(tp.batch_share_tiles > 0 ? tp.batch_share_tiles : 4) * cells_per_tile;

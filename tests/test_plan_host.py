@@ -97,8 +97,9 @@ def test_forward_decomposition(shape):
     assert t["lds_pitch"] % 16 == 0 and t["lds_pitch"] >= tiles[:, 2].max() * c + 15
     assert t["lds_rows"] == tiles[:, 3].max()
     assert 2 * (t["lds_pitch"] * t["lds_rows"] + 16 * t["max_tile_cells"]) < 160 * 1024
-    sizes = np.diff(np.concatenate([[0], np.cumsum(tiles[:, 5])[wg[1:] - 1]]))
-    assert sizes.max() - sizes.min() <= 1  # workgroup shares are balanced to one cell
+    per_share = np.diff(wg)  # whole tiles are dealt to the shares (a tile costs one iteration whatever it holds)
+    assert per_share.max() - per_share.min() <= 1  # balanced to one tile (host-only plans carry no rank weights)
+    assert (tiles[:, 5] >= t["cells_per_tile"] - 1).mean() > 0.9 or len(tiles) < 20  # bands are cut evenly: tiles are full or one short
 
 
 def test_survey_size_table():
