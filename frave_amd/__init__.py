@@ -9,8 +9,10 @@ from .api import (  # noqa: F401
     NONE,
     Context,
     FriHipError,
+    Multi,
     Plan,
     build_library,
     library_path,
     load_library,
+    shard_images,
 )

@@ -21,6 +21,8 @@ SYMBOLS = [
     "fri_hip_predict_histogram_dev", "fri_hip_fit_value_sums", "fri_hip_fit_value_sums_dev", "fri_hip_fit_width_sums",
     "fri_hip_fit_width_sums_dev", "fri_hip_inverse_transform", "fri_hip_inverse_transform_dev",
     "fri_hip_time_transform_quant_dev", "fri_hip_plan_read_trace", "fri_hip_plan_inverse_lists",
+    "fri_hip_shard_size", "fri_hip_shard_image", "fri_hip_multi_create", "fri_hip_multi_destroy", "fri_hip_multi_num_devices",
+    "fri_hip_multi_plan", "fri_hip_multi_transform_quant",
 ]
 
 
@@ -102,6 +104,13 @@ def load_library():
     L.fri_hip_plan_read_trace.argtypes = [vp, vp]
     L.fri_hip_plan_inverse_lists.argtypes = [vp, vp]
     L.fri_hip_time_transform_quant_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, u32, vp, C.POINTER(C.c_double)]
+    L.fri_hip_shard_size.restype, L.fri_hip_shard_size.argtypes = u32, [u32, u32, u32]
+    L.fri_hip_shard_image.restype, L.fri_hip_shard_image.argtypes = u32, [u32, u32, u32]
+    L.fri_hip_multi_create.argtypes = [vp, u32, u32, u32, u32, C.POINTER(vp)]
+    L.fri_hip_multi_destroy.argtypes = [vp]
+    L.fri_hip_multi_num_devices.restype, L.fri_hip_multi_num_devices.argtypes = u32, [vp]
+    L.fri_hip_multi_plan.restype, L.fri_hip_multi_plan.argtypes = vp, [vp, u32]
+    L.fri_hip_multi_transform_quant.argtypes = [vp, u32, vp, vp, vp]
     _lib = L
     return L
 
@@ -143,6 +152,48 @@ def _check(rc, where, ctx=None):
         if ctx is not None and ctx._h:
             detail = load_library().fri_hip_last_hip_error(ctx._h).decode()
         raise FriHipError(rc, where, detail)
+
+
+def shard_images(n_images, shard, n_shards):
+    """Global indices of the images of `shard` (fri_hip_shard_size / fri_hip_shard_image: image i -> shard i mod n_shards)."""
+    L = load_library()
+    return [L.fri_hip_shard_image(k, shard, n_shards) for k in range(L.fri_hip_shard_size(n_images, shard, n_shards))]
+
+
+class Multi:
+    """fri_hip_multi: one process driving several GPUs, one ctx + plan per device, image i on devices[i mod len(devices)]."""
+
+    def __init__(self, devices, width, height, channels):
+        self._h = None
+        h = C.c_void_p()
+        dev = (C.c_int * len(devices))(*devices)
+        _check(load_library().fri_hip_multi_create(dev, len(devices), width, height, channels, C.byref(h)), "fri_hip_multi_create")
+        self._h = h
+        self.channels = channels
+        L = load_library()
+        self.num_devices = L.fri_hip_multi_num_devices(h)
+        self.num_cells = L.fri_hip_plan_num_cells(L.fri_hip_multi_plan(h, 0))
+
+    def transform_quant(self, images, qmatrix=None):
+        imgs = [np.ascontiguousarray(i, np.uint8).reshape(-1) for i in images]
+        outs = [np.empty((self.channels, self.num_cells, 512), np.int32) for _ in imgs]
+        n = len(imgs)
+        pin = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        pout = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        q = _q(qmatrix)
+        _check(load_library().fri_hip_multi_transform_quant(self._h, n, pin, _p(q), pout), "fri_hip_multi_transform_quant")
+        return outs
+
+    def close(self):
+        if self._h:
+            load_library().fri_hip_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

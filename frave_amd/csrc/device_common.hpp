@@ -66,6 +66,13 @@ __device__ __forceinline__ uint32_t xcd_contiguous_share(uint32_t b, uint32_t n)
 #define FRI_HIP_ENABLE_TRACE 0 // `make trace` builds the instrumented library; the stamps are compiled out of the product
 #endif
 constexpr bool kTraceBuild = FRI_HIP_ENABLE_TRACE != 0;
+// Timing-only ablations (skip staging / the cell loop / stores) exist in the `make tuning` build alone; in the product the
+// flags are the constant 0 and every test on them folds away.
+#ifndef FRI_HIP_ENABLE_ABLATE
+#define FRI_HIP_ENABLE_ABLATE 0
+#endif
+constexpr bool kAblateBuild = FRI_HIP_ENABLE_ABLATE != 0;
+__device__ __forceinline__ int ablate_flags(int flags) { return kAblateBuild ? flags : 0; }
 constexpr int kTraceSlots = 16;
 __device__ __forceinline__ void trace_stamp(unsigned long long *trace, uint32_t wg, int slot, int tid) {
     if (kTraceBuild && trace && tid == 0) trace[(size_t)wg * kTraceSlots + min(slot, 13)] = wall_clock64();

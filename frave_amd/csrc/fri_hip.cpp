@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "geometry.hpp"
@@ -55,6 +56,22 @@ struct fri_hip_plan {
     double *d_fit_dbl = nullptr;             // [3][6]
     Slot slots[kBatchSlots];
     bool slots_ready = false;
+    // K2 / K4 hand their sums over through plan-owned accumulators that are all zero between launches (kernels.hpp). One
+    // accumulator per stream that launches on this plan: launches of one stream are ordered anyway; when more streams than
+    // accumulators are in play a stream taking over an accumulator first waits (on the device) for its previous user.
+    struct AccSlot {
+        hipStream_t stream = nullptr;
+        bool used = false;
+        hipEvent_t handed_over = nullptr;
+    } acc_slots[kPredAccRing];
+    uint32_t acc_next = 0;
+    bool acc_dirty = false; // a launch on this plan failed: the accumulators are re-zeroed before the next use
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr; // timing helper's events, created with the plan (creating an event is not work to be timed)
+};
+
+struct fri_hip_multi {
+    std::vector<fri_hip_ctx *> ctxs;
+    std::vector<fri_hip_plan *> plans;
 };
 
 namespace {
@@ -98,8 +115,15 @@ int need_device(const fri_hip_plan *p) {
     return FRI_HIP_OK;
 }
 
+// Tuning knobs (tile shapes, share weights, kernel A/B switches, trace) are read from the environment only when the caller opts
+// in with FRI_HIP_TUNING=1; otherwise the library's behaviour does not depend on the process environment.
+bool tuning_enabled() {
+    const char *s = std::getenv("FRI_HIP_TUNING");
+    return s && s[0] == '1' && s[1] == 0;
+}
+const char *env_str(const char *name) { return tuning_enabled() ? std::getenv(name) : nullptr; }
 int env_int(const char *name) {
-    const char *s = std::getenv(name);
+    const char *s = env_str(name);
     return s ? std::atoi(s) : 0;
 }
 
@@ -117,16 +141,62 @@ int ensure_staging(fri_hip_plan *p) {
     return FRI_HIP_OK;
 }
 
+// Accumulator for a K2 / K4 launch on `stream` (see fri_hip_plan::acc_slots). Returns the index, or a negative error code.
+int acquire_acc(fri_hip_plan *p, hipStream_t stream) {
+    fri_hip_ctx *c = p->ctx;
+    if (p->acc_dirty) { // rare: a previous launch failed part-way; nothing may be in flight on the accumulators when they are cleared
+        HIP_TRY(c, hipDeviceSynchronize());
+        HIP_TRY(c, hipMemset(p->dev.pred_acc, 0, (size_t)kPredAccRing * kPredAccWords * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemset(p->dev.fit_acc, 0, (size_t)kPredAccRing * kFitAccWords * sizeof(unsigned long long)));
+        p->acc_dirty = false;
+    }
+    for (uint32_t i = 0; i < kPredAccRing; i++)
+        if (p->acc_slots[i].used && p->acc_slots[i].stream == stream) return (int)i;
+    for (uint32_t i = 0; i < kPredAccRing; i++)
+        if (!p->acc_slots[i].used) {
+            p->acc_slots[i].used = true;
+            p->acc_slots[i].stream = stream;
+            return (int)i;
+        }
+    auto &v = p->acc_slots[p->acc_next];
+    const int idx = (int)p->acc_next;
+    p->acc_next = (p->acc_next + 1) % kPredAccRing;
+    if (!v.handed_over) HIP_TRY(c, hipEventCreateWithFlags(&v.handed_over, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(v.handed_over, v.stream)); // everything the previous owner has queued so far ...
+    HIP_TRY(c, hipStreamWaitEvent(stream, v.handed_over, 0)); // ... finishes before the new owner's kernel starts
+    v.stream = stream;
+    return idx;
+}
+
+void free_slots(fri_hip_plan *p) {
+    for (Slot &s : p->slots) {
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.h_pixels) (void)hipHostFree(s.h_pixels);
+        if (s.h_coefs) (void)hipHostFree(s.h_coefs);
+        if (s.d_pixels) (void)hipFree(s.d_pixels);
+        if (s.d_coefs) (void)hipFree(s.d_coefs);
+        s = Slot{};
+    }
+    p->slots_ready = false;
+}
+
 int ensure_slots(fri_hip_plan *p) {
     if (p->slots_ready) return FRI_HIP_OK;
     fri_hip_ctx *c = p->ctx;
     const size_t pb = fri_hip_plan_pixel_bytes(p), cb = fri_hip_plan_coef_count(p) * sizeof(int32_t);
-    for (Slot &s : p->slots) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipHostMalloc((void **)&s.h_pixels, pb, hipHostMallocDefault));
-        HIP_TRY(c, hipHostMalloc((void **)&s.h_coefs, cb, hipHostMallocDefault));
-        HIP_TRY(c, hipMalloc((void **)&s.d_pixels, pb));
-        HIP_TRY(c, hipMalloc((void **)&s.d_coefs, cb));
+    auto alloc_all = [&]() -> int {
+        for (Slot &s : p->slots) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+            HIP_TRY(c, hipHostMalloc((void **)&s.h_pixels, pb, hipHostMallocDefault));
+            HIP_TRY(c, hipHostMalloc((void **)&s.h_coefs, cb, hipHostMallocDefault));
+            HIP_TRY(c, hipMalloc((void **)&s.d_pixels, pb));
+            HIP_TRY(c, hipMalloc((void **)&s.d_coefs, cb));
+        }
+        return FRI_HIP_OK;
+    };
+    if (int rc = alloc_all()) { // a partial set is of no use: give everything back, the next call starts over
+        free_slots(p);
+        return rc;
     }
     p->slots_ready = true;
     return FRI_HIP_OK;
@@ -203,7 +273,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         static const float w4[4] = {1.3f, 1.1f, 0.9f, 0.7f}, w3[4] = {1.3f, 1.1f, 0.6f, 0.f}, w2[4] = {1.15f, 0.85f, 0.f, 0.f}, w1[4] = {1.f, 0.f, 0.f, 0.f};
         const float *w = ranks >= 4 ? w4 : ranks == 3 ? w3 : ranks == 2 ? w2 : w1;
         for (int i = 0; i < 4; i++) tp.rank_weight[i] = ctx ? w[i] : 0.f;
-        if (const char *e = std::getenv("FRI_HIP_RANK_WEIGHTS")) { // "w0,w1,w2,w3" (tuning; "1,1,1,1" = equal shares)
+        if (const char *e = env_str("FRI_HIP_RANK_WEIGHTS")) { // "w0,w1,w2,w3" (tuning; "1,1,1,1" = equal shares)
             float v[4];
             if (std::sscanf(e, "%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3]) == 4)
                 for (int i = 0; i < 4; i++) tp.rank_weight[i] = v[i];
@@ -313,7 +383,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.k2_single_buffered = env_int("FRI_HIP_K2_V1") > 0;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
-        if (const char *e = std::getenv("FRI_HIP_K1_BATCH_SHARES")) d.k1_batch_shares = std::atoi(e) != 0;
+        if (const char *e = env_str("FRI_HIP_K1_BATCH_SHARES")) d.k1_batch_shares = std::atoi(e) != 0;
         d.k3_ablate = env_int("FRI_HIP_K3_ABLATE");
         d.k3_scan = env_int("FRI_HIP_K3_SCAN") > 0;
         if (!g.inv_lists.empty()) {
@@ -336,6 +406,10 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         }
         int hb = env_int("FRI_HIP_HIST_BLOCKS");
         if (hb > 0) d.hist_blocks = (uint32_t)hb;
+        if (hipEventCreate(&p->ev_begin) != hipSuccess || hipEventCreate(&p->ev_end) != hipSuccess) {
+            fri_hip_plan_destroy(p);
+            return FRI_HIP_ERR_HIP;
+        }
     }
     *out = p;
     return FRI_HIP_OK;
@@ -348,13 +422,11 @@ int fri_hip_plan_destroy(fri_hip_plan *p) {
         for (void *d : p->owned) (void)hipFree(d);
         for (void *d : {(void *)p->d_pixels, (void *)p->d_coefs, (void *)p->d_bucket, (void *)p->d_prediction, (void *)p->d_hist, (void *)p->d_oob, (void *)p->d_fit_int, (void *)p->d_fit_dbl})
             if (d) (void)hipFree(d);
-        for (Slot &s : p->slots) {
-            if (s.stream) (void)hipStreamDestroy(s.stream);
-            if (s.h_pixels) (void)hipHostFree(s.h_pixels);
-            if (s.h_coefs) (void)hipHostFree(s.h_coefs);
-            if (s.d_pixels) (void)hipFree(s.d_pixels);
-            if (s.d_coefs) (void)hipFree(s.d_coefs);
-        }
+        free_slots(p);
+        for (auto &a : p->acc_slots)
+            if (a.handed_over) (void)hipEventDestroy(a.handed_over);
+        if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
+        if (p->ev_end) (void)hipEventDestroy(p->ev_end);
     }
     delete p;
     return FRI_HIP_OK;
@@ -484,6 +556,69 @@ int fri_hip_transform_quant_batch(fri_hip_plan *p, uint32_t n_images, const uint
     return FRI_HIP_OK;
 }
 
+/* ---- sharding over GPUs ---------------------------------------------------------------------- */
+uint32_t fri_hip_shard_size(uint32_t n_images, uint32_t shard, uint32_t n_shards) {
+    if (!n_shards || shard >= n_shards) return 0;
+    return n_images / n_shards + (shard < n_images % n_shards ? 1u : 0u);
+}
+uint32_t fri_hip_shard_image(uint32_t k, uint32_t shard, uint32_t n_shards) { return k * n_shards + shard; }
+
+int fri_hip_multi_create(const int *devices, uint32_t n_devices, uint32_t width, uint32_t height, uint32_t channels, fri_hip_multi **out) {
+    if (!out) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!devices || !n_devices || n_devices > 64) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    fri_hip_multi *m = new (std::nothrow) fri_hip_multi;
+    if (!m) return FRI_HIP_ERR_OUT_OF_MEMORY;
+    m->ctxs.assign(n_devices, nullptr);
+    m->plans.assign(n_devices, nullptr);
+    for (uint32_t d = 0; d < n_devices; d++) {
+        int rc = fri_hip_ctx_create(devices[d], &m->ctxs[d]);
+        if (rc == FRI_HIP_OK) rc = fri_hip_plan_create(m->ctxs[d], width, height, channels, &m->plans[d]);
+        if (rc != FRI_HIP_OK) {
+            fri_hip_multi_destroy(m);
+            return rc;
+        }
+    }
+    *out = m;
+    return FRI_HIP_OK;
+}
+
+int fri_hip_multi_destroy(fri_hip_multi *m) {
+    if (!m) return FRI_HIP_OK;
+    for (fri_hip_plan *p : m->plans) fri_hip_plan_destroy(p);
+    for (fri_hip_ctx *c : m->ctxs) fri_hip_ctx_destroy(c);
+    delete m;
+    return FRI_HIP_OK;
+}
+
+uint32_t fri_hip_multi_num_devices(const fri_hip_multi *m) { return m ? (uint32_t)m->plans.size() : 0; }
+fri_hip_plan *fri_hip_multi_plan(fri_hip_multi *m, uint32_t d) { return m && d < m->plans.size() ? m->plans[d] : nullptr; }
+
+int fri_hip_multi_transform_quant(fri_hip_multi *m, uint32_t n_images, const uint8_t *const *pixels, const int32_t qmatrix[32], int32_t *const *coefs) {
+    if (!m || !pixels || !coefs || !qmatrix) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    const uint32_t n_devices = (uint32_t)m->plans.size();
+    std::vector<int> rcs(n_devices, FRI_HIP_OK);
+    auto work = [&](uint32_t d) {
+        const uint32_t n = fri_hip_shard_size(n_images, d, n_devices);
+        if (!n) return;
+        std::vector<const uint8_t *> in(n);
+        std::vector<int32_t *> out(n);
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t i = fri_hip_shard_image(k, d, n_devices);
+            in[k] = pixels[i];
+            out[k] = coefs[i];
+        }
+        rcs[d] = fri_hip_transform_quant_batch(m->plans[d], n, in.data(), qmatrix, out.data());
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t d = 1; d < n_devices; d++) threads.emplace_back(work, d);
+    work(0); // the calling thread drives the first device
+    for (auto &t : threads) t.join();
+    for (int rc : rcs)
+        if (rc != FRI_HIP_OK) return rc;
+    return FRI_HIP_OK;
+}
+
 /* ---- prediction + histogram ----------------------------------------------------------------- */
 int fri_hip_predict_histogram_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t channel, const float value_params[3][6],
                                   const float width_params[3][6], uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist,
@@ -494,7 +629,12 @@ int fri_hip_predict_histogram_dev(fri_hip_plan *p, const int32_t *d_coefs, uint3
     std::memcpy(pp.value, value_params, sizeof(pp.value));
     std::memcpy(pp.width, width_params, sizeof(pp.width));
     const int32_t *plane = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
-    HIP_TRY(p->ctx, launch_predict_histogram(p->dev, plane, pp, d_bucket, d_prediction, d_hist, (unsigned long long *)d_n_out_of_alphabet, (hipStream_t)stream));
+    const int acc = acquire_acc(p, (hipStream_t)stream);
+    if (acc < 0) return acc;
+    if (hipError_t e = launch_predict_histogram(p->dev, (uint32_t)acc, plane, pp, d_bucket, d_prediction, d_hist, (unsigned long long *)d_n_out_of_alphabet, (hipStream_t)stream)) {
+        p->acc_dirty = true;
+        return fail_hip(p->ctx, e, "launch_predict_histogram");
+    }
     return FRI_HIP_OK;
 }
 
@@ -525,7 +665,12 @@ int fri_hip_fit_value_sums_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t
     if (!d_coefs || !d_gram || channel >= p->geo.channels) return FRI_HIP_ERR_INVALID_ARGUMENT;
     PredictParams pp{};
     const int32_t *plane = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
-    HIP_TRY(p->ctx, launch_fit_accumulate(p->dev, 0, plane, pp, (unsigned long long *)d_gram, nullptr, (hipStream_t)stream));
+    const int acc = acquire_acc(p, (hipStream_t)stream);
+    if (acc < 0) return acc;
+    if (hipError_t e = launch_fit_accumulate(p->dev, (uint32_t)acc, 0, plane, pp, (unsigned long long *)d_gram, nullptr, (hipStream_t)stream)) {
+        p->acc_dirty = true;
+        return fail_hip(p->ctx, e, "launch_fit_accumulate");
+    }
     return FRI_HIP_OK;
 }
 
@@ -536,7 +681,12 @@ int fri_hip_fit_width_sums_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t
     PredictParams pp{};
     std::memcpy(pp.value, value_params, sizeof(pp.value));
     const int32_t *plane = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
-    HIP_TRY(p->ctx, launch_fit_accumulate(p->dev, 1, plane, pp, (unsigned long long *)d_wtw, d_wtr, (hipStream_t)stream));
+    const int acc = acquire_acc(p, (hipStream_t)stream);
+    if (acc < 0) return acc;
+    if (hipError_t e = launch_fit_accumulate(p->dev, (uint32_t)acc, 1, plane, pp, (unsigned long long *)d_wtw, d_wtr, (hipStream_t)stream)) {
+        p->acc_dirty = true;
+        return fail_hip(p->ctx, e, "launch_fit_accumulate");
+    }
     return FRI_HIP_OK;
 }
 
@@ -600,9 +750,9 @@ int fri_hip_time_transform_quant_dev(fri_hip_plan *p, uint32_t n_images, const u
     QMatrix q;
     if (int rc = check_q(qmatrix, q)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(p->ctx, hipEventCreate(&e0));
-    HIP_TRY(p->ctx, hipEventCreate(&e1));
+    if (!p->ev_begin) HIP_TRY(p->ctx, hipEventCreate(&p->ev_begin)); // normally made by fri_hip_plan_create; owned by the plan either way
+    if (!p->ev_end) HIP_TRY(p->ctx, hipEventCreate(&p->ev_end));
+    const hipEvent_t e0 = p->ev_begin, e1 = p->ev_end;
     HIP_TRY(p->ctx, hipEventRecord(e0, s));
     for (uint32_t i = 0; i < iters; i++) {
         const uint32_t k = i % n_images;
@@ -612,8 +762,6 @@ int fri_hip_time_transform_quant_dev(fri_hip_plan *p, uint32_t n_images, const u
     HIP_TRY(p->ctx, hipEventSynchronize(e1));
     float ms = 0.f;
     HIP_TRY(p->ctx, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *mean_us = (double)ms * 1000.0 / iters;
     return FRI_HIP_OK;
 }

@@ -201,7 +201,7 @@ __device__ __forceinline__ void stage_issue(const FwdArgs &a, const Tile &t, con
     // global_load (a flat_load would also count on lgkmcnt and tie the prefetch to every LDS wait of the transform).
     const uint32_t a16 = (uint32_t)reinterpret_cast<uintptr_t>(img);
     const uint32_t img_bytes = (uint32_t)a.width * (uint32_t)a.height * C;
-    const uint32_t n_rows = (a.ablate & 1) ? 0u : (uint32_t)t.n_rows;
+    const uint32_t n_rows = (ablate_flags(a.ablate) & 1) ? 0u : (uint32_t)t.n_rows;
     const uint32_t row_bytes = (uint32_t)t.width_px * C;
     const uint32_t tile_off = ((uint32_t)t.y_lo * (uint32_t)a.width + (uint32_t)t.x_lo) * C;
     const u32x4 *meta = reinterpret_cast<const u32x4 *>(a.tile_meta + t.cell_begin);
@@ -246,7 +246,7 @@ __device__ __forceinline__ void stage_issue(const FwdArgs &a, const Tile &t, con
 // Branch-free like stage_issue: chunks a thread did not need go to its private junk slot.
 template <int NCH>
 __device__ __forceinline__ void stage_commit(const FwdArgs &a, const Tile &t, uint8_t *buf, uint8_t *junk, int tid, const u32x4 (&sv)[NCH + 1]) {
-    const uint32_t total = (a.ablate & 1) ? 0u : (uint32_t)t.n_rows * a.cpr;
+    const uint32_t total = (ablate_flags(a.ablate) & 1) ? 0u : (uint32_t)t.n_rows * a.cpr;
     uint8_t *mine = junk + 16 * tid;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
@@ -331,7 +331,7 @@ __device__ __forceinline__ ItemAddr item_addr(const FwdArgs &a, const Tile &t, c
 template <int C, bool EDGE, bool FAST, int NCH, bool QID>
 __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    if (a.ablate & 8) return; // timing only: what dispatching the grid alone costs
+    if (ablate_flags(a.ablate) & 8) return; // timing only: what dispatching the grid alone costs
     const int tid = threadIdx.x, lane = tid & 63;
     // scalar: the per-pair branches become uniform and the items' store bases stay in SGPRs (global_store ... s[base:base+1]) instead
     // of 64-bit vector address arithmetic per store: 117 -> 108 VGPRs, ~16 fewer vector instructions per pair
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
         }
 
         const TileCell *meta = reinterpret_cast<const TileCell *>(cur + a.meta_off);
-        const int n_items = (a.ablate & 2) ? 0 : t.cell_count * C;
+        const int n_items = (ablate_flags(a.ablate) & 2) ? 0 : t.cell_count * C;
         const uint32_t sh_base = a16 + (uint32_t)t.x_lo * C;
         int res[kMaxPairsPerWave][8];
         uint32_t offA[kMaxPairsPerWave], offB[kMaxPairsPerWave], valid[kMaxPairsPerWave];
@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
         for (int c = 0; c < kMaxPairsPerWave; c++) {
             const int itA = 2 * (wave + kFwdWaves * c);
             if (itA < n_items) {
-                bool go = !(a.ablate & 4);
+                bool go = !(ablate_flags(a.ablate) & 4);
                 if (!go) go = (res[c][0] ^ res[c][1] ^ res[c][2] ^ res[c][3] ^ res[c][4] ^ res[c][5] ^ res[c][6] ^ res[c][7]) == 0x12345678; // keeps the arithmetic alive
                 if (go) {
                     if (__builtin_amdgcn_readfirstlane(valid[c] == 0xFFFFFFFFu ? 1 : 0) && __all(valid[c] == 0xFFFFFFFFu)) { // no None anywhere in the pair

@@ -466,12 +466,12 @@ void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out) {
     }
 }
 
-hipError_t launch_predict_histogram(const DevicePlan &p, const int32_t *coefs_channel, const PredictParams &pp, uint8_t *bucket,
+hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t acc_slot, const int32_t *coefs_channel, const PredictParams &pp, uint8_t *bucket,
                                     int32_t *prediction, uint32_t *hist, unsigned long long *n_oob, hipStream_t stream) {
-    if (!p.pred_acc) return hipErrorInvalidValue;
+    if (!p.pred_acc || acc_slot >= kPredAccRing) return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     PredArgs a{};
-    a.acc = p.pred_acc + (size_t)(p.pred_seq++ % kPredAccRing) * kPredAccWords; // one accumulator per launch in flight
+    a.acc = p.pred_acc + (size_t)acc_slot * kPredAccWords;
     a.coefs = coefs_channel;
     a.pred_slots = p.pred_slots;
     a.nbr_table = p.nbr_table;

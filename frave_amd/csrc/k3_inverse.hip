@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
 #pragma unroll
         for (int s = 0; s < NI; s++) {
             const int item = wave + kInvWaves * s;
-            if (item < n_items && !(a.ablate & 2)) {
+            if (item < n_items && !(ablate_flags(a.ablate) & 2)) {
                 const int cl = item / C, ch = item - cl * C;
                 const TileCell tc = lds_cells[t.cell_begin - cell0 + cl];
                 const int x0 = tc.cx + lane_dx(lane), y0 = tc.cy + lane_dy(lane);
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
                 uint8_t *p = a.pixels + g - (int)((base_lo + (uint32_t)g) & 15u) + 16 * k; // 16-byte aligned
                 const u32x4 out{__builtin_amdgcn_perm(lo.y, lo.x, 0x06040200u), __builtin_amdgcn_perm(lo.w, lo.z, 0x06040200u),
                                 __builtin_amdgcn_perm(hi.y, hi.x, 0x06040200u), __builtin_amdgcn_perm(hi.w, hi.z, 0x06040200u)};
-                if (!(a.ablate & 1)) *reinterpret_cast<u32x4 *>(p) = out;
+                if (!(ablate_flags(a.ablate) & 1)) *reinterpret_cast<u32x4 *>(p) = out;
             }
             const unsigned long long m = __ballot(rim);
             if (rim) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(r << 8 | k);
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
                 src[0] = u32x4{0u, 0u, 0u, 0u};
                 src[1] = u32x4{0u, 0u, 0u, 0u};
                 const uint32_t u[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                if (!(a.ablate & 1)) {
+                if (!(ablate_flags(a.ablate) & 1)) {
 #pragma unroll
                     for (int d = 0; d < 4; d++) {
                         const uint32_t v0 = u[2 * d], v1 = u[2 * d + 1];
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(co
 #pragma unroll
         for (int s = 0; s < NI; s++) {
             const int item = wave + kInvWaves * s;
-            if (item < n_items && !(a.ablate & 2)) {
+            if (item < n_items && !(ablate_flags(a.ablate) & 2)) {
                 const int cl = item / C, ch = item - cl * C;
                 const TileCell tc = lds_cells[t.cell_begin - cell0 + cl];
                 const int x0 = tc.cx + lane_dx(lane), y0 = tc.cy + lane_dy(lane);
@@ -394,20 +394,20 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(co
             const uint32_t rk = m < kInvListPre ? (m == 0 ? qe[0] : m == 1 ? qe[1] : qe[2]) : a.quads[L.quad_begin + e];
             const uint32_t r = rk >> 8, k = rk & 255u;
             const u32x4 v = *reinterpret_cast<const u32x4 *>(img + r * pitch + 16 * k);
-            if (!(a.ablate & 1)) *reinterpret_cast<u32x4 *>(out0 + (size_t)r * wc + 16 * k) = v;
+            if (!(ablate_flags(a.ablate) & 1)) *reinterpret_cast<u32x4 *>(out0 + (size_t)r * wc + 16 * k) = v;
         }
         for (uint32_t e = tid, m = 0; e < L.dword_count; e += kInvThreads, m++) { // whole dwords of partly owned quads
             const uint32_t rd = m < kInvListPre ? (m == 0 ? de[0] : m == 1 ? de[1] : de[2]) : a.dwords[L.dword_begin + e];
             const uint32_t r = rd >> 8, d = rd & 255u;
             const uint32_t v = *reinterpret_cast<const uint32_t *>(img + r * pitch + 4 * d);
-            if (!(a.ablate & 1)) *reinterpret_cast<uint32_t *>(out0 + (size_t)r * wc + 4 * d) = v;
+            if (!(ablate_flags(a.ablate) & 1)) *reinterpret_cast<uint32_t *>(out0 + (size_t)r * wc + 4 * d) = v;
         }
         for (uint32_t e = tid, m = 0; e < L.part_count; e += kInvThreads, m++) { // the fractal rim proper: byte stores
             const uint32_t ent = m < kInvListPre ? (m == 0 ? pe[0] : m == 1 ? pe[1] : pe[2]) : a.parts[L.part_begin + e];
             const uint32_t r = ent >> 12, d = (ent >> 4) & 255u, nib = ent & 15u;
             const uint32_t v = *reinterpret_cast<const uint32_t *>(img + r * pitch + 4 * d);
             uint8_t *p = out0 + (size_t)r * wc + 4 * d;
-            if (!(a.ablate & 1)) {
+            if (!(ablate_flags(a.ablate) & 1)) {
                 if (nib & 1u) p[0] = (uint8_t)v;
                 if (nib & 2u) p[1] = (uint8_t)(v >> 8);
                 if (nib & 4u) p[2] = (uint8_t)(v >> 16);

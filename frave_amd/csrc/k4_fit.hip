@@ -224,9 +224,9 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
 
 } // namespace
 
-hipError_t launch_fit_accumulate(const DevicePlan &p, int mode, const int32_t *coefs_channel, const PredictParams &pp, unsigned long long *sums_int,
+hipError_t launch_fit_accumulate(const DevicePlan &p, uint32_t acc_slot, int mode, const int32_t *coefs_channel, const PredictParams &pp, unsigned long long *sums_int,
                                  double *sums_dbl, hipStream_t stream) {
-    if (!p.fit_acc) return hipErrorInvalidValue;
+    if (!p.fit_acc || acc_slot >= kPredAccRing) return hipErrorInvalidValue;
     FitArgs a{};
     a.coefs = coefs_channel;
     a.pred_slots = p.pred_slots;
@@ -236,7 +236,7 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, int mode, const int32_t *c
     a.valid_mask = p.valid_mask;
     a.n_tiles = p.n_pred_tiles;
     a.pp = pp;
-    a.acc = p.fit_acc + (size_t)(p.fit_seq++ % kPredAccRing) * kFitAccWords;
+    a.acc = p.fit_acc + (size_t)acc_slot * kFitAccWords;
     a.gram = sums_int;
     a.wtw = sums_int;
     a.wtr = sums_dbl;

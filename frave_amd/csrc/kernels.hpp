@@ -35,9 +35,7 @@ struct DevicePlan {
     uint32_t hist_blocks = 0;
     uint8_t *junk = nullptr;              // [pred_blocks][kPredJunkWaves][kPredJunkBytes]: output lines of block slots without a cell (pipelined K2)
     uint32_t *pred_acc = nullptr;         // [kPredAccRing][kPredAccWords] K2 histogram accumulators, all zero between launches
-    mutable uint32_t pred_seq = 0;
     unsigned long long *fit_acc = nullptr; // [kPredAccRing][kFitAccWords] fit-sum accumulators, all zero between launches
-    mutable uint32_t fit_seq = 0;
     uint32_t pred_blocks = 0;             // workgroups of the pipelined K2: one 1024-thread workgroup per CU
     bool k2_single_buffered = false;      // FRI_HIP_K2_V1=1: the earlier single-buffered K2 (A/B)
     uint32_t n_tiles = 0;
@@ -73,10 +71,11 @@ struct PredictParams {
 hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, const uint8_t *pixels, size_t pixel_stride, int32_t *coefs,
                                       size_t coef_stride, const QMatrix &q, hipStream_t stream);
 // K2: neighbour gather + bucket/prediction + LDS histogram, then the partial-histogram reduction.
-hipError_t launch_predict_histogram(const DevicePlan &p, const int32_t *coefs_channel, const PredictParams &pp, uint8_t *bucket,
+// acc_slot < kPredAccRing selects the plan accumulator the launch hands its sums over through (one per stream, fri_hip.cpp).
+hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t acc_slot, const int32_t *coefs_channel, const PredictParams &pp, uint8_t *bucket,
                                     int32_t *prediction, uint32_t *hist, unsigned long long *n_oob, hipStream_t stream);
 // Fit accumulators: mode 0 = value fit (sums_int[3][28]), mode 1 = width fit (sums_int[3][21], sums_dbl[3][6]).
-hipError_t launch_fit_accumulate(const DevicePlan &p, int mode, const int32_t *coefs_channel, const PredictParams &pp, unsigned long long *sums_int,
+hipError_t launch_fit_accumulate(const DevicePlan &p, uint32_t acc_slot, int mode, const int32_t *coefs_channel, const PredictParams &pp, unsigned long long *sums_int,
                                  double *sums_dbl, hipStream_t stream);
 // K3: (reference-faithful) dequantisation + inverse transform + clamp.
 hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, const QMatrix &q, uint8_t *pixels, hipStream_t stream);

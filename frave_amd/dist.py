@@ -8,10 +8,14 @@ import time
 
 
 def images_for_rank(n_images, rank, world):
-    """Indices of the images rank `rank` of `world` processes: i mod world == rank (BASELINE config 4)."""
+    """Indices of the images rank `rank` of `world` processes owns (BASELINE config 4): the library's partition
+    (fri_hip_shard_size / fri_hip_shard_image, include/fri_hip.h: image i -> shard i mod world), the same one the
+    one-process multi-GPU helper fri_hip_multi_transform_quant and `fri_driver batch --gpus N` use."""
     if world < 1 or not 0 <= rank < world:
         raise ValueError("bad rank/world")
-    return list(range(rank, n_images, world))
+    from .api import shard_images
+
+    return shard_images(n_images, rank, world)
 
 
 def timed_region(fn, dist=None, device_sync=None, device=None):

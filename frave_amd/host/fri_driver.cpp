@@ -7,7 +7,10 @@
 //                                                            24-bit BMP file, 8 bits per sample (fri-cli encode, crates/fri-cli/src/commands/encode.rs:8-54)
 //   fri_driver decode-file <in.frv> <out.pgm|.ppm|.bmp>     container -> rANS / context decoding on the host -> dequantisation + inverse
 //                                                            transform on the device (fri-cli decode, crates/fri-cli/src/commands/decode.rs)
-//   fri_driver batch <width> <height> <channels> <n_images>  BASELINE config 3: host batch with H2D / kernel / D2H overlap
+//   fri_driver batch <width> <height> <channels> <n_images> [--gpus N]
+//                                                            BASELINE config 3: host batch with H2D / kernel / D2H overlap; with --gpus N
+//                                                            BASELINE config 4: the batch sharded over N GPUs of this node (image i -> GPU i mod N,
+//                                                            one host thread + ctx per GPU, no collective; fri_hip_multi_transform_quant)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -275,17 +278,25 @@ int main(int argc, char **argv) {
     }
     if (cmd == "batch") {
         const uint32_t n = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 16;
-        libfri::Device dev(0);
-        std::string err;
-        fri_hip_plan *plan = dev.plan(w, h, c, err);
-        if (!plan) {
-            std::fprintf(stderr, "%s\n", err.c_str());
+        uint32_t gpus = 1;
+        for (int i = 6; i + 1 < argc; i++)
+            if (std::string(argv[i]) == "--gpus") gpus = (uint32_t)std::atoi(argv[i + 1]);
+        if (!gpus || gpus > 64) {
+            std::fprintf(stderr, "--gpus must be 1..64\n");
+            return 2;
+        }
+        std::vector<int> devices(gpus);
+        for (uint32_t d = 0; d < gpus; d++) devices[d] = (int)d;
+        fri_hip_multi *multi = nullptr;
+        if (int rc = fri_hip_multi_create(devices.data(), gpus, w, h, c, &multi)) {
+            std::fprintf(stderr, "%s\n", fri_hip_strerror(rc));
             return 1;
         }
+        const size_t coef_count = fri_hip_plan_coef_count(fri_hip_multi_plan(multi, 0));
         const uint32_t distinct = n < 8 ? n : 8; // a few distinct inputs, every image gets its own output
         std::vector<std::vector<uint8_t>> in(distinct);
         for (uint32_t i = 0; i < distinct; i++) in[i] = noise_image(w, h, c, i);
-        std::vector<std::vector<int32_t>> out(n, std::vector<int32_t>(fri_hip_plan_coef_count(plan)));
+        std::vector<std::vector<int32_t>> out(n, std::vector<int32_t>(coef_count));
         std::vector<const uint8_t *> pin(n);
         std::vector<int32_t *> pout(n);
         for (uint32_t i = 0; i < n; i++) {
@@ -293,15 +304,24 @@ int main(int argc, char **argv) {
             pout[i] = out[i].data();
         }
         std::vector<int32_t> q(32, 1);
-        int rc = fri_hip_transform_quant_batch(plan, n < 3 ? n : 3, pin.data(), q.data(), pout.data()); // warm-up (allocates pinned staging)
+        // warm-up pass on a few images per GPU (allocates the pinned staging), then the timed pass
+        int rc = fri_hip_multi_transform_quant(multi, n < 3 * gpus ? n : 3 * gpus, pin.data(), q.data(), pout.data());
         auto t0 = std::chrono::steady_clock::now();
-        if (rc == FRI_HIP_OK) rc = fri_hip_transform_quant_batch(plan, n, pin.data(), q.data(), pout.data());
+        if (rc == FRI_HIP_OK) rc = fri_hip_multi_transform_quant(multi, n, pin.data(), q.data(), pout.data());
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        fri_hip_multi_destroy(multi);
         if (rc != FRI_HIP_OK) {
-            std::fprintf(stderr, "%s\n", dev.describe(rc).c_str());
+            std::fprintf(stderr, "%s\n", fri_hip_strerror(rc));
             return 1;
         }
-        std::printf("batch %u x %ux%ux%u: %.3f s, %.1f Mpixels/s host-to-host (PCIe inclusive)\n", n, w, h, c, s, (double)n * w * h / s / 1e6);
+        // images that share an input must have produced identical coefficients, whichever GPU they ran on
+        for (uint32_t i = distinct; i < n; i++)
+            if (out[i] != out[i % distinct]) {
+                std::fprintf(stderr, "image %u differs from image %u (same input)\n", i, i % distinct);
+                return 1;
+            }
+        std::printf("batch %u x %ux%ux%u on %u GPU(s) (image i -> GPU i mod %u): %.3f s, %.1f Mpixels/s host-to-host (PCIe inclusive)\n", n, w, h, c, gpus, gpus,
+                    s, (double)n * w * h / s / 1e6);
         return 0;
     }
     std::fprintf(stderr, "unknown command %s\n", cmd.c_str());

@@ -121,6 +121,26 @@ int fri_hip_transform_quant_batch_dev(fri_hip_plan *plan, uint32_t n_images, con
 int fri_hip_transform_quant_batch(fri_hip_plan *plan, uint32_t n_images, const uint8_t *const *pixels, const int32_t qmatrix[32],
                                   int32_t *const *coefs);
 
+/* ---- a batch of independent images over several GPUs (BASELINE config 4) ---------------------- */
+/* The reference encodes a batch as a sequential loop over independent images (crates/fri-cli/src/commands/bench.rs:15-120 around
+ * FRIEncoder::encode, encoder.rs:87-109). Images never exchange data (K2 needs all cells of ONE image, so an image is never
+ * split), hence the batch shards by image with no collective: image i belongs to shard i mod n_shards. These two functions are
+ * the partition every multi-GPU path uses (one process per GPU under torch.distributed: shard = rank; one process driving
+ * several GPUs: shard = position in `devices`). */
+uint32_t fri_hip_shard_size(uint32_t n_images, uint32_t shard, uint32_t n_shards);  /* images of this shard (0 on bad arguments) */
+uint32_t fri_hip_shard_image(uint32_t k, uint32_t shard, uint32_t n_shards);        /* global index of the shard's k-th image */
+/* One process driving several GPUs of a node: a fri_hip_multi owns one ctx + plan (+ its stream set and pinned staging) per
+ * device. fri_hip_multi_transform_quant starts one host thread per device; thread d runs fri_hip_transform_quant_batch over
+ * shard d of the images (image i -> devices[i mod n_devices]). No data moves between devices. Returns the first failing
+ * shard's error code. fri_hip_multi_plan gives device d's plan for use with any other entry point (from one thread at a time). */
+typedef struct fri_hip_multi fri_hip_multi;
+int fri_hip_multi_create(const int *devices, uint32_t n_devices, uint32_t width, uint32_t height, uint32_t channels, fri_hip_multi **out);
+int fri_hip_multi_destroy(fri_hip_multi *m);
+uint32_t fri_hip_multi_num_devices(const fri_hip_multi *m);
+fri_hip_plan *fri_hip_multi_plan(fri_hip_multi *m, uint32_t d);
+int fri_hip_multi_transform_quant(fri_hip_multi *m, uint32_t n_images, const uint8_t *const *pixels, const int32_t qmatrix[32],
+                                  int32_t *const *coefs);
+
 /* ---- prediction + context bucket + ANS symbol histogram -------------------------------------- */
 /* Replaces the loop body of prediction::encode (stages/prediction.rs:237-298) for one channel:
  * get_lf_context_bucket (:86-149) for heap index 0 and 1, get_hf_context_bucket (:151-207) with

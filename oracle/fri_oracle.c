@@ -286,7 +286,7 @@ static void extract_coefficients(fractal *f, const fri_oracle_wavelet *w, uint8_
 }
 
 /* utils.rs:17-32 (order_complex): ascending im, then re */
-static const fri_oracle_wavelet *g_sort_ctx;
+static _Thread_local const fri_oracle_wavelet *g_sort_ctx; /* qsort has no context argument; thread-local so that independent images can be transformed on independent threads (bench.py's all-core cpu_baseline) */
 static int cmp_cells(const void *a, const void *b) {
     const fractal *fa = g_sort_ctx->cells[*(const uint32_t *)a];
     const fractal *fb = g_sort_ctx->cells[*(const uint32_t *)b];

@@ -1,0 +1,97 @@
+"""BASELINE config 4: 1024 x 4096x4096 images sharded per image over 8 MI355X, no collective.
+
+The GPU test runs ONE GPU's share exactly as a rank of the 8-GPU job would (rank 0 of 8: images 0, 8, ..., 1016 = 128 images,
+as 4 launches of 32 through fri_hip_transform_quant_batch_dev), with the partition function every multi-GPU path uses
+(fri_hip_shard_size / fri_hip_shard_image). Sampled images are compared with the CPU oracle bit for bit, every image is checked by
+the K3 round trip, and a batched image equals the same image in a launch of its own. The reference counterpart is the per-image
+loop of crates/fri-cli/src/commands/bench.rs:15-120 around FRIEncoder::encode (encoder.rs:87-109).
+"""
+import numpy as np
+import pytest
+
+W = H = 4096
+WORLD, N_TOTAL, PER_LAUNCH = 8, 1024, 32
+
+
+def synthetic_image_dev(torch, global_index, n_bytes):
+    """Image `global_index` of the synthetic batch, generated on the device: its content depends on the global index only."""
+    g = torch.Generator(device="cuda").manual_seed(0xF7A5E000 + global_index)
+    return torch.randint(0, 256, (n_bytes,), dtype=torch.uint8, device="cuda", generator=g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rank", [0, 5])
+def test_config4_one_gpus_share(oracle, rank):
+    import torch
+
+    import frave_amd as fa
+    from frave_amd.dist import images_for_rank
+
+    mine = images_for_rank(N_TOTAL, rank, WORLD)
+    assert len(mine) == N_TOTAL // WORLD == 128 and all(i % WORLD == rank for i in mine)
+    ctx = fa.Context(0)
+    P = fa.Plan(ctx, W, H, 1)
+    s = torch.cuda.current_stream().cuda_stream
+    d_px = torch.empty((PER_LAUNCH, P.pixel_bytes), dtype=torch.uint8, device="cuda")
+    d_co = torch.empty((PER_LAUNCH, P.coef_count), dtype=torch.int32, device="cuda")
+    d_back = torch.empty(P.pixel_bytes, dtype=torch.uint8, device="cuda")
+    d_single = torch.empty(P.coef_count, dtype=torch.int32, device="cuda")
+    sampled = {mine[0], mine[37], mine[-1]} if rank == 0 else {mine[64]}
+    checked = 0
+    for launch in range(len(mine) // PER_LAUNCH):
+        ids = mine[launch * PER_LAUNCH:(launch + 1) * PER_LAUNCH]
+        for k, gi in enumerate(ids):
+            d_px[k].copy_(synthetic_image_dev(torch, gi, P.pixel_bytes))
+        P.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=s, n_images=PER_LAUNCH, pixel_stride=P.pixel_bytes, coef_stride=P.coef_count)
+        for k, gi in enumerate(ids):
+            # every image: lossless through the inverse kernel
+            P.inverse_transform_dev(d_co[k].data_ptr(), d_back.data_ptr(), stream=s)
+            assert torch.equal(d_back, d_px[k]), f"image {gi}: K3(K1(x)) != x"
+            if gi in sampled:
+                img = d_px[k].cpu().numpy()
+                Wv = oracle.Wavelet(img, H, W, 1)
+                assert np.array_equal(d_co[k].cpu().numpy().reshape(1, P.num_cells, 512), Wv.coefficients()), f"image {gi} differs from the oracle"
+                Wv.close()
+                # and the batched launch gives what a launch of its own gives
+                P.transform_quant_dev(d_px[k].data_ptr(), d_single.data_ptr(), stream=s)
+                assert torch.equal(d_single, d_co[k])
+                checked += 1
+    assert checked == len(sampled)
+    P.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_multi_device_helper_on_the_devices_present(oracle):
+    """fri_hip_multi: one host thread + ctx + plan per device; with one GPU it degenerates to the host batch path."""
+    import torch
+
+    import frave_amd as fa
+    from tests.common import gen_image
+
+    n_dev = min(torch.cuda.device_count(), 2)
+    w, h, c = 640, 360, 3
+    M = fa.Multi(list(range(n_dev)), w, h, c)
+    imgs = [gen_image("noise" if i % 2 else "smooth", w, h, c, i) for i in range(7)]
+    outs = M.transform_quant(imgs)
+    for i in (0, 3, 6):
+        Wv = oracle.Wavelet(imgs[i], h, w, c)
+        assert np.array_equal(outs[i], Wv.coefficients())
+        Wv.close()
+    M.close()
+
+
+def test_shard_functions_cover_the_batch_once():
+    """The C partition itself (host-only: no GPU): disjoint, complete, balanced; image i -> shard i mod n."""
+    import frave_amd as fa
+
+    L = fa.load_library()
+    for n_images, n_shards in [(1024, 8), (7, 2), (3, 8), (0, 4), (1000, 3)]:
+        seen = []
+        for sh in range(n_shards):
+            size = L.fri_hip_shard_size(n_images, sh, n_shards)
+            ids = [L.fri_hip_shard_image(k, sh, n_shards) for k in range(size)]
+            assert all(i % n_shards == sh and i < n_images for i in ids)
+            seen += ids
+        assert sorted(seen) == list(range(n_images))
+    assert L.fri_hip_shard_size(10, 4, 4) == 0 and L.fri_hip_shard_size(10, 0, 0) == 0

@@ -234,6 +234,27 @@ def test_full_size_4096_properties(ctx, c):
     assert np.array_equal(a[:, inter, 0] + 20, b[:, inter, 0])  # the DC carries it
 
 
+@pytest.mark.parametrize("c", [1, 3])
+def test_config2_full_size_4096_against_the_oracle(ctx, oracle, c):
+    """BASELINE config 2 at full size, bit for bit against the CPU oracle: coefficients of every channel, and bucket / prediction /
+    histogram of one channel (the last one). Half smooth, half noise, so every ANS context is populated."""
+    w = h = 4096
+    img = gen_image("noise", w, h, c, 42)
+    img[:, : w // 2] = gen_image("smooth", w // 2, h, c, 43)
+    P = _plan(ctx, w, h, c)
+    W = oracle.Wavelet(img, h, w, c)
+    co = P.transform_quant(img)
+    assert np.array_equal(co, W.coefficients())
+    W.quantize(ONES)
+    ch = c - 1
+    vp, wp = random_params(5 + c)
+    b, p, hist, oob = P.predict_histogram(co, ch, vp, wp)
+    wb, wpred, whist, woob = W.predict(ch, vp, wp)
+    assert np.array_equal(b, wb) and np.array_equal(p, wpred) and np.array_equal(hist, whist) and oob == woob
+    assert int(hist.sum()) + oob == P.num_some
+    W.close()
+
+
 def test_config3_batch_of_1080p_frames(ctx, oracle):
     """BASELINE config 3: 256 x 1920x1080 frames through ONE plan. All 256 go through the device batch entry point (one
     launch, grid.y = images); a sample is checked against the oracle, every frame by the lossless round trip; a handful

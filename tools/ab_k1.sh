@@ -1,4 +1,5 @@
 #!/bin/bash
+export FRI_HIP_TUNING=1  # the library reads its tuning knobs from the environment only with this opt-in
 # A/B of two builds of libfri_hip.so on one GPU box, interleaved so that clock / box effects hit both alike.
 # usage: tools/ab_k1.sh <other-library.so> [rounds]     (the in-tree build is "new")
 OTHER=$1; N=${2:-4}

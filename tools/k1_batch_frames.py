@@ -1,5 +1,6 @@
 """K1 over a batch of 1920x1080 frames in one launch (BASELINE config 3). GPU only. usage: k1_batch_frames.py [C] [n_frames]"""
 import os
+os.environ.setdefault("FRI_HIP_TUNING", "1")  # opt in to the library's tuning knobs (ablations / trace need `make -C frave_amd/csrc tuning` + FRI_HIP_LIBRARY)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,7 @@
 """Time K3 (inverse transform) at 4096x4096, optionally under the timing-only ablation flags. GPU only.
 usage: python tools/k3_time.py [C] [ablate,ablate,...]"""
 import os
+os.environ.setdefault("FRI_HIP_TUNING", "1")  # opt in to the library's tuning knobs (ablations / trace need `make -C frave_amd/csrc tuning` + FRI_HIP_LIBRARY)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

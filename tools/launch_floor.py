@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("FRI_HIP_TUNING", "1")  # opt in to the library's tuning knobs (ablations / trace need `make -C frave_amd/csrc tuning` + FRI_HIP_LIBRARY)
 import torch, time
 x = torch.zeros(64, device="cuda")
 s = torch.cuda.current_stream()

@@ -1,4 +1,7 @@
 """Summarise rocprofv3 --pmc CSV output: mean counter value per dispatch for kernels matching a substring."""
+import os
+os.environ.setdefault("FRI_HIP_TUNING", "1")  # opt in to the library's tuning knobs (ablations / trace need `make -C frave_amd/csrc tuning` + FRI_HIP_LIBRARY)
+
 import csv
 import glob
 import sys

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FRI_HIP_TUNING=1  # the library reads its tuning knobs from the environment only with this opt-in
 # usage: tools/prof_pmc.sh <outdir-under-gpurun_out> <python script + args...>
 # Collects PMC counters in separate passes (no trace domains mixed in), CSV output.
 set -u

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FRI_HIP_TUNING=1  # the library reads its tuning knobs from the environment only with this opt-in
 # Runs on the GPU box: bench.py under rocprofv3 (kernel trace + stats), then PMC passes for HBM traffic of K1.
 # usage: tools/profile_bench.sh <tag>   -> gpurun_out/<tag>/...
 set -u

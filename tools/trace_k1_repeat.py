@@ -1,5 +1,6 @@
 """Are K1's slow tile iterations the same ones from launch to launch? (instrumented build) GPU only."""
 import os
+os.environ.setdefault("FRI_HIP_TUNING", "1")  # opt in to the library's tuning knobs (ablations / trace need `make -C frave_amd/csrc tuning` + FRI_HIP_LIBRARY)
 import sys
 
 os.environ["FRI_HIP_TRACE"] = "1"

@@ -1,5 +1,6 @@
 """Per-workgroup timeline of the pipelined K2 at 4096x4096 (instrumented build: make -C frave_amd/csrc trace). GPU only."""
 import os
+os.environ.setdefault("FRI_HIP_TUNING", "1")  # opt in to the library's tuning knobs (ablations / trace need `make -C frave_amd/csrc tuning` + FRI_HIP_LIBRARY)
 import sys
 
 os.environ["FRI_HIP_TRACE"] = "1"

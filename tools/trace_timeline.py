@@ -1,6 +1,7 @@
 """Per-workgroup timeline of K1 (forward) or K3 (inverse) at 4096x4096 from the diagnostic trace. GPU only.
 usage: FRI_HIP_TRACE=1 python tools/trace_timeline.py [k1|k3] [C]"""
 import os
+os.environ.setdefault("FRI_HIP_TUNING", "1")  # opt in to the library's tuning knobs (ablations / trace need `make -C frave_amd/csrc tuning` + FRI_HIP_LIBRARY)
 import sys
 
 os.environ["FRI_HIP_TRACE"] = "1"
