@@ -87,7 +87,7 @@ def cpu_baseline(seconds_budget=12.0):
     # has touched the GPU (main() calls this first). An oracle instance of a 4096^2 plane holds ~2.5 GB, hence the cap.
     import multiprocessing as mp
 
-    workers = max(1, min(usable, 32))
+    workers = max(1, min(usable, 16))  # a one-GPU box's CPU share is 16 cores, whatever the host shows
     rounds = max(1, min(3, int(seconds_budget / 2 / max(per_image * 1.5, 1e-3))))
 
     def work(k):

@@ -148,6 +148,7 @@ int acquire_acc(fri_hip_plan *p, hipStream_t stream) {
         HIP_TRY(c, hipDeviceSynchronize());
         HIP_TRY(c, hipMemset(p->dev.pred_acc, 0, (size_t)kPredAccRing * kPredAccWords * sizeof(uint32_t)));
         HIP_TRY(c, hipMemset(p->dev.fit_acc, 0, (size_t)kPredAccRing * kFitAccWords * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(p->dev.inexact, 0, 2 * sizeof(uint32_t)));
         p->acc_dirty = false;
     }
     for (uint32_t i = 0; i < kPredAccRing; i++)
@@ -328,9 +329,13 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         std::vector<uint16_t> tab(&st.nbr_table[0][0], &st.nbr_table[0][0] + kCell * 6);
         std::vector<uint32_t> pred_off((size_t)kCell * 4);
         build_pred_offsets(tab.data(), pred_off.data());
+        std::vector<uint32_t> gather_off((size_t)kCell * 4);
+        std::vector<uint16_t> pair_pos(256), heap_of_pos(kCell);
+        build_gather_tables(tab.data(), gather_off.data(), pair_pos.data(), heap_of_pos.data());
         if ((rc = upload(p, g.tiles, d.tiles)) || (rc = upload(p, g.tile_cells, d.tile_cells)) || (rc = upload(p, g.tile_meta, d.tile_meta)) || (rc = upload(p, g.wg_tiles, d.wg_tiles)) || (rc = upload(p, g.wg_tiles_batch, d.wg_tiles_batch)) || (rc = upload(p, g.centers, d.centers)) ||
             (rc = upload(p, g.interior, d.interior)) || (rc = upload(p, g.valid_mask, d.valid_mask)) ||
-            (rc = upload(p, g.nbr_cells, d.nbr_cells)) || (rc = upload(p, g.pred_slots, d.pred_slots)) || (rc = upload(p, tab, d.nbr_table)) || (rc = upload(p, pred_off, d.pred_off))) {
+            (rc = upload(p, g.nbr_cells, d.nbr_cells)) || (rc = upload(p, g.pred_slots, d.pred_slots)) || (rc = upload(p, tab, d.nbr_table)) || (rc = upload(p, pred_off, d.pred_off)) ||
+            (rc = upload(p, gather_off, d.gather_off)) || (rc = upload(p, pair_pos, d.pair_pos)) || (rc = upload(p, heap_of_pos, d.heap_of_pos))) {
             fri_hip_plan_destroy(p);
             return rc;
         }
@@ -371,6 +376,15 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             d.pred_acc = static_cast<uint32_t *>(acc);
         }
         {
+            void *f = nullptr;
+            if (hipMalloc(&f, 2 * sizeof(uint32_t)) != hipSuccess || hipMemset(f, 0, 2 * sizeof(uint32_t)) != hipSuccess) {
+                fri_hip_plan_destroy(p);
+                return FRI_HIP_ERR_HIP;
+            }
+            p->owned.push_back(f);
+            d.inexact = static_cast<uint32_t *>(f);
+        }
+        {
             const size_t bytes = (size_t)kPredAccRing * kFitAccWords * sizeof(unsigned long long);
             void *acc = nullptr;
             if (hipMalloc(&acc, bytes) != hipSuccess || hipMemset(acc, 0, bytes) != hipSuccess) {
@@ -380,9 +394,10 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             p->owned.push_back(acc);
             d.fit_acc = static_cast<unsigned long long *>(acc);
         }
-        d.k2_single_buffered = env_int("FRI_HIP_K2_V1") > 0;
+        d.k2_previous = env_int("FRI_HIP_K2_PREVIOUS") > 0;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
+        d.k2_ablate = env_int("FRI_HIP_K2_ABLATE");
         if (const char *e = env_str("FRI_HIP_K1_BATCH_SHARES")) d.k1_batch_shares = std::atoi(e) != 0;
         d.k3_ablate = env_int("FRI_HIP_K3_ABLATE");
         d.k3_scan = env_int("FRI_HIP_K3_SCAN") > 0;
@@ -631,7 +646,7 @@ int fri_hip_predict_histogram_dev(fri_hip_plan *p, const int32_t *d_coefs, uint3
     const int32_t *plane = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
     const int acc = acquire_acc(p, (hipStream_t)stream);
     if (acc < 0) return acc;
-    if (hipError_t e = launch_predict_histogram(p->dev, (uint32_t)acc, plane, pp, d_bucket, d_prediction, d_hist, (unsigned long long *)d_n_out_of_alphabet, (hipStream_t)stream)) {
+    if (hipError_t e = launch_predict_histogram(p->dev, (uint32_t)acc, plane, pp, d_bucket, d_prediction, d_hist, (unsigned long long *)d_n_out_of_alphabet, false, (hipStream_t)stream)) {
         p->acc_dirty = true;
         return fail_hip(p->ctx, e, "launch_predict_histogram");
     }

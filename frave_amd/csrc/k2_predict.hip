@@ -42,7 +42,13 @@ struct PredArgs {
     const int32_t *coefs;      // one channel plane [F][512]
     const int32_t *pred_slots; // [n_tiles][kPredSlots]
     const uint16_t *nbr_table; // [512][6]
-    const uint32_t *pred_off;  // [512][4] packed neighbour halfword offsets of every node (build_pred_offsets)
+    const uint32_t *pred_off;  // [512][4] packed neighbour offsets of every node: halfwords from the own slot at stride 1040 for the earlier kernels
+                               // (build_pred_offsets), bytes from the own slot in the permuted 1 KiB layout for kernel3 (build_gather_tables)
+    const uint16_t *pair_pos;  // [256] dword position of halfword pair q inside a 1 KiB slot (gather_layout.inc)
+    const uint16_t *heap_of_pos; // [512] its inverse per halfword: heap index stored at halfword position i
+    uint32_t *inexact;         // plan scratch: set when a staged value does not fit the LDS image (the exact kernel then redoes the plane)
+    int32_t ablate;            // timing-only (tuning build, FRI_HIP_K2_ABLATE): 1 = no predict phase (zeros are stored), 2 = tiles after the first are not staged,
+                               // 4 = no histogram update, 8 = no bucket-table read, 16 = no gathers
     const uint8_t *interior;   // [F]
     const uint32_t *valid_mask; // [F][16]
     uint8_t *bucket;
@@ -79,13 +85,15 @@ __device__ __forceinline__ void pred_hand_over(const PredArgs &a, const uint32_t
     // all other workgroups have finished (their adds precede their tickets): plain coherent loads, all in flight together
     // (an atomic exchange per bin, one after the other, took 30-60 us), then the zeros for the next launch
     static_assert(kHistBins % 512 == 0, "unrolled by 512-thread strides");
+    // (a plane kernel3 could not represent - a.inexact raised - hands over an all-zero histogram: the exact kernel behind it adds the real one)
+    const bool inexact = a.inexact && __hip_atomic_load(a.inexact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     if (n_threads == 1024) {
         uint32_t v[kHistBins / 1024];
 #pragma unroll
         for (int k = 0; k < kHistBins / 1024; k++) v[k] = __hip_atomic_load(a.acc + tid + 1024 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < kHistBins / 1024; k++) {
-            a.hist[tid + 1024 * k] = v[k];
+            a.hist[tid + 1024 * k] = inexact ? 0u : v[k];
             __hip_atomic_store(a.acc + tid + 1024 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
@@ -99,121 +107,10 @@ __device__ __forceinline__ void pred_hand_over(const PredArgs &a, const uint32_t
         }
     }
     if (tid == 0) {
-        *a.n_oob = __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(a.acc + kAccOob), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long oob = __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(a.acc + kAccOob), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *a.n_oob = inexact ? 0ull : oob;
         __hip_atomic_store(a.acc + kAccTicket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-// One node of the gather/predict/histogram loop. P_HI = p >> 6 is compile time, so the parameter group
-// (prediction.rs:165-179: level 8 -> 0, level 7 -> 1, levels 1..6 -> 2) is too and the parameters stay in SGPRs.
-template <int I>
-__device__ __forceinline__ void predict_node(const uint8_t *own, int lane, uint32_t o01, uint32_t o23, uint32_t o45, bool some, const PredictParams &pp,
-                                             uint32_t *s_hist, uint8_t *bucket_dst, int32_t *pred_dst) {
-    constexpr int g = I >= 4 ? 0 : I >= 2 ? 1 : 2;
-    const float *wp = pp.width[g], *vp = pp.value[g];
-    const int value = *reinterpret_cast<const short *>(own + 2 * (lane + 64 * I));
-    // neighbour halfword offsets relative to the own slot, two per register
-    const int o[6] = {(int)(short)(o01 & 0xFFFFu), (int)o01 >> 16, (int)(short)(o23 & 0xFFFFu), (int)o23 >> 16, (int)(short)(o45 & 0xFFFFu), (int)o45 >> 16};
-    float f[6];
-    int v[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        v[k] = *reinterpret_cast<const short *>(own + 2 * o[k]);
-        f[k] = (float)v[k];
-    }
-    // get_hf_context_bucket, prediction.rs:165-206: f32, left to right, one rounding per op. The reference takes |a - b|
-    // on i32 and converts; for these magnitudes |f32(a) - f32(b)| is the same exact value, and the absolute value rides
-    // on the multiply as a source modifier.
-    float width = wp[0];
-    width = __fadd_rn(width, __fmul_rn(wp[1], fabsf(__fsub_rn(f[0], f[3]))));
-    width = __fadd_rn(width, __fmul_rn(wp[2], fabsf(__fsub_rn(f[1], f[2]))));
-    width = __fadd_rn(width, __fmul_rn(wp[3], fabsf(__fsub_rn(f[4], f[5]))));
-    width = __fadd_rn(width, __fmul_rn(wp[4], fabsf(__fsub_rn(f[1], f[5]))));
-    width = __fadd_rn(width, __fmul_rn(wp[5], fabsf(__fsub_rn(f[2], f[4]))));
-    uint32_t bucket = assign_bucket(width);
-    float pf = __fmul_rn(f[0], vp[0]);
-    pf = __fadd_rn(pf, __fmul_rn(f[1], vp[1]));
-    pf = __fadd_rn(pf, __fmul_rn(f[2], vp[2]));
-    pf = __fadd_rn(pf, __fmul_rn(f[3], vp[3]));
-    pf = __fadd_rn(pf, __fmul_rn(f[4], vp[4]));
-    pf = __fadd_rn(pf, __fmul_rn(f[5], vp[5]));
-    int prediction = f32_as_i32(pf);
-    if (I == 0) { // heap index 0 (DC) and 1 (root) live in lanes 0, 1: get_lf_context_bucket, prediction.rs:134-144
-        const uint32_t w = (uint32_t)iabs_w(sub_w(v[0], v[2]));
-        const int mx = max(v[0], v[2]), mn = min(v[0], v[2]);
-        const int lf_pred = v[1] >= mx ? mx : v[1] <= mn ? mn : sub_w(add_w(v[0], v[2]), v[1]);
-        const bool lf = lane < 2;
-        bucket = lf ? bucket_of_rt(w) : bucket;
-        prediction = lf ? lf_pred : prediction;
-    }
-    // an out-of-alphabet symbol (the reference would panic, entropy_coding.rs:99) goes to the counter bin behind the 10 x 1024 table
-    const uint32_t sym = pack_signed(sub_w(value, prediction));
-    const uint32_t bin = sym < 1024u ? bucket * 1024u + sym : (uint32_t)kHistBins;
-    if (some) atomicAdd(&s_hist[bin], 1u); // bump_freq, entropy_coding.rs:98-100. None nodes are masked off, not sent to a common trash
-                                           // bin: 64 lanes adding to one LDS address take ~0.7 us per instruction
-    // a None node is never written by the reference and stays (0, 0) (wavelet_transform.rs:60-64)
-    if (bucket_dst) bucket_dst[64 * I] = (uint8_t)(some ? bucket : 0u);
-    if (pred_dst) pred_dst[64 * I] = some ? prediction : 0;
-}
-
-// K2. Persistent workgroups (2 per CU), each walks tiles = 4 x 4 blocks of cells in lattice coordinates. Per tile the 36
-// cells of the block plus its halo ring are staged into LDS as int16 (every coefficient fits; None and missing cells are
-// stored as 0, which is what the reference's unwrap_or(0) yields), so the 6-neighbour gather of
-// ContextModeler::get_neighbour_values (context_modeling.rs:25-77) is an LDS gather: the neighbour of node p sits at
-// (own slot + slot delta) * kSlotStride + 2 * heap, and both are image independent -- each lane keeps the 48 offsets of
-// its 8 nodes in registers (two per VGPR) for the whole kernel. Lane L owns nodes L, L + 64, ..., L + 448 of a cell:
-// neighbouring lanes touch neighbouring halfwords (no structural bank conflict).
-__global__ void __launch_bounds__(kPredThreads, 4) predict_histogram_kernel(const PredArgs a) {
-    __shared__ uint32_t s_hist[kHistBins + 2]; // + out-of-alphabet counter + trash bin
-    __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
-    __shared__ int32_t s_slot_cell[kPredSlots];
-    __shared__ uint32_t s_flag;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < kHistBins + 2; i += kPredThreads) s_hist[i] = 0;
-
-    uint32_t off[8][3]; // neighbour halfword offsets relative to the own slot, loop invariant
-#pragma unroll
-    for (int i = 0; i < 8; i++) { // precomputed at plan creation (build_pred_offsets): 8 loads, no arithmetic
-        const u32x4 o = reinterpret_cast<const u32x4 *>(a.pred_off)[lane + 64 * i];
-        off[i][0] = o.x, off[i][1] = o.y, off[i][2] = o.z;
-    }
-
-    const PredTileWalk walk(a.n_tiles);
-    for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step) {
-        __syncthreads(); // everyone is done with the previous tile's LDS image (and the histogram is zeroed on the first pass)
-        if (tid < kPredSlots) s_slot_cell[tid] = pred_slot_cell(a.pred_slots[(size_t)tile * kPredSlots + tid]);
-        __syncthreads();
-        pred_stage_tile(a.coefs, s_slot_cell, s_cells, lane, wave, &s_hist[kHistBins]);
-        __syncthreads();
-
-        for (int r = wave; r < kPredBlock * kPredBlock; r += kPredWaves) { // two block cells per wave
-            const int slot = (1 + r / kPredBlock) * kPredSide + 1 + (r % kPredBlock);
-            const int cell = s_slot_cell[slot];
-            if (cell < 0) continue;
-            const uint8_t *own = s_cells + slot * kSlotStride;
-            // Some/None of this lane's 8 nodes: node lane + 64 i is bit (lane & 31) of mask word 2 i + (lane >> 5)
-            uint32_t some_bits = 0xFFu;
-            if (__builtin_amdgcn_readfirstlane((int)a.interior[cell]) == 0) { // wave-uniform: boundary cell
-                some_bits = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) some_bits |= ((a.valid_mask[(size_t)cell * 16 + 2 * i + (lane >> 5)] >> (lane & 31)) & 1u) << i;
-            }
-            const size_t base = (size_t)cell * kCell + lane;
-            uint8_t *bd = a.bucket ? a.bucket + base : nullptr;
-            int32_t *pd = a.prediction ? a.prediction + base : nullptr;
-            predict_node<0>(own, lane, off[0][0], off[0][1], off[0][2], some_bits & 1u, a.pp, s_hist, bd, pd);
-            predict_node<1>(own, lane, off[1][0], off[1][1], off[1][2], some_bits & 2u, a.pp, s_hist, bd, pd);
-            predict_node<2>(own, lane, off[2][0], off[2][1], off[2][2], some_bits & 4u, a.pp, s_hist, bd, pd);
-            predict_node<3>(own, lane, off[3][0], off[3][1], off[3][2], some_bits & 8u, a.pp, s_hist, bd, pd);
-            predict_node<4>(own, lane, off[4][0], off[4][1], off[4][2], some_bits & 16u, a.pp, s_hist, bd, pd);
-            predict_node<5>(own, lane, off[5][0], off[5][1], off[5][2], some_bits & 32u, a.pp, s_hist, bd, pd);
-            predict_node<6>(own, lane, off[6][0], off[6][1], off[6][2], some_bits & 64u, a.pp, s_hist, bd, pd);
-            predict_node<7>(own, lane, off[7][0], off[7][1], off[7][2], some_bits & 128u, a.pp, s_hist, bd, pd);
-        }
-    }
-    __syncthreads();
-    pred_hand_over(a, s_hist, &s_flag, tid, kPredThreads);
 }
 
 // K2, pipelined form. One 1024-thread workgroup per CU (16 waves = the 16 block cells of a tile), two LDS cell images:
@@ -455,6 +352,542 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K2, third form: the kernel the product launches. What the counters and microbenchmarks of round 2 said about the pipelined
+// kernel above (tools/micro/valu_rate.hip, tools/lds_layout_search.py, profiles/r01_k2_pmc_summary.txt):
+//  * a random 16-bit LDS gather costs ~7 LDS cycles per wave-instruction (32-lane groups on 32 banks), the structured gathers
+//    of this kernel 3.7 in heap order - against 2 when conflict-free - and the LDS pipe was as busy as the vector ALU;
+//  * v_cvt_f32_i32 and every integer instruction hold the SIMD twice as long as v_mul_f32 / v_add_f32; six conversions and
+//    six address computations per node were a third of the instruction stream;
+//  * 16 store instructions per cell (8 of them one byte per lane).
+// Hence:
+//  * LDS image: 1 KiB per cell, halfword pairs permuted inside their tree level's region (gather_layout.inc, found by annealing
+//    on the static neighbour table): 108-112 LDS cycles for the 48 gathers of a cell instead of 178;
+//  * values are stored as the upper half of their f32 bit pattern (every coefficient the forward kernel produces, |v| <= 255,
+//    is exact in 8 significant bits) and gathered with ds_read_u16_d16_hi into registers whose lower half stays zero: the
+//    gather delivers f32 directly, no conversion; a tile that holds a value outside [-256, 256] takes a slow path that
+//    gathers int32 from global memory and evaluates exactly what the reference does for any i32 (prediction.rs:86-207);
+//  * the 48 LDS addresses of a lane are loop invariant (each wave owns one block slot; the two images differ by a constant
+//    that rides in the instruction's offset field, the tile loop is unrolled by two), so a gather costs no vector ALU work;
+//  * lane L owns heap nodes 4L..4L+3 and 256+4L..256+4L+3: its own values come straight from the registers of the staging
+//    loads (exact int32), and a cell leaves as 2 x dwordx4 (predictions) + 2 x dword (bucket bytes) store instructions.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kP3Threads = 1024;
+constexpr int kP3Waves = kP3Threads / 64;
+static_assert(kP3Waves == kPredBlock * kPredBlock, "one wave per block cell");
+constexpr int kP3SlotBytes = 1024;
+constexpr int kP3ZeroOff = kPredSlots * kP3SlotBytes;          // zero words behind the 36 cells: what "never a node" entries read (one per block cell of a wave, 1 KiB apart)
+constexpr int kP3ImageBytes = kP3ZeroOff + kP3SlotBytes + 64;  // 37 952
+struct P3Lds { // static LDS: every address below is a compile-time constant that folds into the DS instructions' offset fields
+    uint32_t hist[kHistBins + 4];                       // 10 x 1024 counters + the out-of-alphabet counter (+ pad)
+    uint8_t cells[2][kP3ImageBytes];                    // two images of a tile's 36 cells (+ zero words)
+    int32_t ring[3][kPredSlots];                        // slot lists of tiles i, i + 1, i + 2
+    uint16_t bkt[32];                                   // bucket_of(w) << 12
+    uint32_t masks[2][kPredSlots][16];                  // Some/None masks of the staged cells
+    uint32_t flag;
+};
+static_assert(sizeof(P3Lds) <= 160 * 1024 && kP3ImageBytes + kP3SlotBytes < 65536, "LDS budget / image + cell offset must fit a DS instruction's 16-bit offset field");
+constexpr int kP3Halo = kPredSlots - kPredBlock * kPredBlock;  // 20 halo slots: one whole cell per wave + a quarter of one of the last four
+
+// h-th halo slot of a tile (h < 20): top row, bottom row, left column, right column
+__device__ __forceinline__ int p3_halo_slot(int h) {
+    return h < 6 ? h : h < 12 ? 5 * kPredSide + (h - 6) : h < 16 ? (h - 11) * kPredSide : (h - 15) * kPredSide + 5;
+}
+
+struct P3Group { // the parameters of one layer group (prediction.rs:165-179)
+    float w[6], v[6];
+};
+__device__ __forceinline__ P3Group p3_group(const PredictParams &pp, int g) {
+    P3Group q;
+#pragma unroll
+    for (int k = 0; k < 6; k++) q.w[k] = pp.width[g][k], q.v[k] = pp.value[g][k];
+    return q;
+}
+// Six gathers of one node: f32 values straight out of the bf16-style LDS image. The destination registers' low halves are zero and
+// stay zero (d16_hi loads write bits 31:16 only). The compiler does not track these loads, so the waits are explicit: p3_issue_wait
+// starts the gathers of the NEXT node into `nxt` and waits for those of the current node in `cur` - LDS operations complete in
+// order, so lgkmcnt(6) leaves exactly the six just issued in flight while everything older has landed (an LDS operation the
+// compiler slips in behind them only makes the wait longer). Between two blocks nothing may touch the registers in flight:
+// tools/check_k2_isa.py verifies that on the generated code.
+template <int OFFSET>
+__device__ __forceinline__ void p3_issue(float (&g)[6], const uint32_t (&a)[6]) {
+    asm volatile("ds_read_u16_d16_hi %0, %6 offset:%12\n\t"
+                 "ds_read_u16_d16_hi %1, %7 offset:%12\n\t"
+                 "ds_read_u16_d16_hi %2, %8 offset:%12\n\t"
+                 "ds_read_u16_d16_hi %3, %9 offset:%12\n\t"
+                 "ds_read_u16_d16_hi %4, %10 offset:%12\n\t"
+                 "ds_read_u16_d16_hi %5, %11 offset:%12"
+                 : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "n"(OFFSET));
+}
+template <int OFFSET>
+__device__ __forceinline__ void p3_issue_wait(float (&nxt)[6], const uint32_t (&a)[6], float (&cur)[6]) {
+    asm volatile("ds_read_u16_d16_hi %0, %12 offset:%18\n\t"
+                 "ds_read_u16_d16_hi %1, %13 offset:%18\n\t"
+                 "ds_read_u16_d16_hi %2, %14 offset:%18\n\t"
+                 "ds_read_u16_d16_hi %3, %15 offset:%18\n\t"
+                 "ds_read_u16_d16_hi %4, %16 offset:%18\n\t"
+                 "ds_read_u16_d16_hi %5, %17 offset:%18\n\t"
+                 "s_waitcnt lgkmcnt(6)"
+                 : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]), "+v"(nxt[5]), "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]),
+                   "+v"(cur[5])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "n"(OFFSET));
+}
+__device__ __forceinline__ void p3_wait(float (&cur)[6]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]));
+}
+
+// get_hf_context_bucket (prediction.rs:151-207) on f32 neighbour values: left to right, one rounding per operation. The reference
+// takes |a - b| on i32 and converts; for |a|, |b| <= 256 the difference of the two floats is the same exact value, and the
+// absolute value rides on the multiply as a source modifier.
+__device__ __forceinline__ void p3_node_math(const float (&f)[6], const P3Group &q, float &width, float &pf) {
+    width = q.w[0];
+    width = __fadd_rn(width, __fmul_rn(q.w[1], fabsf(__fsub_rn(f[0], f[3]))));
+    width = __fadd_rn(width, __fmul_rn(q.w[2], fabsf(__fsub_rn(f[1], f[2]))));
+    width = __fadd_rn(width, __fmul_rn(q.w[3], fabsf(__fsub_rn(f[4], f[5]))));
+    width = __fadd_rn(width, __fmul_rn(q.w[4], fabsf(__fsub_rn(f[1], f[5]))));
+    width = __fadd_rn(width, __fmul_rn(q.w[5], fabsf(__fsub_rn(f[2], f[4]))));
+    pf = __fmul_rn(f[0], q.v[0]);
+    pf = __fadd_rn(pf, __fmul_rn(f[1], q.v[1]));
+    pf = __fadd_rn(pf, __fmul_rn(f[2], q.v[2]));
+    pf = __fadd_rn(pf, __fmul_rn(f[3], q.v[3]));
+    pf = __fadd_rn(pf, __fmul_rn(f[4], q.v[4]));
+    pf = __fadd_rn(pf, __fmul_rn(f[5], q.v[5]));
+}
+
+// get_lf_context_bucket (prediction.rs:134-144); on wave-uniform values this is scalar ALU work
+__device__ __forceinline__ void p3_lf(int v0, int v1, int v2, uint32_t &b12, int &prediction) {
+    const uint32_t w = (uint32_t)iabs_w(sub_w(v0, v2));
+    const int mx = max(v0, v2), mn = min(v0, v2);
+    prediction = v1 >= mx ? mx : v1 <= mn ? mn : sub_w(add_w(v0, v2), v1);
+    b12 = bucket_of_rt(w) << 12;
+}
+
+// The heap node behind node slot n (0..3) of a lane. Waves of role 1 own level 8: 256 + 4 lane + n. Waves of role 0 own levels 0..7 as
+// 2 lane, 2 lane + 1 (levels 0..6) and 128 + 2 lane, 128 + 2 lane + 1 (level 7): every instruction then works on ONE parameter group
+// (prediction.rs:165-179), so the parameters stay in scalar registers for both roles.
+template <int ROLE>
+__device__ __forceinline__ int p3_node_of(int lane, int n) {
+    return ROLE ? 256 + 4 * lane + n : 128 * (n >> 1) + 2 * lane + (n & 1);
+}
+
+// Four nodes of one of the wave's two block cells (CELL = 0, 1: neighbouring slots, 1 KiB apart - the same address registers serve
+// both, the distance rides in the offset field) out of LDS image IMG. Role 1 leaves as one dwordx4 + one dword store, role 0 as two
+// dwordx2 + two short stores.
+template <int IMG, int ROLE, int CELL, bool INTERIOR>
+__device__ __forceinline__ void p3_half(const uint32_t (&addr)[4][6], float (&ga)[6], float (&gb)[6], const int (&own)[2][4], const PredictParams &pp, uint32_t some4, int lane,
+                                        uint32_t *s_hist, const uint16_t *s_bkt, uint8_t *bd, int32_t *pd, int ablate) {
+    constexpr int kOff = IMG * kP3ImageBytes + CELL * kP3SlotBytes;
+    uint32_t b12[4];
+    int pred[4];
+    if (!(ablate & 16)) p3_issue<kOff>(ga, addr[0]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        // the next node's gathers fly while this node is evaluated; the two register sets alternate
+        float(&g)[6] = (j & 1) ? gb : ga;
+        float(&gn)[6] = (j & 1) ? ga : gb;
+        if (ablate & 16) { // timing only: no gathers
+        } else if (j < 3)
+            p3_issue_wait<kOff>(gn, addr[j + 1], g);
+        else
+            p3_wait(g);
+        const P3Group q = p3_group(pp, ROLE ? 0 : j < 2 ? 2 : 1); // uniform: scalar registers
+        float width, pf;
+        p3_node_math(g, q, width, pf);
+        uint32_t b = (ablate & 8) ? (f32_as_u32(width) & 7u) << 12 : s_bkt[min(f32_as_u32(width), 31u)]; // assign_bucket (prediction.rs:55-68) as a 32-entry table of bucket << 12
+        int prediction = f32_as_i32(pf);
+        if (ROLE == 0 && j < 2) { // heap index 0 (DC) and 1 (root) sit in lane 0: the LF predictor, evaluated on the scalar unit
+            uint32_t lb;
+            int lp;
+            p3_lf(__builtin_amdgcn_readfirstlane(f32_as_i32(g[0])), __builtin_amdgcn_readfirstlane(f32_as_i32(g[1])), __builtin_amdgcn_readfirstlane(f32_as_i32(g[2])), lb, lp);
+            b = lane == 0 ? lb : b;
+            prediction = lane == 0 ? lp : prediction;
+        }
+        const uint32_t sym = pack_signed(sub_w(own[CELL][j], prediction));
+        uint32_t bin = b + (sym << 2); // byte offset of the counter in the 10 x 1024 table
+        if (__builtin_expect(__any(sym >= 1024u), 0)) bin = sym < 1024u ? bin : (uint32_t)kHistBins * 4u; // out of alphabet (entropy_coding.rs:99 would panic): counted apart
+        const bool some = INTERIOR || ((some4 >> j) & 1u);
+        if (some && !(ablate & 4)) atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(s_hist) + bin), 1u); // bump_freq, entropy_coding.rs:98-100
+        if (ablate & 4) prediction ^= (int)bin; // (timing only: keeps the bin arithmetic alive)
+        // a None node is not counted and stays (0, 0) in the outputs (wavelet_transform.rs:60-64)
+        pred[j] = some ? prediction : 0;
+        b12[j] = some ? b : 0u;
+    }
+    // bucket << 12 in each: byte 1 holds bucket << 4; collect the byte-1s, then one shift moves all the nibbles down.
+    // Wave-uniform bases + a 32-bit lane offset: the stores address as saddr + voffset, no 64-bit pointer arithmetic per cell.
+    if (ROLE) {
+        const uint32_t lo = __builtin_amdgcn_perm(b12[1], b12[0], 0x0C0C0501u), hi = __builtin_amdgcn_perm(b12[3], b12[2], 0x05010C0Cu);
+        __builtin_nontemporal_store(i32x4{pred[0], pred[1], pred[2], pred[3]}, reinterpret_cast<i32x4 *>(pd + 256) + lane);
+        __builtin_nontemporal_store((lo | hi) >> 4, reinterpret_cast<uint32_t *>(bd + 256) + lane);
+    } else {
+        const uint32_t lo = __builtin_amdgcn_perm(b12[1], b12[0], 0x0C0C0501u) >> 4, hi = __builtin_amdgcn_perm(b12[3], b12[2], 0x0C0C0501u) >> 4;
+        __builtin_nontemporal_store(i32x2{pred[0], pred[1]}, reinterpret_cast<i32x2 *>(pd) + lane);
+        __builtin_nontemporal_store((uint16_t)lo, reinterpret_cast<uint16_t *>(bd) + lane);
+        __builtin_nontemporal_store(i32x2{pred[2], pred[3]}, reinterpret_cast<i32x2 *>(pd + 128) + lane);
+        __builtin_nontemporal_store((uint16_t)hi, reinterpret_cast<uint16_t *>(bd + 128) + lane);
+    }
+}
+
+// The same outputs the way the reference computes them for ANY int32 input (prediction.rs:86-207, context_modeling.rs:25-77): one
+// thread per node, neighbour values gathered from global memory as int32 through the static neighbour table and the cells' neighbour
+// lists, |a - b| in wrapping i32 before the conversion. kernel3's LDS image holds magnitudes up to 256 only (everything the forward
+// kernel produces); when it meets a larger value it raises the plan's `inexact` flag, its hand-over then writes an all-zero histogram,
+// and this kernel - enqueued behind it by the entry points that take coefficients of unknown origin - redoes the plane. With the flag
+// down it returns at once.
+struct ExactArgs {
+    const int32_t *coefs;      // one channel plane [F][512]
+    const uint16_t *nbr_table; // [512][6]
+    const int32_t *nbr_cells;  // [F][kNbr]
+    const uint8_t *interior;   // [F]
+    const uint32_t *valid_mask; // [F][16]
+    uint8_t *bucket;
+    int32_t *prediction;
+    uint32_t *hist;
+    unsigned long long *n_oob;
+    uint32_t *inexact; // [0] flag, [1] ticket
+    uint32_t F;
+    PredictParams pp;
+};
+__global__ void __launch_bounds__(kCell) exact_predict_kernel(const ExactArgs a) {
+    __shared__ uint32_t s_go;
+    if (threadIdx.x == 0) s_go = __hip_atomic_load(a.inexact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_go == 0) return;
+    const int p = threadIdx.x;
+    for (uint32_t cell = blockIdx.x; cell < a.F; cell += gridDim.x) {
+        int v[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const uint32_t e = a.nbr_table[p * 6 + k];
+            v[k] = 0;
+            if (!(e & 0x8000u)) { // else: the position is never a node of that level, the reference finds nothing and reads 0
+                const int c = a.nbr_cells[(size_t)cell * kNbr + ((e >> 9) & 7u)];
+                if (c >= 0) {
+                    const int x = a.coefs[(size_t)c * kCell + (e & 511u)];
+                    v[k] = x == kNone ? 0 : x; // unwrap_or(0)
+                }
+            }
+        }
+        uint32_t bucket;
+        int prediction;
+        if (p < 2) { // get_lf_context_bucket, prediction.rs:134-144
+            const uint32_t w = (uint32_t)iabs_w(sub_w(v[0], v[2]));
+            const int mx = max(v[0], v[2]), mn = min(v[0], v[2]);
+            prediction = v[1] >= mx ? mx : v[1] <= mn ? mn : sub_w(add_w(v[0], v[2]), v[1]);
+            bucket = bucket_of_rt(w);
+        } else { // get_hf_context_bucket, prediction.rs:165-206
+            const int g = p >= 256 ? 0 : p >= 128 ? 1 : 2;
+            const float *wp = a.pp.width[g], *vp = a.pp.value[g];
+            float width = wp[0];
+            width = __fadd_rn(width, __fmul_rn(wp[1], (float)iabs_w(sub_w(v[0], v[3]))));
+            width = __fadd_rn(width, __fmul_rn(wp[2], (float)iabs_w(sub_w(v[1], v[2]))));
+            width = __fadd_rn(width, __fmul_rn(wp[3], (float)iabs_w(sub_w(v[4], v[5]))));
+            width = __fadd_rn(width, __fmul_rn(wp[4], (float)iabs_w(sub_w(v[1], v[5]))));
+            width = __fadd_rn(width, __fmul_rn(wp[5], (float)iabs_w(sub_w(v[2], v[4]))));
+            bucket = assign_bucket(width);
+            float pf = __fmul_rn((float)v[0], vp[0]);
+#pragma unroll
+            for (int k = 1; k < 6; k++) pf = __fadd_rn(pf, __fmul_rn((float)v[k], vp[k]));
+            prediction = f32_as_i32(pf);
+        }
+        const bool some = a.interior[cell] || ((a.valid_mask[(size_t)cell * 16 + (p >> 5)] >> (p & 31)) & 1u);
+        const int value = a.coefs[(size_t)cell * kCell + p];
+        const uint32_t sym = pack_signed(sub_w(value, prediction));
+        if (some) {
+            if (sym < 1024u)
+                atomicAdd(a.hist + bucket * 1024u + sym, 1u); // bump_freq, entropy_coding.rs:98-100
+            else
+                atomicAdd(a.n_oob, 1ull);
+        }
+        if (a.prediction) a.prediction[(size_t)cell * kCell + p] = some ? prediction : 0;
+        if (a.bucket) a.bucket[(size_t)cell * kCell + p] = (uint8_t)(some ? bucket : 0u);
+    }
+    // the last block to finish lowers the flag for the next launch
+    __syncthreads();
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(a.inexact + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        __hip_atomic_store(a.inexact + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.inexact, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+struct P3Staged { // one whole (halo) cell on its way from global memory to an LDS image
+    i32x4 lo, hi;  // heap nodes 4 lane .. 4 lane + 3 and 256 + 4 lane .. 256 + 4 lane + 3
+    uint32_t mask; // lanes 0..15: the cell's Some/None words
+};
+__device__ __forceinline__ void p3_issue_cell(const PredArgs &a, const int32_t *plane, int raw, int lane, P3Staged &st) {
+    const int cell = max(pred_slot_cell(raw), 0); // a slot without a cell loads cell 0 and is zeroed at the commit: no load is conditional
+    const i32x4 *src = reinterpret_cast<const i32x4 *>(plane + (size_t)cell * kCell + 4 * lane);
+    st.lo = src[0];
+    st.hi = src[64];
+    st.mask = a.valid_mask[(size_t)cell * 16 + (lane & 15)];
+}
+__device__ __forceinline__ int p3_some_or_zero(int v) { return v == kNone ? 0 : v; }
+// int32 -> upper half of the f32 pattern, two per dword; returns the larger magnitude (as f32)
+__device__ __forceinline__ float p3_pack2(int x, int y, uint32_t &d) {
+    const float f0 = (float)x, f1 = (float)y;
+    d = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, f1), __builtin_bit_cast(uint32_t, f0), 0x07060302u);
+    return __builtin_fmaxf(__builtin_fabsf(f0), __builtin_fabsf(f1));
+}
+// Four consecutive heap nodes (two pairs) of a cell into its slot at byte positions pos0, pos1. `raw` is the slot-list entry.
+// Returns the largest magnitude written.
+__device__ __forceinline__ float p3_commit4(int raw, i32x4 v, uint8_t *dst, uint32_t pos0, uint32_t pos1) {
+    if (!pred_slot_interior(raw)) { // wave-uniform and rare: a slot without a retained cell reads as 0, a boundary cell's None entries too (unwrap_or(0))
+        if (raw < 0)
+            v = i32x4{0, 0, 0, 0};
+        else
+            v = i32x4{p3_some_or_zero(v.x), p3_some_or_zero(v.y), p3_some_or_zero(v.z), p3_some_or_zero(v.w)};
+    }
+    uint32_t d0, d1;
+    const float m = __builtin_fmaxf(p3_pack2(v.x, v.y, d0), p3_pack2(v.z, v.w, d1));
+    *reinterpret_cast<uint32_t *>(dst + pos0) = d0;
+    *reinterpret_cast<uint32_t *>(dst + pos1) = d1;
+    return m;
+}
+// every integer of magnitude <= 256 is exact in the 8 significant bits of the stored half; a plane that holds anything larger is redone by
+// the exact kernel (exact_predict_kernel), which the library launches behind this one whenever the caller's coefficients are not known
+// to come from the forward kernel
+__device__ __forceinline__ void p3_check(float m, int lane, uint32_t *inexact) {
+    if (__builtin_expect(__any(m > 256.0f), 0) && lane == 0) __hip_atomic_store(inexact, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a quarter of a halo cell: heap nodes 128 quarter + 2 lane, + 1 = one pair per lane
+struct P3Quarter {
+    i32x2 v;
+    uint32_t mask;
+};
+__device__ __forceinline__ void p3_issue_quarter(const PredArgs &a, const int32_t *plane, int raw, int quarter, int lane, P3Quarter &st) {
+    const int cell = max(pred_slot_cell(raw), 0);
+    st.v = *reinterpret_cast<const i32x2 *>(plane + (size_t)cell * kCell + 128 * quarter + 2 * lane);
+    st.mask = a.valid_mask[(size_t)cell * 16 + (lane & 15)];
+}
+__device__ __forceinline__ float p3_commit_quarter(int raw, int slot, int quarter, int lane, uint32_t qpos, P3Quarter st, uint8_t *image, uint32_t *masks) {
+    if (quarter == 0 && lane < 16) masks[slot * 16 + lane] = st.mask;
+    int x = st.v.x, y = st.v.y;
+    if (!pred_slot_interior(raw)) {
+        if (raw < 0)
+            x = y = 0;
+        else
+            x = p3_some_or_zero(x), y = p3_some_or_zero(y);
+    }
+    uint32_t d;
+    const float m = p3_pack2(x, y, d);
+    *reinterpret_cast<uint32_t *>(image + slot * kP3SlotBytes + qpos) = d;
+    return m;
+}
+
+// Wave w of a workgroup works on the block cells 2 (w >> 1) and 2 (w >> 1) + 1 of a tile - neighbours in a block row, so their LDS slots
+// are 1 KiB apart - and on one half of their nodes (p3_node_of): role 1 = level 8, role 0 = levels 0..7. One set of 24 neighbour
+// addresses serves both cells.
+struct P3Lane {          // loop invariants of a lane
+    uint32_t addr[4][6]; // LDS addresses (image 0, first cell) of the six neighbours of its four nodes
+    uint32_t wpos[4];    // byte positions inside a slot of pairs 2 lane, 2 lane + 1, 128 + 2 lane, 128 + 2 lane + 1 (what a lane stages of a halo cell)
+    uint32_t opos[2];    // of the two pairs it stages of its own cells: role 1 = wpos[2], wpos[3]; role 0 = pairs lane and 64 + lane
+    uint32_t qpos;       // of its pair of the quarter cell
+};
+
+// what a wave stages of one of its own block cells: its four nodes (role 1: one dwordx4, role 0: two dwordx2)
+template <int ROLE>
+__device__ __forceinline__ i32x4 p3_load_own(const int32_t *cell_base, int lane) {
+    if (ROLE) return *reinterpret_cast<const i32x4 *>(cell_base + 256 + 4 * lane);
+    const i32x2 a = *reinterpret_cast<const i32x2 *>(cell_base + 2 * lane), b = *reinterpret_cast<const i32x2 *>(cell_base + 128 + 2 * lane);
+    return i32x4{a.x, a.y, b.x, b.y};
+}
+
+template <int IMG, int ROLE>
+__device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane, P3Lds &lds, int it, bool more, uint32_t next2_tile, int tid, int lane, int wave, int slot_a,
+                                        const P3Lane &L, float (&ga)[6], float (&gb)[6], int (&own)[2][4]) {
+    uint32_t *s_hist = lds.hist;
+    const uint16_t *s_bkt = lds.bkt;
+    const int32_t *cur_slots = lds.ring[it % 3], *nxt_slots = lds.ring[(it + 1) % 3];
+    const uint32_t *cur_masks = &lds.masks[IMG][0][0];
+    // in flight across the arithmetic below: the slot list of tile i + 2 and what this wave stages of tile i + 1 - its half of its two
+    // block cells, one halo cell, a quarter of one of the last four halo cells
+    const int32_t slot_pre = a.pred_slots[(size_t)next2_tile * kPredSlots + tid % kPredSlots];
+    const int halo_slot = p3_halo_slot(wave), quarter_slot = p3_halo_slot(kP3Waves + (wave >> 2)), quarter = wave & 3;
+    i32x4 st_own[2];
+    uint32_t st_own_mask[2];
+    P3Staged st_halo;
+    P3Quarter st_q;
+    int raw_own[2] = {-1, -1}, raw_halo = -1, raw_q = -1;
+    if (ablate_flags(a.ablate) & 2) more = false;
+    if (more) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            raw_own[c] = __builtin_amdgcn_readfirstlane(nxt_slots[slot_a + c]);
+            const int cell = max(pred_slot_cell(raw_own[c]), 0);
+            st_own[c] = p3_load_own<ROLE>(plane + (size_t)cell * kCell, lane);
+            if (ROLE == 1) st_own_mask[c] = a.valid_mask[(size_t)cell * 16 + (lane & 15)]; // the level-8 waves have registers to spare
+        }
+        raw_halo = __builtin_amdgcn_readfirstlane(nxt_slots[halo_slot]);
+        raw_q = __builtin_amdgcn_readfirstlane(nxt_slots[quarter_slot]);
+        p3_issue_cell(a, plane, raw_halo, lane, st_halo);
+        p3_issue_quarter(a, plane, raw_q, quarter, lane, st_q);
+    }
+
+    // two block cells per wave; every path issues the same number of stores per cell (a wave without a retained cell at a block slot
+    // writes zeros to its junk lines), so the commit below waits for the staging loads with a counted vmcnt and not for the stores just issued
+#define FRI_P3_CELL(C)                                                                                                                                  \
+    {                                                                                                                                                   \
+        const int raw = (ablate_flags(a.ablate) & 1) ? -1 : __builtin_amdgcn_readfirstlane(cur_slots[slot_a + C]); /* all this phase needs is in LDS or registers */ \
+        const int cell = pred_slot_cell(raw);                                                                                                           \
+        const bool has = cell >= 0;                                                                                                                     \
+        const size_t junk = ((size_t)blockIdx.x * kP3Waves + wave) * kPredJunkBytes;                                                                    \
+        uint8_t *bd = has && a.bucket ? a.bucket + (size_t)cell * kCell : a.junk + junk;                                                                \
+        int32_t *pd = has && a.prediction ? a.prediction + (size_t)cell * kCell : reinterpret_cast<int32_t *>(a.junk + junk + 512);                    \
+        if (pred_slot_interior(raw)) {                                                                                                                  \
+            p3_half<IMG, ROLE, C, true>(L.addr, ga, gb, own, a.pp, 15u, lane, s_hist, s_bkt, bd, pd, ablate_flags(a.ablate));                                                   \
+        } else if (has) { /* boundary cell: node p is bit (p & 31) of mask word p >> 5 */                                                               \
+            uint32_t some4;                                                                                                                             \
+            if (ROLE) {                                                                                                                                 \
+                some4 = (cur_masks[(slot_a + C) * 16 + 8 + (lane >> 3)] >> (4 * (lane & 7))) & 15u;                                                      \
+            } else {                                                                                                                                    \
+                const uint32_t w0 = cur_masks[(slot_a + C) * 16 + (lane >> 4)], w1 = cur_masks[(slot_a + C) * 16 + 4 + (lane >> 4)];                     \
+                some4 = ((w0 >> (2 * (lane & 15))) & 3u) | (((w1 >> (2 * (lane & 15))) & 3u) << 2);                                                      \
+            }                                                                                                                                           \
+            p3_half<IMG, ROLE, C, false>(L.addr, ga, gb, own, a.pp, some4, lane, s_hist, s_bkt, bd, pd, ablate_flags(a.ablate));                                                \
+        } else if (ROLE) {                                                                                                                              \
+            __builtin_nontemporal_store(i32x4{0, 0, 0, 0}, reinterpret_cast<i32x4 *>(pd + 256) + lane);                                                  \
+            __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t *>(bd + 256) + lane);                                                              \
+        } else {                                                                                                                                        \
+            __builtin_nontemporal_store(i32x2{0, 0}, reinterpret_cast<i32x2 *>(pd) + lane);                                                              \
+            __builtin_nontemporal_store((uint16_t)0, reinterpret_cast<uint16_t *>(bd) + lane);                                                           \
+            __builtin_nontemporal_store(i32x2{0, 0}, reinterpret_cast<i32x2 *>(pd + 128) + lane);                                                        \
+            __builtin_nontemporal_store((uint16_t)0, reinterpret_cast<uint16_t *>(bd + 128) + lane);                                                     \
+        }                                                                                                                                               \
+    }
+    FRI_P3_CELL(0)
+    FRI_P3_CELL(1)
+#undef FRI_P3_CELL
+
+    if (more) {
+        // The staged registers are consumed from here on, not earlier: left alone, the compiler hoists the copy of the next tile's own
+        // values to the top of the iteration and waits for the loads there - in front of the arithmetic they are meant to hide behind.
+        asm volatile("" : "+v"(st_own[0]), "+v"(st_own[1]), "+v"(st_halo.lo), "+v"(st_halo.hi), "+v"(st_q.v));
+        uint8_t *nxt = lds.cells[IMG ^ 1];
+        uint32_t *nxt_masks = &lds.masks[IMG ^ 1][0][0];
+        float m = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            m = __builtin_fmaxf(m, p3_commit4(raw_own[c], st_own[c], nxt + (slot_a + c) * kP3SlotBytes, L.opos[0], L.opos[1]));
+            if (ROLE == 1 && lane < 16) nxt_masks[(slot_a + c) * 16 + lane] = st_own_mask[c];
+            // the own values of the next tile stay in registers: exact int32 for the residual (a None or absent cell never reaches the histogram)
+            own[c][0] = st_own[c].x, own[c][1] = st_own[c].y, own[c][2] = st_own[c].z, own[c][3] = st_own[c].w;
+        }
+        if (lane < 16) nxt_masks[halo_slot * 16 + lane] = st_halo.mask;
+        m = __builtin_fmaxf(m, p3_commit4(raw_halo, st_halo.lo, nxt + halo_slot * kP3SlotBytes, L.wpos[0], L.wpos[1]));
+        m = __builtin_fmaxf(m, p3_commit4(raw_halo, st_halo.hi, nxt + halo_slot * kP3SlotBytes, L.wpos[2], L.wpos[3]));
+        m = __builtin_fmaxf(m, p3_commit_quarter(raw_q, quarter_slot, quarter, lane, L.qpos, st_q, nxt, nxt_masks));
+        p3_check(m, lane, a.inexact);
+    }
+    if (tid < kPredSlots) lds.ring[(it + 2) % 3][tid] = slot_pre;
+    lds_barrier();
+    trace_stamp(a.trace, blockIdx.x, 2 + it, tid);
+}
+
+template <int ROLE>
+__device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, int lane, int wave) {
+    uint8_t *s_cells = lds.cells[0];
+    int32_t *s_ring = &lds.ring[0][0];
+    uint32_t *s_masks = &lds.masks[0][0][0];
+    const int pair = wave >> 1; // block cells 2 pair, 2 pair + 1: block row pair >> 1, columns 2 (pair & 1), + 1
+    const int slot_a = (1 + (pair >> 1)) * kPredSide + 1 + 2 * (pair & 1);
+    const int32_t *plane = a.coefs;
+
+    P3Lane L;
+    const uint32_t cells_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_cells;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const u32x4 o = reinterpret_cast<const u32x4 *>(a.pred_off)[p3_node_of<ROLE>(lane, j)];
+        const uint32_t rel[3] = {o.x, o.y, o.z};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int r = (int)(short)((rel[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+            // "never a node": the image's zero words. The second cell reads them 1 KiB further on, hence 1 KiB + of zeros behind the cells.
+            L.addr[j][k] = r == 0x7FFF ? cells_lds + kP3ZeroOff : cells_lds + (uint32_t)(slot_a * kP3SlotBytes + r);
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) L.wpos[w] = 4u * a.pair_pos[2 * lane + (w & 1) + 128 * (w >> 1)];
+    L.opos[0] = ROLE ? L.wpos[2] : 4u * a.pair_pos[lane];
+    L.opos[1] = ROLE ? L.wpos[3] : 4u * a.pair_pos[64 + lane];
+    L.qpos = 4u * a.pair_pos[64 * (wave & 3) + lane];
+    float ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int own[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+
+    const PredTileWalk walk(a.n_tiles);
+    if (walk.first >= walk.end) return; // (a workgroup without a tile still takes part in the hand-over)
+    const uint32_t last = walk.first + ((walk.end - 1 - walk.first) / walk.step) * walk.step; // this workgroup's last tile
+    if (tid < kPredSlots) {
+        s_ring[tid] = a.pred_slots[(size_t)walk.first * kPredSlots + tid];
+        s_ring[kPredSlots + tid] = a.pred_slots[(size_t)min(walk.first + walk.step, last) * kPredSlots + tid];
+    }
+    __syncthreads();
+    { // tile 0 straight into image 0: everything a wave stages is requested before the first value is converted
+        const int halo_slot = p3_halo_slot(wave), quarter_slot = p3_halo_slot(kP3Waves + (wave >> 2)), quarter = wave & 3;
+        const int raw_halo = __builtin_amdgcn_readfirstlane(s_ring[halo_slot]), raw_q = __builtin_amdgcn_readfirstlane(s_ring[quarter_slot]);
+        i32x4 st_own[2];
+        uint32_t st_own_mask[2] = {0, 0};
+        int raw_own[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            raw_own[c] = __builtin_amdgcn_readfirstlane(s_ring[slot_a + c]);
+            const int cell = max(pred_slot_cell(raw_own[c]), 0);
+            st_own[c] = p3_load_own<ROLE>(plane + (size_t)cell * kCell, lane);
+            if (ROLE == 1) st_own_mask[c] = a.valid_mask[(size_t)cell * 16 + (lane & 15)];
+        }
+        P3Staged st_halo;
+        P3Quarter st_q;
+        p3_issue_cell(a, plane, raw_halo, lane, st_halo);
+        p3_issue_quarter(a, plane, raw_q, quarter, lane, st_q);
+        float m = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            m = __builtin_fmaxf(m, p3_commit4(raw_own[c], st_own[c], s_cells + (slot_a + c) * kP3SlotBytes, L.opos[0], L.opos[1]));
+            if (ROLE == 1 && lane < 16) s_masks[(slot_a + c) * 16 + lane] = st_own_mask[c];
+            own[c][0] = st_own[c].x, own[c][1] = st_own[c].y, own[c][2] = st_own[c].z, own[c][3] = st_own[c].w;
+        }
+        if (lane < 16) s_masks[halo_slot * 16 + lane] = st_halo.mask;
+        m = __builtin_fmaxf(m, p3_commit4(raw_halo, st_halo.lo, s_cells + halo_slot * kP3SlotBytes, L.wpos[0], L.wpos[1]));
+        m = __builtin_fmaxf(m, p3_commit4(raw_halo, st_halo.hi, s_cells + halo_slot * kP3SlotBytes, L.wpos[2], L.wpos[3]));
+        m = __builtin_fmaxf(m, p3_commit_quarter(raw_q, quarter_slot, quarter, lane, L.qpos, st_q, s_cells, s_masks));
+        p3_check(m, lane, a.inexact);
+    }
+    __syncthreads();
+    trace_stamp(a.trace, blockIdx.x, 1, tid);
+
+    int it = 0;
+    for (uint32_t tile = walk.first; tile < walk.end;) { // unrolled by two: the LDS image a tile lives in is a compile-time constant
+        p3_tile<0, ROLE>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own);
+        tile += walk.step, it++;
+        if (tile >= walk.end) break;
+        p3_tile<1, ROLE>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own);
+        tile += walk.step, it++;
+    }
+}
+
+__global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const PredArgs a) {
+    __shared__ __attribute__((aligned(16))) P3Lds lds;
+    uint32_t *s_hist = lds.hist;
+    uint8_t *s_cells = lds.cells[0];
+    int32_t *s_ring = &lds.ring[0][0];
+    uint16_t *s_bkt = lds.bkt;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    trace_stamp(a.trace, blockIdx.x, 0, tid);
+    for (int i = tid; i < kHistBins + 4; i += kP3Threads) s_hist[i] = 0;
+    if (tid < 32) s_bkt[tid] = (uint16_t)(bucket_of((uint32_t)tid) << 12);
+    for (int i = tid; i < 2 * (kP3ImageBytes - kP3ZeroOff) / 4; i += kP3Threads) // the zero words behind the cells of both images
+        reinterpret_cast<uint32_t *>(s_cells + (i / ((kP3ImageBytes - kP3ZeroOff) / 4)) * kP3ImageBytes + kP3ZeroOff)[i % ((kP3ImageBytes - kP3ZeroOff) / 4)] = 0;
+    if (wave & 1)
+        p3_run<1>(a, lds, tid, lane, wave);
+    else
+        p3_run<0>(a, lds, tid, lane, wave);
+    __syncthreads();
+    trace_stamp(a.trace, blockIdx.x, 13, tid);
+    pred_hand_over(a, s_hist, reinterpret_cast<uint32_t *>(s_ring), tid, kP3Threads);
+    trace_exit(a.trace, blockIdx.x, tid);
+}
+
 } // namespace
 
 void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out) {
@@ -466,8 +899,34 @@ void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out) {
     }
 }
 
+// The permuted 1 KiB cell layout of kernel3 (and of the fit kernels once they move to it): pair_pos from gather_layout.inc, its
+// inverse, and per node the six neighbour offsets in bytes from the own slot (0x7FFF = "never a node": the image's zero word).
+void build_gather_tables(const uint16_t *nbr_table, uint32_t *gather_off /* [512][4] */, uint16_t *pair_pos /* [256] */, uint16_t *heap_of_pos /* [512] */) {
+    static const uint16_t kPairPos[256] = {
+#include "gather_layout.inc"
+    };
+    for (int q = 0; q < 256; q++) {
+        pair_pos[q] = kPairPos[q];
+        heap_of_pos[2 * kPairPos[q]] = (uint16_t)(2 * q);
+        heap_of_pos[2 * kPairPos[q] + 1] = (uint16_t)(2 * q + 1);
+    }
+    for (int p = 0; p < kCell; p++) {
+        uint32_t h[6];
+        for (int k = 0; k < 6; k++) {
+            const uint32_t e = nbr_table[p * 6 + k];
+            const int slot = (e >> 9) & 7; // index into {self, +V9[0..5]} = lattice deltas (0,0),(1,0),(1,-1),(0,-1),(-1,0),(-1,1),(0,1)
+            const int da = (int)((0x0F14u >> (2 * slot)) & 3u), db = (int)((0x14F0u >> (2 * slot)) & 3u); // 2-bit fields: 0 -> 0, 1 -> +1, 3 -> -1
+            const int sa = (da & 1) - (da & 2), sb = (db & 1) - (db & 2);
+            const int heap = (int)(e & 511u);
+            const int rel = (sa * kPredSide + sb) * 1024 + 2 * (2 * kPairPos[heap >> 1] + (heap & 1));
+            h[k] = (e & 0x8000u) ? 0x7FFFu : ((uint32_t)rel & 0xFFFFu);
+        }
+        gather_off[4 * p] = h[0] | (h[1] << 16), gather_off[4 * p + 1] = h[2] | (h[3] << 16), gather_off[4 * p + 2] = h[4] | (h[5] << 16), gather_off[4 * p + 3] = 0;
+    }
+}
+
 hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t acc_slot, const int32_t *coefs_channel, const PredictParams &pp, uint8_t *bucket,
-                                    int32_t *prediction, uint32_t *hist, unsigned long long *n_oob, hipStream_t stream) {
+                                    int32_t *prediction, uint32_t *hist, unsigned long long *n_oob, bool from_forward_kernel, hipStream_t stream) {
     if (!p.pred_acc || acc_slot >= kPredAccRing) return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     PredArgs a{};
@@ -484,19 +943,40 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t acc_slot, cons
     a.n_oob = n_oob;
     a.n_tiles = p.n_pred_tiles;
     a.pp = pp;
-    if (p.k2_single_buffered || !bucket || !prediction) { // optional outputs: the single-buffered kernel skips the stores of a NULL output
-        uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
-        if (!blocks) blocks = 1;
-        hipLaunchKernelGGL(predict_histogram_kernel, dim3(blocks), dim3(kPredThreads), 0, stream, a);
-        return hipGetLastError();
-    }
     uint32_t blocks = p.n_pred_tiles < p.pred_blocks ? p.n_pred_tiles : p.pred_blocks;
     if (!blocks) blocks = 1;
     a.junk = p.junk;
     a.trace = p.trace;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(predict_histogram_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, kPred2LdsBytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(predict_histogram_kernel2, dim3(blocks), dim3(kPred2Threads), kPred2LdsBytes, stream, a);
+    if (p.k2_previous) { // FRI_HIP_TUNING=1 FRI_HIP_K2_PREVIOUS=1: the pipelined kernel of round 1 (A/B on one box); needs both outputs
+        if (!bucket || !prediction) return hipErrorInvalidValue;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(predict_histogram_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, kPred2LdsBytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(predict_histogram_kernel2, dim3(blocks), dim3(kPred2Threads), kPred2LdsBytes, stream, a);
+        return hipGetLastError();
+    }
+    a.pred_off = p.gather_off;
+    a.pair_pos = p.pair_pos;
+    a.heap_of_pos = p.heap_of_pos;
+    a.inexact = p.inexact;
+    a.ablate = p.k2_ablate;
+    hipLaunchKernelGGL(predict_histogram_kernel3, dim3(blocks), dim3(kP3Threads), 0, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess || from_forward_kernel) return e; // the forward kernel's coefficients are differences of 8-bit pixels divided by a quantiser: always representable
+    ExactArgs x{};
+    x.coefs = coefs_channel;
+    x.nbr_table = p.nbr_table;
+    x.nbr_cells = p.nbr_cells;
+    x.interior = p.interior;
+    x.valid_mask = p.valid_mask;
+    x.bucket = bucket;
+    x.prediction = prediction;
+    x.hist = hist;
+    x.n_oob = n_oob;
+    x.inexact = p.inexact;
+    x.F = p.F;
+    x.pp = pp;
+    const uint32_t xb = p.F < p.pred_blocks ? p.F : p.pred_blocks;
+    hipLaunchKernelGGL(exact_predict_kernel, dim3(xb ? xb : 1), dim3(kCell), 0, stream, x);
     return hipGetLastError();
 }
 

@@ -28,22 +28,27 @@ struct DevicePlan {
     const int32_t *nbr_cells = nullptr;   // [F][kNbr]
     const uint16_t *nbr_table = nullptr;  // [512][6]
     const uint32_t *pred_off = nullptr;   // [512][4] K2's packed LDS offsets per node, derived from nbr_table
+    const uint32_t *gather_off = nullptr; // [512][4] the same in bytes for the permuted 1 KiB cell layout (build_gather_tables)
+    const uint16_t *pair_pos = nullptr;   // [256] gather_layout.inc
+    const uint16_t *heap_of_pos = nullptr; // [512]
     const int32_t *pred_slots = nullptr;  // [n_pred_tiles][kPredSlots]
     uint32_t n_pred_tiles = 0;
     uint32_t *hist_partial = nullptr;     // [hist_blocks][10*1024] scratch for the histogram reduction
     unsigned long long *oob_partial = nullptr; // [hist_blocks]
     uint32_t hist_blocks = 0;
+    uint32_t *inexact = nullptr;          // [2] flag + ticket: K2's fast kernel met a value its LDS image cannot hold; zero between launches
     uint8_t *junk = nullptr;              // [pred_blocks][kPredJunkWaves][kPredJunkBytes]: output lines of block slots without a cell (pipelined K2)
     uint32_t *pred_acc = nullptr;         // [kPredAccRing][kPredAccWords] K2 histogram accumulators, all zero between launches
     unsigned long long *fit_acc = nullptr; // [kPredAccRing][kFitAccWords] fit-sum accumulators, all zero between launches
     uint32_t pred_blocks = 0;             // workgroups of the pipelined K2: one 1024-thread workgroup per CU
-    bool k2_single_buffered = false;      // FRI_HIP_K2_V1=1: the earlier single-buffered K2 (A/B)
+    bool k2_previous = false;             // tuning: round 1's pipelined K2 (A/B)
     uint32_t n_tiles = 0;
     uint32_t F = 0;
     int32_t width = 0, height = 0, channels = 0;
     int32_t lds_pitch = 0, lds_rows = 0, cells_per_tile = 0;
     bool k1_batch_shares = true; // FRI_HIP_K1_BATCH_SHARES=0 disables the merged shares (A/B)
     int32_t k1_ablate = 0; // timing-only ablation flags, see FwdArgs::ablate
+    int32_t k2_ablate = 0; // the same for K2, see PredArgs::ablate
     unsigned long long *trace = nullptr; // [n_wg][16] diagnostic timeline (FRI_HIP_TRACE=1), else null
     // K3's static write-out lists (null = not built: the kernel scans the rectangle)
     const InvTileLists *inv_lists = nullptr;
@@ -72,8 +77,10 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
                                       size_t coef_stride, const QMatrix &q, hipStream_t stream);
 // K2: neighbour gather + bucket/prediction + LDS histogram, then the partial-histogram reduction.
 // acc_slot < kPredAccRing selects the plan accumulator the launch hands its sums over through (one per stream, fri_hip.cpp).
+// from_forward_kernel: the coefficients are this library's forward kernel's output (magnitudes <= 255): the exact int32 kernel that
+// backs the fast one up for arbitrary arrays is not enqueued.
 hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t acc_slot, const int32_t *coefs_channel, const PredictParams &pp, uint8_t *bucket,
-                                    int32_t *prediction, uint32_t *hist, unsigned long long *n_oob, hipStream_t stream);
+                                    int32_t *prediction, uint32_t *hist, unsigned long long *n_oob, bool from_forward_kernel, hipStream_t stream);
 // Fit accumulators: mode 0 = value fit (sums_int[3][28]), mode 1 = width fit (sums_int[3][21], sums_dbl[3][6]).
 hipError_t launch_fit_accumulate(const DevicePlan &p, uint32_t acc_slot, int mode, const int32_t *coefs_channel, const PredictParams &pp, unsigned long long *sums_int,
                                  double *sums_dbl, hipStream_t stream);
@@ -82,6 +89,7 @@ hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, c
 
 // K2's per-node neighbour offsets (LDS halfword offsets relative to the own slot, two per word) from the static neighbour table
 void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out /* [512][4] */);
+void build_gather_tables(const uint16_t *nbr_table, uint32_t *gather_off /* [512][4] */, uint16_t *pair_pos /* [256] */, uint16_t *heap_of_pos /* [512] */);
 size_t fwd_lds_bytes(const DevicePlan &p);
 size_t inv_lds_bytes(const DevicePlan &p);
 // True iff the lane/leaf footprint hard-wired in the kernels equals the table derived from LITERALS.

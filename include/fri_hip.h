@@ -151,9 +151,9 @@ int fri_hip_multi_transform_quant(fri_hip_multi *m, uint32_t n_images, const uin
  * coefs is the whole [channels][F][512] array (quantised); `channel` selects the plane.
  * hist is overwritten. Symbols >= 1024 (Rust: index panic, entropy_coding.rs:99) are not
  * histogrammed; their count is returned in *n_out_of_alphabet. bucket/prediction may be NULL.
- * The kernel holds coefficients as int16 (every output of fri_hip_transform_quant fits): a Some
- * coefficient outside [-32768, 32767] is also counted in *n_out_of_alphabet, and outputs that depend
- * on it are unspecified. *n_out_of_alphabet == 0 means: every output is what libfri computes. */
+ * Any int32 coefficient array is accepted and gives what libfri computes for it (i32 gathers, f32 predictor): a fast kernel
+ * whose LDS image holds magnitudes up to 256 - all the forward transform produces - is followed by an exact int32 kernel that
+ * returns at once unless the fast one met a larger value. *n_out_of_alphabet == 0 means: libfri would have produced a stream. */
 int fri_hip_predict_histogram(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, const float value_params[3][6],
                               const float width_params[3][6], uint8_t *bucket, int32_t *prediction, uint32_t *hist,
                               uint64_t *n_out_of_alphabet);

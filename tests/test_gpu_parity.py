@@ -121,11 +121,11 @@ def test_predict_out_of_alphabet_counted_not_clamped(ctx, oracle):
     assert np.array_equal(hist, whist) and np.array_equal(b, wb) and np.array_equal(p, wpred)
 
 
-@pytest.mark.parametrize("both_outputs", [True, False])
-def test_predict_arbitrary_int16_coefficients_and_outlier_counter(ctx, oracle, both_outputs):
-    """K2 takes any coefficient array, not only K1's outputs: the whole int16 range must match the oracle; a Some value
-    outside it is counted (include/fri_hip.h) instead of being truncated silently. Both kernels: the pipelined one
-    (both outputs wanted) and the single-buffered one (an output is NULL)."""
+@pytest.mark.parametrize("want", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("span", ["int16", "int32", "few_outliers"])
+def test_predict_arbitrary_int32_coefficients(ctx, oracle, want, span):
+    """K2 takes any coefficient array, not only K1's outputs, and computes what libfri computes for it in i32 / f32 (prediction.rs:86-207):
+    the fast kernel's LDS image holds magnitudes up to 256, anything else is redone by the exact kernel behind it. Outputs may be NULL."""
     w, h, c = 300, 260, 1
     img = gen_image("noise", w, h, c, 3)
     P = _plan(ctx, w, h, c)
@@ -133,23 +133,32 @@ def test_predict_arbitrary_int16_coefficients_and_outlier_counter(ctx, oracle, b
     co = P.transform_quant(img)
     valid = co != oracle.NONE
     rng = np.random.default_rng(5)
-    rnd = rng.integers(-32768, 32768, co.shape, dtype=np.int32)
-    rnd[rng.random(co.shape) < 0.5] //= 64  # half of them small, so that many symbols stay inside the alphabet
+    if span == "int16":
+        rnd = rng.integers(-32768, 32768, co.shape, dtype=np.int32)
+        rnd[rng.random(co.shape) < 0.5] //= 64  # half of them small, so that many symbols stay inside the alphabet
+    elif span == "int32":
+        rnd = rng.integers(-(2 ** 31) + 1, 2 ** 31, co.shape, dtype=np.int64).astype(np.int32)
+        rnd[rng.random(co.shape) < 0.7] //= 2 ** 22
+    else:  # the forward kernel's output with a handful of values the fast kernel cannot represent: 257 is the first one
+        rnd = co.copy()
+        idx = np.flatnonzero(valid.reshape(-1))
+        pick = rng.choice(idx, 9, replace=False)
+        rnd.reshape(-1)[pick] = rng.choice(np.array([257, -257, 40000, -32769, 2 ** 31 - 1, -(2 ** 31) + 1], np.int32), 9)
     rnd[~valid] = oracle.NONE
     vp, wp = random_params(3)
     W.set_coefficients(rnd)
     wb, wpred, whist, woob = W.predict(0, vp, wp)
-    b, p, hist, oob = P.predict_histogram(rnd, 0, vp, wp, want_bucket=True, want_prediction=both_outputs)
-    assert np.array_equal(hist, whist) and oob == woob and np.array_equal(b, wb)
-    if both_outputs:
+    b, p, hist, oob = P.predict_histogram(rnd, 0, vp, wp, want_bucket=want[0], want_prediction=want[1])
+    assert np.array_equal(hist, whist) and oob == woob
+    if want[0]:
+        assert np.array_equal(b, wb)
+    if want[1]:
         assert np.array_equal(p, wpred)
-    # outliers: exactly these are reported on top of the symbols that are out of the alphabet anyway
-    big = rnd.copy()
-    idx = np.flatnonzero(valid.reshape(-1))
-    pick = rng.choice(idx, 37, replace=False)
-    big.reshape(-1)[pick] = rng.choice(np.array([40000, -32769, 32768, 2 ** 31 - 1, -(2 ** 31) + 1], np.int32), 37)
-    _, _, hist2, oob2 = P.predict_histogram(big, 0, vp, wp, want_bucket=True, want_prediction=both_outputs)
-    assert oob2 >= 37
+    # and the plan is back in its normal state: the forward kernel's own output next, through the fast kernel alone
+    W.set_coefficients(co)
+    wb, wpred, whist, woob = W.predict(0, vp, wp)
+    b, p, hist, oob = P.predict_histogram(co, 0, vp, wp)
+    assert np.array_equal(hist, whist) and oob == woob and np.array_equal(b, wb) and np.array_equal(p, wpred)
 
 
 @pytest.mark.parametrize("shape", [(10, 10, 3), (100, 37, 3), (512, 512, 1), (777, 333, 3), (1920, 1080, 1)])
