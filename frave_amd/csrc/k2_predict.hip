@@ -48,7 +48,7 @@ struct PredArgs {
     const uint16_t *heap_of_pos; // [512] its inverse per halfword: heap index stored at halfword position i
     uint32_t *inexact;         // plan scratch: set when a staged value does not fit the LDS image (the exact kernel then redoes the plane)
     int32_t ablate;            // timing-only (tuning build, FRI_HIP_K2_ABLATE): 1 = no predict phase (zeros are stored), 2 = tiles after the first are not staged,
-                               // 4 = no histogram update, 8 = no bucket-table read, 16 = no gathers
+                               // 4 = no histogram update, 8 = no bucket-table read, 16 = no gathers, 32 = no output stores
     const uint8_t *interior;   // [F]
     const uint32_t *valid_mask; // [F][16]
     uint8_t *bucket;
@@ -385,7 +385,7 @@ struct P3Lds { // static LDS: every address below is a compile-time constant tha
     int32_t ring[3][kPredSlots];                        // slot lists of tiles i, i + 1, i + 2
     uint16_t bkt[32];                                   // bucket_of(w) << 12
     uint32_t masks[2][kPredSlots][16];                  // Some/None masks of the staged cells
-    uint32_t flag;
+    uint32_t lf_rel[2][4];                              // the LF pass's offsets (p3_lf_pass), per heap node 0 / 1
 };
 static_assert(sizeof(P3Lds) <= 160 * 1024 && kP3ImageBytes + kP3SlotBytes < 65536, "LDS budget / image + cell offset must fit a DS instruction's 16-bit offset field");
 constexpr int kP3Halo = kPredSlots - kPredBlock * kPredBlock;  // 20 halo slots: one whole cell per wave + a quarter of one of the last four
@@ -473,13 +473,16 @@ __device__ __forceinline__ int p3_node_of(int lane, int n) {
 }
 
 // Four nodes of one of the wave's two block cells (CELL = 0, 1: neighbouring slots, 1 KiB apart - the same address registers serve
-// both, the distance rides in the offset field) out of LDS image IMG. Role 1 leaves as one dwordx4 + one dword store, role 0 as two
-// dwordx2 + two short stores.
-template <int IMG, int ROLE, int CELL, bool INTERIOR>
-__device__ __forceinline__ void p3_half(const uint32_t (&addr)[4][6], float (&ga)[6], float (&gb)[6], const int (&own)[2][4], const PredictParams &pp, uint32_t some4, int lane,
-                                        uint32_t *s_hist, const uint16_t *s_bkt, uint8_t *bd, int32_t *pd, int ablate) {
+// both, the distance rides in the offset field) out of LDS image IMG. One straight-line body for every kind of cell: interior,
+// boundary (some4 = which of the lane's nodes are Some) and absent (some4 = 0, the results go to the wave's junk lines) - the gather
+// registers then never pass through a control-flow merge, where the compiler would copy all twelve. Heap nodes 0 and 1 (lane 0 of
+// role 0) belong to the LF predictor, which p3_lf_pass evaluates for the whole tile: here they are computed like any node and masked.
+// Role 1 leaves as one dwordx4 + one dword store, role 0 as two dwordx2 + two short stores.
+template <int IMG, int ROLE, int CELL>
+__device__ __forceinline__ void p3_half(const uint32_t (&addr)[4][6], float (&ga)[6], float (&gb)[6], const int (&own)[4], const PredictParams &pp, bool interior, uint32_t some4,
+                                        int lane, uint32_t *s_hist, const uint16_t *s_bkt, uint8_t *bd, int32_t *pd, uint8_t *junk, int ablate) {
     constexpr int kOff = IMG * kP3ImageBytes + CELL * kP3SlotBytes;
-    uint32_t b12[4];
+    uint32_t b12[4], bin[4], sym[4];
     int pred[4];
     if (!(ablate & 16)) p3_issue<kOff>(ga, addr[0]);
 #pragma unroll
@@ -495,37 +498,87 @@ __device__ __forceinline__ void p3_half(const uint32_t (&addr)[4][6], float (&ga
         const P3Group q = p3_group(pp, ROLE ? 0 : j < 2 ? 2 : 1); // uniform: scalar registers
         float width, pf;
         p3_node_math(g, q, width, pf);
-        uint32_t b = (ablate & 8) ? (f32_as_u32(width) & 7u) << 12 : s_bkt[min(f32_as_u32(width), 31u)]; // assign_bucket (prediction.rs:55-68) as a 32-entry table of bucket << 12
-        int prediction = f32_as_i32(pf);
-        if (ROLE == 0 && j < 2) { // heap index 0 (DC) and 1 (root) sit in lane 0: the LF predictor, evaluated on the scalar unit
-            uint32_t lb;
-            int lp;
-            p3_lf(__builtin_amdgcn_readfirstlane(f32_as_i32(g[0])), __builtin_amdgcn_readfirstlane(f32_as_i32(g[1])), __builtin_amdgcn_readfirstlane(f32_as_i32(g[2])), lb, lp);
-            b = lane == 0 ? lb : b;
-            prediction = lane == 0 ? lp : prediction;
-        }
-        const uint32_t sym = pack_signed(sub_w(own[CELL][j], prediction));
-        uint32_t bin = b + (sym << 2); // byte offset of the counter in the 10 x 1024 table
-        if (__builtin_expect(__any(sym >= 1024u), 0)) bin = sym < 1024u ? bin : (uint32_t)kHistBins * 4u; // out of alphabet (entropy_coding.rs:99 would panic): counted apart
-        const bool some = INTERIOR || ((some4 >> j) & 1u);
-        if (some && !(ablate & 4)) atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(s_hist) + bin), 1u); // bump_freq, entropy_coding.rs:98-100
-        if (ablate & 4) prediction ^= (int)bin; // (timing only: keeps the bin arithmetic alive)
-        // a None node is not counted and stays (0, 0) in the outputs (wavelet_transform.rs:60-64)
-        pred[j] = some ? prediction : 0;
-        b12[j] = some ? b : 0u;
+        b12[j] = (ablate & 8) ? (f32_as_u32(width) & 7u) << 12 : s_bkt[min(f32_as_u32(width), 31u)]; // assign_bucket (prediction.rs:55-68) as a 32-entry table of bucket << 12
+        pred[j] = f32_as_i32(pf);
+        sym[j] = pack_signed(sub_w(own[j], pred[j]));
+        bin[j] = b12[j] + (sym[j] << 2); // byte offset of the counter in the 10 x 1024 table
     }
+    // out of alphabet (entropy_coding.rs:99 would panic): counted apart. One test for the four nodes.
+    if (__builtin_expect(__any((sym[0] | sym[1] | sym[2] | sym[3]) >= 1024u), 0)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) bin[j] = sym[j] < 1024u ? bin[j] : (uint32_t)kHistBins * 4u;
+    }
+    if (__builtin_expect(interior, 1)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool lf = ROLE == 0 && j < 2 && lane == 0;
+            if (!lf && !(ablate & 4)) atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(s_hist) + bin[j]), 1u); // bump_freq, entropy_coding.rs:98-100
+        }
+    } else { // a None node is not counted and stays (0, 0) in the outputs (wavelet_transform.rs:60-64)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool some = (some4 >> j) & 1u; // (the LF nodes' bits are already cleared)
+            if (some && !(ablate & 4)) atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(s_hist) + bin[j]), 1u);
+            pred[j] = some ? pred[j] : 0;
+            b12[j] = some ? b12[j] : 0u;
+        }
+    }
+    if (ablate & 4) pred[0] ^= (int)(bin[0] ^ bin[1] ^ bin[2] ^ bin[3]); // (timing only: keeps the bin arithmetic alive)
     // bucket << 12 in each: byte 1 holds bucket << 4; collect the byte-1s, then one shift moves all the nibbles down.
     // Wave-uniform bases + a 32-bit lane offset: the stores address as saddr + voffset, no 64-bit pointer arithmetic per cell.
     if (ROLE) {
         const uint32_t lo = __builtin_amdgcn_perm(b12[1], b12[0], 0x0C0C0501u), hi = __builtin_amdgcn_perm(b12[3], b12[2], 0x05010C0Cu);
-        __builtin_nontemporal_store(i32x4{pred[0], pred[1], pred[2], pred[3]}, reinterpret_cast<i32x4 *>(pd + 256) + lane);
-        __builtin_nontemporal_store((lo | hi) >> 4, reinterpret_cast<uint32_t *>(bd + 256) + lane);
+        if (!(ablate & 32) || ((lo ^ hi ^ pred[0] ^ pred[1] ^ pred[2] ^ pred[3]) == 0x12345678)) { // (32: timing only, no stores; the test keeps the arithmetic alive)
+            __builtin_nontemporal_store(i32x4{pred[0], pred[1], pred[2], pred[3]}, reinterpret_cast<i32x4 *>(pd + 256) + lane);
+            __builtin_nontemporal_store((lo | hi) >> 4, reinterpret_cast<uint32_t *>(bd + 256) + lane);
+        }
     } else {
         const uint32_t lo = __builtin_amdgcn_perm(b12[1], b12[0], 0x0C0C0501u) >> 4, hi = __builtin_amdgcn_perm(b12[3], b12[2], 0x0C0C0501u) >> 4;
-        __builtin_nontemporal_store(i32x2{pred[0], pred[1]}, reinterpret_cast<i32x2 *>(pd) + lane);
-        __builtin_nontemporal_store((uint16_t)lo, reinterpret_cast<uint16_t *>(bd) + lane);
-        __builtin_nontemporal_store(i32x2{pred[2], pred[3]}, reinterpret_cast<i32x2 *>(pd + 128) + lane);
-        __builtin_nontemporal_store((uint16_t)hi, reinterpret_cast<uint16_t *>(bd + 128) + lane);
+        // Nodes 0 and 1 are written by the LF pass: lane 0's pair goes to the wave's junk lines instead. By address, not under a branch -
+        // the number of stores per cell must be the same on every path, or the wait for the staging loads turns into a wait for stores.
+        i32x2 *p01 = lane == 0 ? reinterpret_cast<i32x2 *>(junk + 512) : reinterpret_cast<i32x2 *>(pd) + lane;
+        uint16_t *b01 = lane == 0 ? reinterpret_cast<uint16_t *>(junk) : reinterpret_cast<uint16_t *>(bd) + lane;
+        if (!(ablate & 32) || ((lo ^ hi ^ pred[0] ^ pred[1] ^ pred[2] ^ pred[3]) == 0x12345678)) {
+            __builtin_nontemporal_store(i32x2{pred[0], pred[1]}, p01);
+            __builtin_nontemporal_store((uint16_t)lo, b01);
+            __builtin_nontemporal_store(i32x2{pred[2], pred[3]}, reinterpret_cast<i32x2 *>(pd + 128) + lane);
+            __builtin_nontemporal_store((uint16_t)hi, reinterpret_cast<uint16_t *>(bd + 128) + lane);
+        }
+    }
+}
+
+// get_lf_context_bucket (prediction.rs:86-149) for heap nodes 0 (DC) and 1 (root) of all 16 block cells of a tile at once: lane = 2 *
+// block cell + node, run by one wave per tile. The three neighbours are the same heap node of the cells to the left, up-left and
+// up-right (lf_addr: their LDS addresses relative to the own slot); values come out of the image as integers (exact: the image holds
+// magnitudes <= 256 only).
+template <int IMG>
+__device__ __forceinline__ void p3_lf_pass(const PredArgs &a, P3Lds &lds, const int32_t *cur_slots, int lane) {
+    if (lane >= 2 * kPredBlock * kPredBlock) return;
+    // (nothing loop invariant may be hoisted out of here into registers all sixteen waves would pay for: the lane index the address
+    // arithmetic starts from is made opaque)
+    asm volatile("" : "+v"(lane));
+    const int c = lane >> 1, n = lane & 1;
+    const u32x4 lf = *reinterpret_cast<const u32x4 *>(lds.lf_rel[n]); // kept in LDS: loop invariants of ONE wave must not cost all of them registers
+    const uint32_t lf_rel[4] = {lf.x, lf.y, lf.z, lf.w};
+    const int slot = (1 + c / kPredBlock) * kPredSide + 1 + (c % kPredBlock);
+    const int raw = cur_slots[slot];
+    const int cell = pred_slot_cell(raw);
+    const uint8_t *img = lds.cells[IMG];
+    auto value_at = [&](uint32_t rel) -> int { // rel: byte offset from the own slot, 0x7FFF = never a node
+        const uint32_t off = rel == 0x7FFFu ? (uint32_t)kP3ZeroOff : (uint32_t)(slot * kP3SlotBytes + (int)(short)rel);
+        const uint32_t h = *reinterpret_cast<const uint16_t *>(img + off);
+        return f32_as_i32(__builtin_bit_cast(float, h << 16));
+    };
+    const int v0 = value_at(lf_rel[0]), v1 = value_at(lf_rel[1]), v2 = value_at(lf_rel[2]), value = value_at(lf_rel[3]);
+    uint32_t b12;
+    int prediction;
+    p3_lf(v0, v1, v2, b12, prediction);
+    const bool some = cell >= 0 && (pred_slot_interior(raw) || ((lds.masks[IMG][slot][0] >> n) & 1u));
+    const uint32_t sym = pack_signed(sub_w(value, prediction));
+    if (some) atomicAdd(&lds.hist[sym < 1024u ? (b12 >> 2) + sym : (uint32_t)kHistBins], 1u);
+    if (cell >= 0) {
+        if (a.prediction) a.prediction[(size_t)cell * kCell + n] = some ? prediction : 0;
+        if (a.bucket) a.bucket[(size_t)cell * kCell + n] = (uint8_t)(some ? b12 >> 12 : 0u);
     }
 }
 
@@ -617,10 +670,10 @@ struct P3Staged { // one whole (halo) cell on its way from global memory to an L
 };
 __device__ __forceinline__ void p3_issue_cell(const PredArgs &a, const int32_t *plane, int raw, int lane, P3Staged &st) {
     const int cell = max(pred_slot_cell(raw), 0); // a slot without a cell loads cell 0 and is zeroed at the commit: no load is conditional
-    const i32x4 *src = reinterpret_cast<const i32x4 *>(plane + (size_t)cell * kCell + 4 * lane);
-    st.lo = src[0];
-    st.hi = src[64];
-    st.mask = a.valid_mask[(size_t)cell * 16 + (lane & 15)];
+    const i32x4 *src = reinterpret_cast<const i32x4 *>(plane + (size_t)cell * kCell); // wave-uniform base + 32-bit lane offset
+    st.lo = src[(uint32_t)lane];
+    st.hi = src[64u + (uint32_t)lane];
+    st.mask = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u];
 }
 __device__ __forceinline__ int p3_some_or_zero(int v) { return v == kNone ? 0 : v; }
 // int32 -> upper half of the f32 pattern, two per dword; returns the larger magnitude (as f32)
@@ -657,8 +710,8 @@ struct P3Quarter {
 };
 __device__ __forceinline__ void p3_issue_quarter(const PredArgs &a, const int32_t *plane, int raw, int quarter, int lane, P3Quarter &st) {
     const int cell = max(pred_slot_cell(raw), 0);
-    st.v = *reinterpret_cast<const i32x2 *>(plane + (size_t)cell * kCell + 128 * quarter + 2 * lane);
-    st.mask = a.valid_mask[(size_t)cell * 16 + (lane & 15)];
+    st.v = reinterpret_cast<const i32x2 *>(plane + (size_t)cell * kCell + 128 * quarter)[(uint32_t)lane];
+    st.mask = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u];
 }
 __device__ __forceinline__ float p3_commit_quarter(int raw, int slot, int quarter, int lane, uint32_t qpos, P3Quarter st, uint8_t *image, uint32_t *masks) {
     if (quarter == 0 && lane < 16) masks[slot * 16 + lane] = st.mask;
@@ -685,26 +738,27 @@ struct P3Lane {          // loop invariants of a lane
     uint32_t qpos;       // of its pair of the quarter cell
 };
 
-// what a wave stages of one of its own block cells: its four nodes (role 1: one dwordx4, role 0: two dwordx2)
+// what a wave stages of one of its own block cells: its four nodes (role 1: one dwordx4, role 0: two dwordx2). Wave-uniform base
+// + 32-bit lane offset: saddr + voffset addressing, no vector pointer arithmetic.
 template <int ROLE>
-__device__ __forceinline__ i32x4 p3_load_own(const int32_t *cell_base, int lane) {
-    if (ROLE) return *reinterpret_cast<const i32x4 *>(cell_base + 256 + 4 * lane);
-    const i32x2 a = *reinterpret_cast<const i32x2 *>(cell_base + 2 * lane), b = *reinterpret_cast<const i32x2 *>(cell_base + 128 + 2 * lane);
+__device__ __forceinline__ i32x4 p3_load_own(const int32_t *cell_base, uint32_t lane) {
+    if (ROLE) return reinterpret_cast<const i32x4 *>(cell_base + 256)[lane];
+    const i32x2 a = reinterpret_cast<const i32x2 *>(cell_base)[lane], b = reinterpret_cast<const i32x2 *>(cell_base + 128)[lane];
     return i32x4{a.x, a.y, b.x, b.y};
 }
 
+// OWN_CUR / OWN_NXT: the lane's own values (exact int32, for the residuals) of this tile's two cells and, loaded here, of the next
+// tile's; the two register sets swap roles from tile to tile (IMG), so nothing is copied.
 template <int IMG, int ROLE>
 __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane, P3Lds &lds, int it, bool more, uint32_t next2_tile, int tid, int lane, int wave, int slot_a,
-                                        const P3Lane &L, float (&ga)[6], float (&gb)[6], int (&own)[2][4]) {
+                                        const P3Lane &L, float (&ga)[6], float (&gb)[6], const i32x4 (&own_cur)[2], i32x4 (&own_nxt)[2]) {
     uint32_t *s_hist = lds.hist;
     const uint16_t *s_bkt = lds.bkt;
     const int32_t *cur_slots = lds.ring[it % 3], *nxt_slots = lds.ring[(it + 1) % 3];
-    const uint32_t *cur_masks = &lds.masks[IMG][0][0];
     // in flight across the arithmetic below: the slot list of tile i + 2 and what this wave stages of tile i + 1 - its half of its two
     // block cells, one halo cell, a quarter of one of the last four halo cells
     const int32_t slot_pre = a.pred_slots[(size_t)next2_tile * kPredSlots + tid % kPredSlots];
     const int halo_slot = p3_halo_slot(wave), quarter_slot = p3_halo_slot(kP3Waves + (wave >> 2)), quarter = wave & 3;
-    i32x4 st_own[2];
     uint32_t st_own_mask[2];
     P3Staged st_halo;
     P3Quarter st_q;
@@ -715,8 +769,8 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
         for (int c = 0; c < 2; c++) {
             raw_own[c] = __builtin_amdgcn_readfirstlane(nxt_slots[slot_a + c]);
             const int cell = max(pred_slot_cell(raw_own[c]), 0);
-            st_own[c] = p3_load_own<ROLE>(plane + (size_t)cell * kCell, lane);
-            if (ROLE == 1) st_own_mask[c] = a.valid_mask[(size_t)cell * 16 + (lane & 15)]; // the level-8 waves have registers to spare
+            own_nxt[c] = p3_load_own<ROLE>(plane + (size_t)cell * kCell, (uint32_t)lane);
+            if (ROLE == 1) st_own_mask[c] = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u]; // the level-8 waves have registers to spare
         }
         raw_halo = __builtin_amdgcn_readfirstlane(nxt_slots[halo_slot]);
         raw_q = __builtin_amdgcn_readfirstlane(nxt_slots[quarter_slot]);
@@ -724,54 +778,57 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
         p3_issue_quarter(a, plane, raw_q, quarter, lane, st_q);
     }
 
-    // two block cells per wave; every path issues the same number of stores per cell (a wave without a retained cell at a block slot
-    // writes zeros to its junk lines), so the commit below waits for the staging loads with a counted vmcnt and not for the stores just issued
-#define FRI_P3_CELL(C)                                                                                                                                  \
-    {                                                                                                                                                   \
-        const int raw = (ablate_flags(a.ablate) & 1) ? -1 : __builtin_amdgcn_readfirstlane(cur_slots[slot_a + C]); /* all this phase needs is in LDS or registers */ \
-        const int cell = pred_slot_cell(raw);                                                                                                           \
-        const bool has = cell >= 0;                                                                                                                     \
-        const size_t junk = ((size_t)blockIdx.x * kP3Waves + wave) * kPredJunkBytes;                                                                    \
-        uint8_t *bd = has && a.bucket ? a.bucket + (size_t)cell * kCell : a.junk + junk;                                                                \
-        int32_t *pd = has && a.prediction ? a.prediction + (size_t)cell * kCell : reinterpret_cast<int32_t *>(a.junk + junk + 512);                    \
-        if (pred_slot_interior(raw)) {                                                                                                                  \
-            p3_half<IMG, ROLE, C, true>(L.addr, ga, gb, own, a.pp, 15u, lane, s_hist, s_bkt, bd, pd, ablate_flags(a.ablate));                                                   \
-        } else if (has) { /* boundary cell: node p is bit (p & 31) of mask word p >> 5 */                                                               \
-            uint32_t some4;                                                                                                                             \
-            if (ROLE) {                                                                                                                                 \
-                some4 = (cur_masks[(slot_a + C) * 16 + 8 + (lane >> 3)] >> (4 * (lane & 7))) & 15u;                                                      \
-            } else {                                                                                                                                    \
-                const uint32_t w0 = cur_masks[(slot_a + C) * 16 + (lane >> 4)], w1 = cur_masks[(slot_a + C) * 16 + 4 + (lane >> 4)];                     \
-                some4 = ((w0 >> (2 * (lane & 15))) & 3u) | (((w1 >> (2 * (lane & 15))) & 3u) << 2);                                                      \
-            }                                                                                                                                           \
-            p3_half<IMG, ROLE, C, false>(L.addr, ga, gb, own, a.pp, some4, lane, s_hist, s_bkt, bd, pd, ablate_flags(a.ablate));                                                \
-        } else if (ROLE) {                                                                                                                              \
-            __builtin_nontemporal_store(i32x4{0, 0, 0, 0}, reinterpret_cast<i32x4 *>(pd + 256) + lane);                                                  \
-            __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t *>(bd + 256) + lane);                                                              \
-        } else {                                                                                                                                        \
-            __builtin_nontemporal_store(i32x2{0, 0}, reinterpret_cast<i32x2 *>(pd) + lane);                                                              \
-            __builtin_nontemporal_store((uint16_t)0, reinterpret_cast<uint16_t *>(bd) + lane);                                                           \
-            __builtin_nontemporal_store(i32x2{0, 0}, reinterpret_cast<i32x2 *>(pd + 128) + lane);                                                        \
-            __builtin_nontemporal_store((uint16_t)0, reinterpret_cast<uint16_t *>(bd + 128) + lane);                                                     \
-        }                                                                                                                                               \
+    if (ROLE == 1 && wave == 1 && !(ablate_flags(a.ablate) & 1)) p3_lf_pass<IMG>(a, lds, cur_slots, lane);
+
+    // two block cells per wave; every cell issues the same number of stores (without a retained cell at the block slot they go to the
+    // wave's junk lines), so the commit below waits for the staging loads with a counted vmcnt and not for the stores just issued
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int raw = (ablate_flags(a.ablate) & 1) ? -1 : __builtin_amdgcn_readfirstlane(cur_slots[slot_a + c]); // all this phase needs is in LDS or registers
+        const int cell = pred_slot_cell(raw);
+        const bool has = cell >= 0, interior = pred_slot_interior(raw);
+        const size_t junk = ((size_t)blockIdx.x * kP3Waves + wave) * kPredJunkBytes;
+        uint8_t *bd = has && a.bucket ? a.bucket + (size_t)cell * kCell : a.junk + junk;
+        int32_t *pd = has && a.prediction ? a.prediction + (size_t)cell * kCell : reinterpret_cast<int32_t *>(a.junk + junk + 512);
+        uint32_t some4 = 0;
+        if (!interior && has) { // boundary cell: node p is bit (p & 31) of mask word p >> 5
+            const uint32_t *m = lds.masks[IMG][slot_a + c];
+            if (ROLE) {
+                some4 = (m[8 + (lane >> 3)] >> (4 * (lane & 7))) & 15u;
+            } else {
+                some4 = ((m[lane >> 4] >> (2 * (lane & 15))) & 3u) | (((m[4 + (lane >> 4)] >> (2 * (lane & 15))) & 3u) << 2);
+                if (lane == 0) some4 &= ~3u; // heap nodes 0 and 1: p3_lf_pass
+            }
+        }
+        const int own4[4] = {own_cur[c].x, own_cur[c].y, own_cur[c].z, own_cur[c].w};
+        if (ablate_flags(a.ablate) & 1) {
+            if (ROLE) {
+                __builtin_nontemporal_store(i32x4{0, 0, 0, 0}, reinterpret_cast<i32x4 *>(pd + 256) + lane);
+                __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t *>(bd + 256) + lane);
+            } else {
+                __builtin_nontemporal_store(i32x2{0, 0}, reinterpret_cast<i32x2 *>(pd) + lane);
+                __builtin_nontemporal_store((uint16_t)0, reinterpret_cast<uint16_t *>(bd) + lane);
+                __builtin_nontemporal_store(i32x2{0, 0}, reinterpret_cast<i32x2 *>(pd + 128) + lane);
+                __builtin_nontemporal_store((uint16_t)0, reinterpret_cast<uint16_t *>(bd + 128) + lane);
+            }
+        } else if (c == 0) {
+            p3_half<IMG, ROLE, 0>(L.addr, ga, gb, own4, a.pp, interior, some4, lane, s_hist, s_bkt, bd, pd, a.junk + junk, ablate_flags(a.ablate));
+        } else {
+            p3_half<IMG, ROLE, 1>(L.addr, ga, gb, own4, a.pp, interior, some4, lane, s_hist, s_bkt, bd, pd, a.junk + junk, ablate_flags(a.ablate));
+        }
     }
-    FRI_P3_CELL(0)
-    FRI_P3_CELL(1)
-#undef FRI_P3_CELL
 
     if (more) {
-        // The staged registers are consumed from here on, not earlier: left alone, the compiler hoists the copy of the next tile's own
+        // The staged registers are consumed from here on, not earlier: left alone, the compiler hoists uses of the next tile's own
         // values to the top of the iteration and waits for the loads there - in front of the arithmetic they are meant to hide behind.
-        asm volatile("" : "+v"(st_own[0]), "+v"(st_own[1]), "+v"(st_halo.lo), "+v"(st_halo.hi), "+v"(st_q.v));
+        asm volatile("" : "+v"(own_nxt[0]), "+v"(own_nxt[1]), "+v"(st_halo.lo), "+v"(st_halo.hi), "+v"(st_q.v));
         uint8_t *nxt = lds.cells[IMG ^ 1];
         uint32_t *nxt_masks = &lds.masks[IMG ^ 1][0][0];
         float m = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            m = __builtin_fmaxf(m, p3_commit4(raw_own[c], st_own[c], nxt + (slot_a + c) * kP3SlotBytes, L.opos[0], L.opos[1]));
+            m = __builtin_fmaxf(m, p3_commit4(raw_own[c], own_nxt[c], nxt + (slot_a + c) * kP3SlotBytes, L.opos[0], L.opos[1]));
             if (ROLE == 1 && lane < 16) nxt_masks[(slot_a + c) * 16 + lane] = st_own_mask[c];
-            // the own values of the next tile stay in registers: exact int32 for the residual (a None or absent cell never reaches the histogram)
-            own[c][0] = st_own[c].x, own[c][1] = st_own[c].y, own[c][2] = st_own[c].z, own[c][3] = st_own[c].w;
         }
         if (lane < 16) nxt_masks[halo_slot * 16 + lane] = st_halo.mask;
         m = __builtin_fmaxf(m, p3_commit4(raw_halo, st_halo.lo, nxt + halo_slot * kP3SlotBytes, L.wpos[0], L.wpos[1]));
@@ -812,7 +869,7 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
     L.opos[1] = ROLE ? L.wpos[3] : 4u * a.pair_pos[64 + lane];
     L.qpos = 4u * a.pair_pos[64 * (wave & 3) + lane];
     float ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int own[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    i32x4 own_a[2] = {i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}}, own_b[2] = {i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
 
     const PredTileWalk walk(a.n_tiles);
     if (walk.first >= walk.end) return; // (a workgroup without a tile still takes part in the hand-over)
@@ -825,15 +882,14 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
     { // tile 0 straight into image 0: everything a wave stages is requested before the first value is converted
         const int halo_slot = p3_halo_slot(wave), quarter_slot = p3_halo_slot(kP3Waves + (wave >> 2)), quarter = wave & 3;
         const int raw_halo = __builtin_amdgcn_readfirstlane(s_ring[halo_slot]), raw_q = __builtin_amdgcn_readfirstlane(s_ring[quarter_slot]);
-        i32x4 st_own[2];
         uint32_t st_own_mask[2] = {0, 0};
         int raw_own[2];
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             raw_own[c] = __builtin_amdgcn_readfirstlane(s_ring[slot_a + c]);
             const int cell = max(pred_slot_cell(raw_own[c]), 0);
-            st_own[c] = p3_load_own<ROLE>(plane + (size_t)cell * kCell, lane);
-            if (ROLE == 1) st_own_mask[c] = a.valid_mask[(size_t)cell * 16 + (lane & 15)];
+            own_a[c] = p3_load_own<ROLE>(plane + (size_t)cell * kCell, (uint32_t)lane);
+            if (ROLE == 1) st_own_mask[c] = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u];
         }
         P3Staged st_halo;
         P3Quarter st_q;
@@ -842,9 +898,8 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
         float m = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            m = __builtin_fmaxf(m, p3_commit4(raw_own[c], st_own[c], s_cells + (slot_a + c) * kP3SlotBytes, L.opos[0], L.opos[1]));
+            m = __builtin_fmaxf(m, p3_commit4(raw_own[c], own_a[c], s_cells + (slot_a + c) * kP3SlotBytes, L.opos[0], L.opos[1]));
             if (ROLE == 1 && lane < 16) s_masks[(slot_a + c) * 16 + lane] = st_own_mask[c];
-            own[c][0] = st_own[c].x, own[c][1] = st_own[c].y, own[c][2] = st_own[c].z, own[c][3] = st_own[c].w;
         }
         if (lane < 16) s_masks[halo_slot * 16 + lane] = st_halo.mask;
         m = __builtin_fmaxf(m, p3_commit4(raw_halo, st_halo.lo, s_cells + halo_slot * kP3SlotBytes, L.wpos[0], L.wpos[1]));
@@ -857,10 +912,10 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
 
     int it = 0;
     for (uint32_t tile = walk.first; tile < walk.end;) { // unrolled by two: the LDS image a tile lives in is a compile-time constant
-        p3_tile<0, ROLE>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own);
+        p3_tile<0, ROLE>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_a, own_b);
         tile += walk.step, it++;
         if (tile >= walk.end) break;
-        p3_tile<1, ROLE>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own);
+        p3_tile<1, ROLE>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_b, own_a);
         tile += walk.step, it++;
     }
 }
@@ -876,6 +931,11 @@ __global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const Pr
     trace_stamp(a.trace, blockIdx.x, 0, tid);
     for (int i = tid; i < kHistBins + 4; i += kP3Threads) s_hist[i] = 0;
     if (tid < 32) s_bkt[tid] = (uint16_t)(bucket_of((uint32_t)tid) << 12);
+    if (tid < 2) { // the LF pass: byte offsets, from a cell's slot, of heap node tid's neighbours left, up-left, up-right and of the node itself
+        const u32x4 o = reinterpret_cast<const u32x4 *>(a.pred_off)[tid];
+        lds.lf_rel[tid][0] = o.x & 0xFFFFu, lds.lf_rel[tid][1] = o.x >> 16, lds.lf_rel[tid][2] = o.y & 0xFFFFu;
+        lds.lf_rel[tid][3] = 4u * a.pair_pos[0] + 2u * (uint32_t)tid;
+    }
     for (int i = tid; i < 2 * (kP3ImageBytes - kP3ZeroOff) / 4; i += kP3Threads) // the zero words behind the cells of both images
         reinterpret_cast<uint32_t *>(s_cells + (i / ((kP3ImageBytes - kP3ZeroOff) / 4)) * kP3ImageBytes + kP3ZeroOff)[i % ((kP3ImageBytes - kP3ZeroOff) / 4)] = 0;
     if (wave & 1)
