@@ -12,6 +12,8 @@ from .api import (  # noqa: F401
     Multi,
     Plan,
     build_library,
+    fit_value_params,
+    fit_width_params,
     library_path,
     load_library,
     shard_images,

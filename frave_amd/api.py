@@ -22,7 +22,9 @@ SYMBOLS = [
     "fri_hip_fit_width_sums_dev", "fri_hip_inverse_transform", "fri_hip_inverse_transform_dev",
     "fri_hip_time_transform_quant_dev", "fri_hip_plan_read_trace", "fri_hip_plan_inverse_lists",
     "fri_hip_shard_size", "fri_hip_shard_image", "fri_hip_multi_create", "fri_hip_multi_destroy", "fri_hip_multi_num_devices",
-    "fri_hip_multi_plan", "fri_hip_multi_transform_quant",
+    "fri_hip_multi_plan", "fri_hip_multi_transform_quant", "fri_hip_predict_histogram_batch_dev", "fri_hip_fit_value_sums_batch_dev",
+    "fri_hip_fit_width_sums_batch_dev", "fri_hip_solve6", "fri_hip_fit_value_params", "fri_hip_fit_width_params", "fri_hip_encode_image",
+    "fri_hip_encode_image_dev", "fri_hip_inverse_transform_batch_dev", "fri_hip_predict_image", "fri_hip_predict_image_dev",
 ]
 
 
@@ -111,6 +113,17 @@ def load_library():
     L.fri_hip_multi_num_devices.restype, L.fri_hip_multi_num_devices.argtypes = u32, [vp]
     L.fri_hip_multi_plan.restype, L.fri_hip_multi_plan.argtypes = vp, [vp, u32]
     L.fri_hip_multi_transform_quant.argtypes = [vp, u32, vp, vp, vp]
+    L.fri_hip_predict_histogram_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp, vp, sz, vp, vp, vp]
+    L.fri_hip_fit_value_sums_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp]
+    L.fri_hip_fit_width_sums_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp, vp, vp]
+    L.fri_hip_solve6.restype, L.fri_hip_solve6.argtypes = None, [vp, vp, vp]
+    L.fri_hip_fit_value_params.restype, L.fri_hip_fit_value_params.argtypes = None, [vp, vp]
+    L.fri_hip_fit_width_params.restype, L.fri_hip_fit_width_params.argtypes = None, [vp, vp, vp, vp]
+    L.fri_hip_encode_image.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.fri_hip_encode_image_dev.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.fri_hip_inverse_transform_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, vp]
+    L.fri_hip_predict_image.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.fri_hip_predict_image_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -158,6 +171,24 @@ def shard_images(n_images, shard, n_shards):
     """Global indices of the images of `shard` (fri_hip_shard_size / fri_hip_shard_image: image i -> shard i mod n_shards)."""
     L = load_library()
     return [L.fri_hip_shard_image(k, shard, n_shards) for k in range(L.fri_hip_shard_size(n_images, shard, n_shards))]
+
+
+def fit_value_params(gram_tri):
+    """fri_hip_fit_value_params: gram_tri int64 [3][28] (upper triangles) -> float32 [3][6]."""
+    g = np.ascontiguousarray(gram_tri, np.int64).reshape(3, 28)
+    out = np.empty((3, 6), np.float32)
+    load_library().fri_hip_fit_value_params(_p(g), _p(out))
+    return out
+
+
+def fit_width_params(wtw_tri, wtr, rows):
+    """fri_hip_fit_width_params: wtw_tri int64 [3][21], wtr float64 [3][6], rows uint64 [3] -> float32 [3][6]."""
+    w = np.ascontiguousarray(wtw_tri, np.int64).reshape(3, 21)
+    r = np.ascontiguousarray(wtr, np.float64).reshape(3, 6)
+    n = np.ascontiguousarray(rows, np.uint64).reshape(3)
+    out = np.empty((3, 6), np.float32)
+    load_library().fri_hip_fit_width_params(_p(w), _p(r), _p(n), _p(out))
+    return out
 
 
 class Multi:
@@ -380,6 +411,58 @@ class Plan:
     def fit_width_sums_dev(self, d_coefs, channel, value_params, d_wtw, d_wtr, stream=0):
         vp = np.ascontiguousarray(value_params, np.float32).reshape(3, 6)
         _check(load_library().fri_hip_fit_width_sums_dev(self._h, d_coefs, channel, _p(vp), d_wtw, d_wtr, stream), "fri_hip_fit_width_sums_dev", self.ctx)
+
+    def encode_image(self, pixels, qmatrix=None, fit=True, value_params=None, width_params=None, want_bucket=True, want_prediction=True):
+        """fri_hip_encode_image: (coefs [C][F][512], value_params [C][3][6], width_params [C][3][6], bucket, prediction, hist [C][10][1024], oob [C])."""
+        px = np.ascontiguousarray(pixels, np.uint8).reshape(-1)
+        assert px.size == self.pixel_bytes
+        c, f = self.channels, self.num_cells
+        vp = np.zeros((c, 3, 6), np.float32) if value_params is None else np.ascontiguousarray(value_params, np.float32).reshape(c, 3, 6).copy()
+        wp = np.zeros((c, 3, 6), np.float32) if width_params is None else np.ascontiguousarray(width_params, np.float32).reshape(c, 3, 6).copy()
+        coefs = np.empty((c, f, 512), np.int32)
+        bucket = np.empty((c, f, 512), np.uint8) if want_bucket else None
+        pred = np.empty((c, f, 512), np.int32) if want_prediction else None
+        hist = np.empty((c, 10, 1024), np.uint32)
+        oob = np.zeros(c, np.uint64)
+        q = _q(qmatrix)
+        _check(load_library().fri_hip_encode_image(self._h, _p(px), _p(q), 1 if fit else 0, _p(vp), _p(wp), _p(coefs), _p(bucket) if want_bucket else None,
+                                                   _p(pred) if want_prediction else None, _p(hist), _p(oob)), "fri_hip_encode_image", self.ctx)
+        return coefs, vp, wp, bucket, pred, hist, oob
+
+    def predict_image(self, coefs, fit=True, value_params=None, width_params=None):
+        """fri_hip_predict_image: (value_params, width_params, bucket [C][F][512], prediction, hist [C][10][1024], oob [C])."""
+        co = np.ascontiguousarray(coefs, np.int32)
+        assert co.size == self.coef_count
+        c, f = self.channels, self.num_cells
+        vp = np.zeros((c, 3, 6), np.float32) if value_params is None else np.ascontiguousarray(value_params, np.float32).reshape(c, 3, 6).copy()
+        wp = np.zeros((c, 3, 6), np.float32) if width_params is None else np.ascontiguousarray(width_params, np.float32).reshape(c, 3, 6).copy()
+        bucket, pred = np.empty((c, f, 512), np.uint8), np.empty((c, f, 512), np.int32)
+        hist, oob = np.empty((c, 10, 1024), np.uint32), np.zeros(c, np.uint64)
+        _check(load_library().fri_hip_predict_image(self._h, _p(co), 1 if fit else 0, _p(vp), _p(wp), _p(bucket), _p(pred), _p(hist), _p(oob)), "fri_hip_predict_image", self.ctx)
+        return vp, wp, bucket, pred, hist, oob
+
+    def encode_image_dev(self, d_pixels, d_coefs, d_bucket, d_prediction, d_hist, d_oob, value_params, width_params, fit=False, qmatrix=None, stream=0):
+        """fri_hip_encode_image_dev; value_params / width_params are float32 [C][3][6] numpy arrays (in, or out when fit)."""
+        q = _q(qmatrix)
+        assert value_params.dtype == np.float32 and width_params.dtype == np.float32 and value_params.size == width_params.size == self.channels * 18
+        _check(load_library().fri_hip_encode_image_dev(self._h, d_pixels, _p(q), 1 if fit else 0, _p(value_params), _p(width_params), d_coefs, d_bucket, d_prediction,
+                                                       d_hist, d_oob, stream), "fri_hip_encode_image_dev", self.ctx)
+
+    def predict_histogram_batch_dev(self, n_planes, d_coefs, coef_stride, d_params, d_bucket, d_prediction, out_stride, d_hist, d_oob, stream=0):
+        _check(load_library().fri_hip_predict_histogram_batch_dev(self._h, n_planes, d_coefs, coef_stride, d_params, d_bucket, d_prediction, out_stride, d_hist, d_oob,
+                                                                  stream), "fri_hip_predict_histogram_batch_dev", self.ctx)
+
+    def fit_value_sums_batch_dev(self, n_planes, d_coefs, coef_stride, d_gram, stream=0):
+        _check(load_library().fri_hip_fit_value_sums_batch_dev(self._h, n_planes, d_coefs, coef_stride, d_gram, stream), "fri_hip_fit_value_sums_batch_dev", self.ctx)
+
+    def fit_width_sums_batch_dev(self, n_planes, d_coefs, coef_stride, d_params, d_wtw, d_wtr, stream=0):
+        _check(load_library().fri_hip_fit_width_sums_batch_dev(self._h, n_planes, d_coefs, coef_stride, d_params, d_wtw, d_wtr, stream),
+               "fri_hip_fit_width_sums_batch_dev", self.ctx)
+
+    def inverse_transform_batch_dev(self, n_images, d_coefs, coef_stride, d_pixels, pixel_stride, qmatrix=None, stream=0):
+        q = _q(qmatrix)
+        _check(load_library().fri_hip_inverse_transform_batch_dev(self._h, n_images, d_coefs, coef_stride, _p(q), d_pixels, pixel_stride, stream),
+               "fri_hip_inverse_transform_batch_dev", self.ctx)
 
     def inverse_transform_dev(self, d_coefs, d_pixels, qmatrix=None, stream=0):
         q = _q(qmatrix)

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
@@ -63,7 +64,18 @@ struct fri_hip_plan {
         hipStream_t stream = nullptr;
         bool used = false;
         hipEvent_t handed_over = nullptr;
+        uint32_t *pred_acc = nullptr;           // [planes][kPredAccWords], grown on demand, all zero between launches
+        unsigned long long *fit_acc = nullptr;  // [planes][kFitAccWords]
+        uint32_t planes = 0;
     } acc_slots[kPredAccRing];
+    std::vector<void *> retired_acc; // accumulators outgrown by a larger batch: freed with the plan (a launch may still be draining them)
+    // fri_hip_encode_image: all channels' outputs + fit sums on the device, pinned mirrors of the small ones
+    uint8_t *d_bucket_all = nullptr;
+    int32_t *d_prediction_all = nullptr;
+    uint32_t *d_hist_all = nullptr;           // [C][10][1024]
+    unsigned long long *d_oob_all = nullptr;  // [C]
+    unsigned long long *d_sums_int = nullptr; // [C][3][28]
+    double *d_sums_dbl = nullptr;             // [C][3][6]
     uint32_t acc_next = 0;
     bool acc_dirty = false; // a launch on this plan failed: the accumulators are re-zeroed before the next use
     hipEvent_t ev_begin = nullptr, ev_end = nullptr; // timing helper's events, created with the plan (creating an event is not work to be timed)
@@ -141,31 +153,55 @@ int ensure_staging(fri_hip_plan *p) {
     return FRI_HIP_OK;
 }
 
-// Accumulator for a K2 / K4 launch on `stream` (see fri_hip_plan::acc_slots). Returns the index, or a negative error code.
-int acquire_acc(fri_hip_plan *p, hipStream_t stream) {
+// Accumulators for a K2 / K4 launch over n_planes planes on `stream` (see fri_hip_plan::acc_slots). Returns the slot index, or a negative error code.
+int acquire_acc(fri_hip_plan *p, hipStream_t stream, uint32_t n_planes = 1) {
     fri_hip_ctx *c = p->ctx;
     if (p->acc_dirty) { // rare: a previous launch failed part-way; nothing may be in flight on the accumulators when they are cleared
         HIP_TRY(c, hipDeviceSynchronize());
-        HIP_TRY(c, hipMemset(p->dev.pred_acc, 0, (size_t)kPredAccRing * kPredAccWords * sizeof(uint32_t)));
-        HIP_TRY(c, hipMemset(p->dev.fit_acc, 0, (size_t)kPredAccRing * kFitAccWords * sizeof(unsigned long long)));
-        HIP_TRY(c, hipMemset(p->dev.inexact, 0, 2 * sizeof(uint32_t)));
+        for (auto &a : p->acc_slots) {
+            if (a.pred_acc) HIP_TRY(c, hipMemset(a.pred_acc, 0, (size_t)a.planes * kPredAccWords * sizeof(uint32_t)));
+            if (a.fit_acc) HIP_TRY(c, hipMemset(a.fit_acc, 0, (size_t)a.planes * kFitAccWords * sizeof(unsigned long long)));
+        }
         p->acc_dirty = false;
     }
-    for (uint32_t i = 0; i < kPredAccRing; i++)
-        if (p->acc_slots[i].used && p->acc_slots[i].stream == stream) return (int)i;
-    for (uint32_t i = 0; i < kPredAccRing; i++)
+    int idx = -1;
+    for (uint32_t i = 0; i < kPredAccRing && idx < 0; i++)
+        if (p->acc_slots[i].used && p->acc_slots[i].stream == stream) idx = (int)i;
+    for (uint32_t i = 0; i < kPredAccRing && idx < 0; i++)
         if (!p->acc_slots[i].used) {
             p->acc_slots[i].used = true;
             p->acc_slots[i].stream = stream;
-            return (int)i;
+            idx = (int)i;
         }
-    auto &v = p->acc_slots[p->acc_next];
-    const int idx = (int)p->acc_next;
-    p->acc_next = (p->acc_next + 1) % kPredAccRing;
-    if (!v.handed_over) HIP_TRY(c, hipEventCreateWithFlags(&v.handed_over, hipEventDisableTiming));
-    HIP_TRY(c, hipEventRecord(v.handed_over, v.stream)); // everything the previous owner has queued so far ...
-    HIP_TRY(c, hipStreamWaitEvent(stream, v.handed_over, 0)); // ... finishes before the new owner's kernel starts
-    v.stream = stream;
+    if (idx < 0) {
+        auto &v = p->acc_slots[p->acc_next];
+        idx = (int)p->acc_next;
+        p->acc_next = (p->acc_next + 1) % kPredAccRing;
+        if (!v.handed_over) HIP_TRY(c, hipEventCreateWithFlags(&v.handed_over, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(v.handed_over, v.stream)); // everything the previous owner has queued so far ...
+        HIP_TRY(c, hipStreamWaitEvent(stream, v.handed_over, 0)); // ... finishes before the new owner's kernel starts
+        v.stream = stream;
+    }
+    auto &a = p->acc_slots[idx];
+    if (a.planes < n_planes) { // grow: the old buffers may still be in use by queued launches, so they are retired, not freed
+        const uint32_t planes = n_planes < 4 ? 4 : n_planes;
+        void *pa = nullptr, *fa = nullptr;
+        const size_t pb = (size_t)planes * kPredAccWords * sizeof(uint32_t), fb = (size_t)planes * kFitAccWords * sizeof(unsigned long long);
+        hipError_t e = hipMalloc(&pa, pb);
+        if (e == hipSuccess) e = hipMalloc(&fa, fb);
+        if (e == hipSuccess) e = hipMemset(pa, 0, pb);
+        if (e == hipSuccess) e = hipMemset(fa, 0, fb);
+        if (e != hipSuccess) {
+            if (pa) (void)hipFree(pa);
+            if (fa) (void)hipFree(fa);
+            return fail_hip(c, e, "accumulator allocation");
+        }
+        if (a.pred_acc) p->retired_acc.push_back(a.pred_acc);
+        if (a.fit_acc) p->retired_acc.push_back(a.fit_acc);
+        a.pred_acc = static_cast<uint32_t *>(pa);
+        a.fit_acc = static_cast<unsigned long long *>(fa);
+        a.planes = planes;
+    }
     return idx;
 }
 
@@ -365,35 +401,6 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             p->owned.push_back(j);
             d.junk = static_cast<uint8_t *>(j);
         }
-        {
-            const size_t bytes = (size_t)kPredAccRing * kPredAccWords * sizeof(uint32_t);
-            void *acc = nullptr;
-            if (hipMalloc(&acc, bytes) != hipSuccess || hipMemset(acc, 0, bytes) != hipSuccess) {
-                fri_hip_plan_destroy(p);
-                return FRI_HIP_ERR_HIP;
-            }
-            p->owned.push_back(acc);
-            d.pred_acc = static_cast<uint32_t *>(acc);
-        }
-        {
-            void *f = nullptr;
-            if (hipMalloc(&f, 2 * sizeof(uint32_t)) != hipSuccess || hipMemset(f, 0, 2 * sizeof(uint32_t)) != hipSuccess) {
-                fri_hip_plan_destroy(p);
-                return FRI_HIP_ERR_HIP;
-            }
-            p->owned.push_back(f);
-            d.inexact = static_cast<uint32_t *>(f);
-        }
-        {
-            const size_t bytes = (size_t)kPredAccRing * kFitAccWords * sizeof(unsigned long long);
-            void *acc = nullptr;
-            if (hipMalloc(&acc, bytes) != hipSuccess || hipMemset(acc, 0, bytes) != hipSuccess) {
-                fri_hip_plan_destroy(p);
-                return FRI_HIP_ERR_HIP;
-            }
-            p->owned.push_back(acc);
-            d.fit_acc = static_cast<unsigned long long *>(acc);
-        }
         d.k2_previous = env_int("FRI_HIP_K2_PREVIOUS") > 0;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
@@ -438,8 +445,14 @@ int fri_hip_plan_destroy(fri_hip_plan *p) {
         for (void *d : {(void *)p->d_pixels, (void *)p->d_coefs, (void *)p->d_bucket, (void *)p->d_prediction, (void *)p->d_hist, (void *)p->d_oob, (void *)p->d_fit_int, (void *)p->d_fit_dbl})
             if (d) (void)hipFree(d);
         free_slots(p);
-        for (auto &a : p->acc_slots)
+        for (auto &a : p->acc_slots) {
             if (a.handed_over) (void)hipEventDestroy(a.handed_over);
+            if (a.pred_acc) (void)hipFree(a.pred_acc);
+            if (a.fit_acc) (void)hipFree(a.fit_acc);
+        }
+        for (void *d : p->retired_acc) (void)hipFree(d);
+        for (void *d : {(void *)p->d_bucket_all, (void *)p->d_prediction_all, (void *)p->d_hist_all, (void *)p->d_oob_all, (void *)p->d_sums_int, (void *)p->d_sums_dbl})
+            if (d) (void)hipFree(d);
         if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
         if (p->ev_end) (void)hipEventDestroy(p->ev_end);
     }
@@ -635,22 +648,51 @@ int fri_hip_multi_transform_quant(fri_hip_multi *m, uint32_t n_images, const uin
 }
 
 /* ---- prediction + histogram ----------------------------------------------------------------- */
+static int predict_launch(fri_hip_plan *p, const PredBatch &b, uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist, uint64_t *d_oob, bool from_forward_kernel,
+                          hipStream_t stream) {
+    const int slot = acquire_acc(p, stream, b.n_planes);
+    if (slot < 0) return slot;
+    if (hipError_t e = launch_predict_histogram(p->dev, p->acc_slots[slot].pred_acc, b, d_bucket, d_prediction, d_hist, (unsigned long long *)d_oob, from_forward_kernel, stream)) {
+        p->acc_dirty = true;
+        return fail_hip(p->ctx, e, "launch_predict_histogram");
+    }
+    return FRI_HIP_OK;
+}
+static int fit_launch(fri_hip_plan *p, int mode, const PredBatch &b, int64_t *d_int, double *d_dbl, hipStream_t stream) {
+    const int slot = acquire_acc(p, stream, b.n_planes);
+    if (slot < 0) return slot;
+    if (hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, stream)) {
+        p->acc_dirty = true;
+        return fail_hip(p->ctx, e, "launch_fit_accumulate");
+    }
+    return FRI_HIP_OK;
+}
+
+int fri_hip_predict_histogram_batch_dev(fri_hip_plan *p, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, const float *d_params, uint8_t *d_bucket,
+                                        int32_t *d_prediction, size_t out_stride, uint32_t *d_hist, uint64_t *d_n_out_of_alphabet, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    const size_t plane = p->geo.centers.size() * kCell;
+    if (!d_coefs || !d_params || !d_hist || !d_n_out_of_alphabet || !n_planes || n_planes > 65535u) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    if (n_planes > 1 && (coef_stride < plane || ((d_bucket || d_prediction) && out_stride < plane))) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    PredBatch b;
+    b.n_planes = n_planes;
+    b.coefs = d_coefs;
+    b.coef_stride = coef_stride;
+    b.out_stride = out_stride;
+    b.params = reinterpret_cast<const PredictParams *>(d_params);
+    return predict_launch(p, b, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, false, (hipStream_t)stream);
+}
+
 int fri_hip_predict_histogram_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t channel, const float value_params[3][6],
                                   const float width_params[3][6], uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist,
                                   uint64_t *d_n_out_of_alphabet, void *stream) {
     if (int rc = need_device(p)) return rc;
     if (!d_coefs || !value_params || !width_params || !d_hist || !d_n_out_of_alphabet || channel >= p->geo.channels) return FRI_HIP_ERR_INVALID_ARGUMENT;
-    PredictParams pp;
-    std::memcpy(pp.value, value_params, sizeof(pp.value));
-    std::memcpy(pp.width, width_params, sizeof(pp.width));
-    const int32_t *plane = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
-    const int acc = acquire_acc(p, (hipStream_t)stream);
-    if (acc < 0) return acc;
-    if (hipError_t e = launch_predict_histogram(p->dev, (uint32_t)acc, plane, pp, d_bucket, d_prediction, d_hist, (unsigned long long *)d_n_out_of_alphabet, false, (hipStream_t)stream)) {
-        p->acc_dirty = true;
-        return fail_hip(p->ctx, e, "launch_predict_histogram");
-    }
-    return FRI_HIP_OK;
+    PredBatch b;
+    std::memcpy(b.pp[0].value, value_params, sizeof(b.pp[0].value));
+    std::memcpy(b.pp[0].width, width_params, sizeof(b.pp[0].width));
+    b.coefs = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
+    return predict_launch(p, b, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, false, (hipStream_t)stream);
 }
 
 int fri_hip_predict_histogram(fri_hip_plan *p, const int32_t *coefs, uint32_t channel, const float value_params[3][6],
@@ -675,34 +717,45 @@ int fri_hip_predict_histogram(fri_hip_plan *p, const int32_t *coefs, uint32_t ch
 }
 
 /* ---- context-model fit sums ----------------------------------------------------------------------- */
+int fri_hip_fit_value_sums_batch_dev(fri_hip_plan *p, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, int64_t *d_gram, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_coefs || !d_gram || !n_planes || n_planes > 65535u || (n_planes > 1 && coef_stride < p->geo.centers.size() * kCell)) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    PredBatch b;
+    b.n_planes = n_planes;
+    b.coefs = d_coefs;
+    b.coef_stride = coef_stride;
+    return fit_launch(p, 0, b, d_gram, nullptr, (hipStream_t)stream);
+}
+
+int fri_hip_fit_width_sums_batch_dev(fri_hip_plan *p, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, const float *d_params, int64_t *d_wtw, double *d_wtr,
+                                     void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_coefs || !d_params || !d_wtw || !d_wtr || !n_planes || n_planes > 65535u || (n_planes > 1 && coef_stride < p->geo.centers.size() * kCell))
+        return FRI_HIP_ERR_INVALID_ARGUMENT;
+    PredBatch b;
+    b.n_planes = n_planes;
+    b.coefs = d_coefs;
+    b.coef_stride = coef_stride;
+    b.params = reinterpret_cast<const PredictParams *>(d_params);
+    return fit_launch(p, 1, b, d_wtw, d_wtr, (hipStream_t)stream);
+}
+
 int fri_hip_fit_value_sums_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t channel, int64_t *d_gram, void *stream) {
     if (int rc = need_device(p)) return rc;
     if (!d_coefs || !d_gram || channel >= p->geo.channels) return FRI_HIP_ERR_INVALID_ARGUMENT;
-    PredictParams pp{};
-    const int32_t *plane = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
-    const int acc = acquire_acc(p, (hipStream_t)stream);
-    if (acc < 0) return acc;
-    if (hipError_t e = launch_fit_accumulate(p->dev, (uint32_t)acc, 0, plane, pp, (unsigned long long *)d_gram, nullptr, (hipStream_t)stream)) {
-        p->acc_dirty = true;
-        return fail_hip(p->ctx, e, "launch_fit_accumulate");
-    }
-    return FRI_HIP_OK;
+    PredBatch b;
+    b.coefs = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
+    return fit_launch(p, 0, b, d_gram, nullptr, (hipStream_t)stream);
 }
 
 int fri_hip_fit_width_sums_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t channel, const float value_params[3][6], int64_t *d_wtw, double *d_wtr,
                                void *stream) {
     if (int rc = need_device(p)) return rc;
     if (!d_coefs || !value_params || !d_wtw || !d_wtr || channel >= p->geo.channels) return FRI_HIP_ERR_INVALID_ARGUMENT;
-    PredictParams pp{};
-    std::memcpy(pp.value, value_params, sizeof(pp.value));
-    const int32_t *plane = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
-    const int acc = acquire_acc(p, (hipStream_t)stream);
-    if (acc < 0) return acc;
-    if (hipError_t e = launch_fit_accumulate(p->dev, (uint32_t)acc, 1, plane, pp, (unsigned long long *)d_wtw, d_wtr, (hipStream_t)stream)) {
-        p->acc_dirty = true;
-        return fail_hip(p->ctx, e, "launch_fit_accumulate");
-    }
-    return FRI_HIP_OK;
+    PredBatch b;
+    std::memcpy(b.pp[0].value, value_params, sizeof(b.pp[0].value));
+    b.coefs = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
+    return fit_launch(p, 1, b, d_wtw, d_wtr, (hipStream_t)stream);
 }
 
 int fri_hip_fit_value_sums(fri_hip_plan *p, const int32_t *coefs, uint32_t channel, int64_t gram[3][28]) {
@@ -735,14 +788,212 @@ int fri_hip_fit_width_sums(fri_hip_plan *p, const int32_t *coefs, uint32_t chann
     return FRI_HIP_OK;
 }
 
-/* ---- inverse ---------------------------------------------------------------------------------- */
-int fri_hip_inverse_transform_dev(fri_hip_plan *p, const int32_t *d_coefs, const int32_t qmatrix[32], uint8_t *d_pixels, void *stream) {
+/* ---- the 6 x 6 solves behind the fit -------------------------------------------------------------- */
+void fri_hip_solve6(const double m[6][6], const double y[6], double x[6]) {
+    // cyclic Jacobi: a = V diag(lam) V^T; x = sum over the eigen-directions above the cut-off of v (v . y) / lam
+    double a[6][6], v[6][6];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            a[i][j] = m[i][j];
+            v[i][j] = i == j ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i + 1; j < 6; j++) off += a[i][j] * a[i][j];
+        if (off < 1e-300) break;
+        for (int pp = 0; pp < 6; pp++)
+            for (int q = pp + 1; q < 6; q++) {
+                if (std::fabs(a[pp][q]) < 1e-300) continue;
+                const double theta = (a[q][q] - a[pp][pp]) / (2.0 * a[pp][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 6; k++) {
+                    const double akp = a[k][pp], akq = a[k][q];
+                    a[k][pp] = c * akp - sn * akq;
+                    a[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 6; k++) {
+                    const double apk = a[pp][k], aqk = a[q][k];
+                    a[pp][k] = c * apk - sn * aqk;
+                    a[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 6; k++) {
+                    const double vkp = v[k][pp], vkq = v[k][q];
+                    v[k][pp] = c * vkp - sn * vkq;
+                    v[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    double lmax = 0.0;
+    for (int i = 0; i < 6; i++) lmax = std::fmax(lmax, a[i][i]);
+    for (int k = 0; k < 6; k++) x[k] = 0.0;
+    for (int i = 0; i < 6; i++) {
+        if (!(a[i][i] > 1e-12 * lmax)) continue; // rank-deficient direction: the minimum-norm solution leaves it at 0
+        double proj = 0.0;
+        for (int k = 0; k < 6; k++) proj += v[k][i] * y[k];
+        for (int k = 0; k < 6; k++) x[k] += v[k][i] * proj / a[i][i];
+    }
+}
+
+static int tri(int i, int j, int n) { // index into the upper triangle (row major)
+    if (i > j) std::swap(i, j);
+    return i * n - i * (i - 1) / 2 + (j - i);
+}
+
+void fri_hip_fit_value_params(const int64_t gram[3][28], float value_params[3][6]) {
+    for (int g = 0; g < 3; g++) { // optimize_value_prediction, context_modeling.rs:175-202
+        double m[6][6], y[6], x[6];
+        for (int i = 0; i < 6; i++) {
+            y[i] = (double)gram[g][tri(i, 6, 7)];
+            for (int j = 0; j < 6; j++) m[i][j] = (double)gram[g][tri(i, j, 7)];
+        }
+        fri_hip_solve6(m, y, x);
+        for (int k = 0; k < 6; k++) value_params[g][k] = (float)x[k];
+    }
+}
+
+void fri_hip_fit_width_params(const int64_t wtw[3][21], const double wtr[3][6], const uint64_t rows[3], float width_params[3][6]) {
+    for (int g = 0; g < 3; g++) { // optimize_width_prediction, context_modeling.rs:144-173
+        double m[6][6], y[6], x[6];
+        for (int i = 0; i < 6; i++) {
+            y[i] = wtr[g][i];
+            for (int j = 0; j < 6; j++) m[i][j] = (double)wtw[g][tri(i, j, 6)];
+        }
+        m[0][0] += (double)rows[g] - (double)wtw[g][0]; // the reference's all-zero rows: constant feature 1, residual 0
+        fri_hip_solve6(m, y, x);
+        for (int k = 0; k < 6; k++) width_params[g][k] = (float)x[k];
+    }
+}
+
+/* ---- the device part of FRIEncoder::encode in one call ------------------------------------------------ */
+static int ensure_encode_staging(fri_hip_plan *p) {
+    fri_hip_ctx *c = p->ctx;
+    const size_t C = p->geo.channels, plane = p->geo.centers.size() * kCell;
+    if (!p->d_bucket_all) HIP_TRY(c, hipMalloc((void **)&p->d_bucket_all, C * plane));
+    if (!p->d_prediction_all) HIP_TRY(c, hipMalloc((void **)&p->d_prediction_all, C * plane * sizeof(int32_t)));
+    if (!p->d_hist_all) HIP_TRY(c, hipMalloc((void **)&p->d_hist_all, C * 10 * 1024 * sizeof(uint32_t)));
+    if (!p->d_oob_all) HIP_TRY(c, hipMalloc((void **)&p->d_oob_all, C * sizeof(unsigned long long)));
+    if (!p->d_sums_int) HIP_TRY(c, hipMalloc((void **)&p->d_sums_int, C * 3 * 28 * sizeof(unsigned long long)));
+    if (!p->d_sums_dbl) HIP_TRY(c, hipMalloc((void **)&p->d_sums_dbl, C * 18 * sizeof(double)));
+    return FRI_HIP_OK;
+}
+
+// prediction::encode for all channels of one image whose coefficients are in device memory (prediction.rs:224-323 minus the host's
+// ANS model): optional fit (sums on the device, solves on the host: two stream synchronisations), then K2 for every channel in one launch.
+static int predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, float *value_params, float *width_params, uint8_t *d_bucket, int32_t *d_prediction,
+                             uint32_t *d_hist, uint64_t *d_oob, bool from_forward_kernel, hipStream_t s) {
+    fri_hip_ctx *c = p->ctx;
+    if (int rc = ensure_encode_staging(p)) return rc;
+    const uint32_t C = p->geo.channels;
+    const size_t F = p->geo.centers.size(), plane = F * kCell;
+    PredBatch b;
+    b.n_planes = C;
+    b.coefs = d_coefs;
+    b.coef_stride = plane;
+    b.out_stride = plane;
+    if (fit) { // ContextModeler::optimize_parameters per channel (prediction.rs:232-235, context_modeling.rs:204-213)
+        int64_t sums[3][3][28], wtw[3][3][21];
+        double wtr[3][3][6];
+        if (int rc = fit_launch(p, 0, b, (int64_t *)p->d_sums_int, nullptr, s)) return rc;
+        HIP_TRY(c, hipMemcpyAsync(sums, p->d_sums_int, (size_t)C * 3 * 28 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        for (uint32_t ch = 0; ch < C; ch++) {
+            fri_hip_fit_value_params(sums[ch], reinterpret_cast<float(*)[6]>(value_params + ch * 18));
+            std::memcpy(b.pp[ch].value, value_params + ch * 18, sizeof(b.pp[ch].value));
+        }
+        if (int rc = fit_launch(p, 1, b, (int64_t *)p->d_sums_int, p->d_sums_dbl, s)) return rc;
+        HIP_TRY(c, hipMemcpyAsync(wtw, p->d_sums_int, (size_t)C * 3 * 21 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(wtr, p->d_sums_dbl, (size_t)C * 18 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        const uint64_t rows[3] = {F * 256, F * 128, F * 128}; // num_ctx_last_layer / num_ctx_middle_layer, context_modeling.rs:84-85
+        for (uint32_t ch = 0; ch < C; ch++) fri_hip_fit_width_params(wtw[ch], wtr[ch], rows, reinterpret_cast<float(*)[6]>(width_params + ch * 18));
+    }
+    for (uint32_t ch = 0; ch < C; ch++) {
+        std::memcpy(b.pp[ch].value, value_params + ch * 18, sizeof(b.pp[ch].value));
+        std::memcpy(b.pp[ch].width, width_params + ch * 18, sizeof(b.pp[ch].width));
+    }
+    // the scan loop of prediction::encode (prediction.rs:237-298) for every channel
+    return predict_launch(p, b, d_bucket, d_prediction, d_hist, d_oob, from_forward_kernel, s);
+}
+
+int fri_hip_encode_image_dev(fri_hip_plan *p, const uint8_t *d_pixels, const int32_t qmatrix[32], int fit, float *value_params, float *width_params, int32_t *d_coefs,
+                             uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist, uint64_t *d_n_out_of_alphabet, void *stream) {
     if (int rc = need_device(p)) return rc;
-    if (!d_coefs || !d_pixels) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    if (!d_pixels || !value_params || !width_params || !d_coefs || !d_hist || !d_n_out_of_alphabet) return FRI_HIP_ERR_INVALID_ARGUMENT;
     QMatrix q;
     if (int rc = check_q(qmatrix, q)) return rc;
-    HIP_TRY(p->ctx, launch_inverse_transform(p->dev, d_coefs, q, d_pixels, (hipStream_t)stream));
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    // wavelet_transform::encode + quantization::encode (encoder.rs:24-31): one kernel, all channels; the coefficients then stay where they are
+    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, 1, d_pixels, 0, d_coefs, 0, q, (hipStream_t)stream));
+    bool small = true; // |coefficient| <= 255 for quantisers of magnitude >= 1: the exact kernel behind K2 cannot be needed
+    return predict_image_dev(p, d_coefs, fit, value_params, width_params, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, small, (hipStream_t)stream);
+}
+
+int fri_hip_predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, float *value_params, float *width_params, uint8_t *d_bucket, int32_t *d_prediction,
+                              uint32_t *d_hist, uint64_t *d_n_out_of_alphabet, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_coefs || !value_params || !width_params || !d_hist || !d_n_out_of_alphabet) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    return predict_image_dev(p, d_coefs, fit, value_params, width_params, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, false, (hipStream_t)stream);
+}
+
+int fri_hip_predict_image(fri_hip_plan *p, const int32_t *coefs, int fit, float *value_params, float *width_params, uint8_t *bucket, int32_t *prediction, uint32_t *hist,
+                          uint64_t *n_out_of_alphabet) {
+    if (int rc = need_device(p)) return rc;
+    if (!coefs || !value_params || !width_params || !hist || !n_out_of_alphabet) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    fri_hip_ctx *c = p->ctx;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = ensure_staging(p)) return rc;
+    if (int rc = ensure_encode_staging(p)) return rc;
+    const size_t C = p->geo.channels, plane = p->geo.centers.size() * kCell;
+    HIP_TRY(c, hipMemcpy(p->d_coefs, coefs, C * plane * sizeof(int32_t), hipMemcpyHostToDevice)); // once, for the fit and the scan of every channel
+    if (int rc = predict_image_dev(p, p->d_coefs, fit, value_params, width_params, bucket ? p->d_bucket_all : nullptr, prediction ? p->d_prediction_all : nullptr, p->d_hist_all,
+                                   (uint64_t *)p->d_oob_all, false, nullptr))
+        return rc;
+    if (bucket) HIP_TRY(c, hipMemcpy(bucket, p->d_bucket_all, C * plane, hipMemcpyDeviceToHost));
+    if (prediction) HIP_TRY(c, hipMemcpy(prediction, p->d_prediction_all, C * plane * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(hist, p->d_hist_all, C * 10 * 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(n_out_of_alphabet, p->d_oob_all, C * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return FRI_HIP_OK;
+}
+
+int fri_hip_encode_image(fri_hip_plan *p, const uint8_t *pixels, const int32_t qmatrix[32], int fit, float *value_params, float *width_params, int32_t *coefs, uint8_t *bucket,
+                         int32_t *prediction, uint32_t *hist, uint64_t *n_out_of_alphabet) {
+    if (int rc = need_device(p)) return rc;
+    if (!pixels || !value_params || !width_params || !coefs || !hist || !n_out_of_alphabet) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    fri_hip_ctx *c = p->ctx;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = ensure_staging(p)) return rc;
+    if (int rc = ensure_encode_staging(p)) return rc;
+    const size_t C = p->geo.channels, plane = p->geo.centers.size() * kCell;
+    // one upload of the pixels, one download of each output; the coefficients stay on the device between the stages
+    HIP_TRY(c, hipMemcpy(p->d_pixels, pixels, fri_hip_plan_pixel_bytes(p), hipMemcpyHostToDevice));
+    if (int rc = fri_hip_encode_image_dev(p, p->d_pixels, qmatrix, fit, value_params, width_params, p->d_coefs, bucket ? p->d_bucket_all : nullptr,
+                                          prediction ? p->d_prediction_all : nullptr, p->d_hist_all, (uint64_t *)p->d_oob_all, nullptr))
+        return rc;
+    HIP_TRY(c, hipMemcpy(coefs, p->d_coefs, C * plane * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (bucket) HIP_TRY(c, hipMemcpy(bucket, p->d_bucket_all, C * plane, hipMemcpyDeviceToHost));
+    if (prediction) HIP_TRY(c, hipMemcpy(prediction, p->d_prediction_all, C * plane * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(hist, p->d_hist_all, C * 10 * 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(n_out_of_alphabet, p->d_oob_all, C * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return FRI_HIP_OK;
+}
+
+/* ---- inverse ---------------------------------------------------------------------------------- */
+int fri_hip_inverse_transform_batch_dev(fri_hip_plan *p, uint32_t n_images, const int32_t *d_coefs, size_t coef_stride, const int32_t qmatrix[32], uint8_t *d_pixels,
+                                        size_t pixel_stride, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_coefs || !d_pixels || !n_images || n_images > 65535u) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    if (n_images > 1 && (pixel_stride < fri_hip_plan_pixel_bytes(p) || coef_stride < fri_hip_plan_coef_count(p))) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    QMatrix q;
+    if (int rc = check_q(qmatrix, q)) return rc;
+    HIP_TRY(p->ctx, launch_inverse_transform(p->dev, n_images, d_coefs, coef_stride, q, d_pixels, pixel_stride, (hipStream_t)stream));
+    return FRI_HIP_OK;
+}
+
+int fri_hip_inverse_transform_dev(fri_hip_plan *p, const int32_t *d_coefs, const int32_t qmatrix[32], uint8_t *d_pixels, void *stream) {
+    return fri_hip_inverse_transform_batch_dev(p, 1, d_coefs, 0, qmatrix, d_pixels, 0, stream);
 }
 
 int fri_hip_inverse_transform(fri_hip_plan *p, const int32_t *coefs, const int32_t qmatrix[32], uint8_t *pixels) {

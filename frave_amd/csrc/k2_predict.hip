@@ -46,7 +46,11 @@ struct PredArgs {
                                // (build_pred_offsets), bytes from the own slot in the permuted 1 KiB layout for kernel3 (build_gather_tables)
     const uint16_t *pair_pos;  // [256] dword position of halfword pair q inside a 1 KiB slot (gather_layout.inc)
     const uint16_t *heap_of_pos; // [512] its inverse per halfword: heap index stored at halfword position i
-    uint32_t *inexact;         // plan scratch: set when a staged value does not fit the LDS image (the exact kernel then redoes the plane)
+    uint32_t *inexact;         // (set per plane by the kernel: acc + kAccInexact) raised when a staged value does not fit the LDS image; the exact kernel then redoes the plane
+    // planes of a batch (grid.y): plane k reads coefs + k * coef_stride, writes bucket / prediction + k * out_stride, hist + k * 10 * 1024, n_oob + k,
+    // hands over through acc + k * kPredAccWords and takes its parameters from params[k] (NULL: pp)
+    size_t coef_stride, out_stride;
+    const PredictParams *params;
     int32_t ablate;            // timing-only (tuning build, FRI_HIP_K2_ABLATE): 1 = no predict phase (zeros are stored), 2 = tiles after the first are not staged,
                                // 4 = no histogram update, 8 = no bucket-table read, 16 = no gathers, 32 = no output stores
     const uint8_t *interior;   // [F]
@@ -59,14 +63,15 @@ struct PredArgs {
     unsigned long long *trace; // diagnostic timeline, null in production
     uint32_t *acc;             // plan scratch, all zero between launches: [kHistBins] counts, then kAccOob (u64), kAccTicket
     uint32_t n_tiles;
-    PredictParams pp;
+    PredictParams pp;     // this plane's parameters (filled per plane inside the kernel)
+    PredictParams pp3[3]; // plane k < 3 of a launch without a params array
 };
 
 // Histogram hand-over without a memset in front of the kernel (two fill kernels cost ~6 us per call): every workgroup adds
 // its LDS table into the plan's accumulator, then takes a ticket; the workgroup that draws the last ticket moves the totals to
 // the caller's arrays with atomic exchanges, which leaves the accumulator zero for the next launch.
-constexpr int kAccOob = kHistBins, kAccTicket = kHistBins + 2;
-static_assert(kHistBins + 4 == (int)kPredAccWords, "accumulator layout");
+constexpr int kAccOob = kHistBins, kAccTicket = kHistBins + 2, kAccInexact = kHistBins + 4; // + the exact kernel's ticket at kAccInexact + 1
+static_assert(kHistBins + 8 == (int)kPredAccWords, "accumulator layout");
 __device__ __forceinline__ void pred_hand_over(const PredArgs &a, const uint32_t *s_hist, uint32_t *s_flag, int tid, int n_threads) {
     for (int i = tid; i < kHistBins; i += n_threads) {
         const uint32_t c = s_hist[i];
@@ -389,6 +394,7 @@ struct P3Lds { // static LDS: every address below is a compile-time constant tha
 };
 static_assert(sizeof(P3Lds) <= 160 * 1024 && kP3ImageBytes + kP3SlotBytes < 65536, "LDS budget / image + cell offset must fit a DS instruction's 16-bit offset field");
 constexpr int kP3Halo = kPredSlots - kPredBlock * kPredBlock;  // 20 halo slots: one whole cell per wave + a quarter of one of the last four
+static_assert(kP3Halo == kP3Waves + kP3Waves / 4, "halo staging: a whole cell per wave, the remaining cells in quarters");
 
 // h-th halo slot of a tile (h < 20): top row, bottom row, left column, right column
 __device__ __forceinline__ int p3_halo_slot(int h) {
@@ -598,13 +604,28 @@ struct ExactArgs {
     int32_t *prediction;
     uint32_t *hist;
     unsigned long long *n_oob;
-    uint32_t *inexact; // [0] flag, [1] ticket
+    uint32_t *acc;     // plane k's flag and ticket sit at acc + k * kPredAccWords + kAccInexact, + 1
     uint32_t F;
     PredictParams pp;
+    size_t coef_stride, out_stride; // planes of a batch, as in PredArgs
+    const PredictParams *params;
+    PredictParams pp3[3]; // plane k < 3 of a launch without a params array
 };
-__global__ void __launch_bounds__(kCell) exact_predict_kernel(const ExactArgs a) {
+__global__ void __launch_bounds__(kCell) exact_predict_kernel(const ExactArgs a0) {
+    ExactArgs a = a0;
+    {
+        const uint32_t plane = blockIdx.y;
+        a.coefs += plane * a0.coef_stride;
+        if (a.bucket) a.bucket += plane * a0.out_stride;
+        if (a.prediction) a.prediction += plane * a0.out_stride;
+        a.hist += (size_t)plane * kHistBins;
+        a.n_oob += plane;
+        a.acc += (size_t)plane * kPredAccWords;
+        a.pp = a0.params ? a0.params[plane] : a0.pp3[plane < 3 ? plane : 2];
+    }
+    uint32_t *const inexact = a.acc + kAccInexact;
     __shared__ uint32_t s_go;
-    if (threadIdx.x == 0) s_go = __hip_atomic_load(a.inexact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) s_go = __hip_atomic_load(inexact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_go == 0) return;
     const int p = threadIdx.x;
@@ -658,9 +679,9 @@ __global__ void __launch_bounds__(kCell) exact_predict_kernel(const ExactArgs a)
     }
     // the last block to finish lowers the flag for the next launch
     __syncthreads();
-    if (threadIdx.x == 0 && __hip_atomic_fetch_add(a.inexact + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-        __hip_atomic_store(a.inexact + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.inexact, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(inexact + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        __hip_atomic_store(inexact + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(inexact, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -920,7 +941,21 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
     }
 }
 
-__global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const PredArgs a) {
+__device__ __forceinline__ PredArgs pred_plane_view(const PredArgs &a0, uint32_t plane) {
+    PredArgs a = a0;
+    a.coefs += plane * a0.coef_stride;
+    if (a.bucket) a.bucket += plane * a0.out_stride;
+    if (a.prediction) a.prediction += plane * a0.out_stride;
+    a.hist += (size_t)plane * kHistBins;
+    a.n_oob += plane;
+    a.acc += (size_t)plane * kPredAccWords;
+    a.inexact = a.acc + kAccInexact;
+    a.pp = a0.params ? a0.params[plane] : a0.pp3[plane < 3 ? plane : 2];
+    return a;
+}
+
+__global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const PredArgs a0) {
+    const PredArgs a = pred_plane_view(a0, blockIdx.y);
     __shared__ __attribute__((aligned(16))) P3Lds lds;
     uint32_t *s_hist = lds.hist;
     uint8_t *s_cells = lds.cells[0];
@@ -985,13 +1020,17 @@ void build_gather_tables(const uint16_t *nbr_table, uint32_t *gather_off /* [512
     }
 }
 
-hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t acc_slot, const int32_t *coefs_channel, const PredictParams &pp, uint8_t *bucket,
-                                    int32_t *prediction, uint32_t *hist, unsigned long long *n_oob, bool from_forward_kernel, hipStream_t stream) {
-    if (!p.pred_acc || acc_slot >= kPredAccRing) return hipErrorInvalidValue;
+hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const PredBatch &b, uint8_t *bucket, int32_t *prediction, uint32_t *hist, unsigned long long *n_oob,
+                                    bool from_forward_kernel, hipStream_t stream) {
+    if (!acc || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     PredArgs a{};
-    a.acc = p.pred_acc + (size_t)acc_slot * kPredAccWords;
-    a.coefs = coefs_channel;
+    a.acc = acc;
+    a.coefs = b.coefs;
+    a.coef_stride = b.coef_stride;
+    a.out_stride = b.out_stride;
+    a.params = b.params;
+    for (int k = 0; k < 3; k++) a.pp3[k] = b.pp[k];
     a.pred_slots = p.pred_slots;
     a.nbr_table = p.nbr_table;
     a.pred_off = p.pred_off;
@@ -1002,13 +1041,20 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t acc_slot, cons
     a.hist = hist;
     a.n_oob = n_oob;
     a.n_tiles = p.n_pred_tiles;
-    a.pp = pp;
+    // One plane: a workgroup per CU. Many planes: a plane keeps an eighth of the machine busy (at least ~8 tiles per workgroup, so that
+    // the start-up and the hand-over are paid once per 8 tiles) and eight planes run side by side.
     uint32_t blocks = p.n_pred_tiles < p.pred_blocks ? p.n_pred_tiles : p.pred_blocks;
+    if (b.n_planes > 1) {
+        const uint32_t share = (p.n_pred_tiles + 7) / 8, eighth = p.pred_blocks / 8 ? p.pred_blocks / 8 : 1;
+        blocks = share < eighth ? eighth : share;
+        if (blocks > p.pred_blocks) blocks = p.pred_blocks;
+        if (blocks > p.n_pred_tiles) blocks = p.n_pred_tiles;
+    }
     if (!blocks) blocks = 1;
     a.junk = p.junk;
     a.trace = p.trace;
-    if (p.k2_previous) { // FRI_HIP_TUNING=1 FRI_HIP_K2_PREVIOUS=1: the pipelined kernel of round 1 (A/B on one box); needs both outputs
-        if (!bucket || !prediction) return hipErrorInvalidValue;
+    if (p.k2_previous) { // FRI_HIP_TUNING=1 FRI_HIP_K2_PREVIOUS=1: the pipelined kernel of round 1 (A/B on one box); one plane, both outputs
+        if (!bucket || !prediction || b.n_planes != 1) return hipErrorInvalidValue;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(predict_histogram_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, kPred2LdsBytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(predict_histogram_kernel2, dim3(blocks), dim3(kPred2Threads), kPred2LdsBytes, stream, a);
@@ -1017,13 +1063,16 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t acc_slot, cons
     a.pred_off = p.gather_off;
     a.pair_pos = p.pair_pos;
     a.heap_of_pos = p.heap_of_pos;
-    a.inexact = p.inexact;
     a.ablate = p.k2_ablate;
-    hipLaunchKernelGGL(predict_histogram_kernel3, dim3(blocks), dim3(kP3Threads), 0, stream, a);
+    hipLaunchKernelGGL(predict_histogram_kernel3, dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess || from_forward_kernel) return e; // the forward kernel's coefficients are differences of 8-bit pixels divided by a quantiser: always representable
     ExactArgs x{};
-    x.coefs = coefs_channel;
+    x.coefs = b.coefs;
+    x.coef_stride = b.coef_stride;
+    x.out_stride = b.out_stride;
+    x.params = b.params;
+    for (int k = 0; k < 3; k++) x.pp3[k] = b.pp[k];
     x.nbr_table = p.nbr_table;
     x.nbr_cells = p.nbr_cells;
     x.interior = p.interior;
@@ -1032,11 +1081,10 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t acc_slot, cons
     x.prediction = prediction;
     x.hist = hist;
     x.n_oob = n_oob;
-    x.inexact = p.inexact;
+    x.acc = acc;
     x.F = p.F;
-    x.pp = pp;
-    const uint32_t xb = p.F < p.pred_blocks ? p.F : p.pred_blocks;
-    hipLaunchKernelGGL(exact_predict_kernel, dim3(xb ? xb : 1), dim3(kCell), 0, stream, x);
+    const uint32_t xb = p.F < blocks ? p.F : blocks;
+    hipLaunchKernelGGL(exact_predict_kernel, dim3(xb ? xb : 1, b.n_planes), dim3(kCell), 0, stream, x);
     return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@ constexpr int kInvMaxItemsPerWave = 4; // (cell, channel) items of one tile per 
 struct InvArgs {
     const int32_t *coefs;
     uint8_t *pixels;
+    size_t coef_stride, pixel_stride; // images of a batch (grid.y): image k at coefs + k * coef_stride (elements), pixels + k * pixel_stride (bytes)
     const Tile *tiles;
     const TileCell *tile_meta; // in tile order
     const int32_t *wg_tiles;   // [n_wg + 1]
@@ -150,7 +151,10 @@ __device__ __forceinline__ InvTileLists scalar_lists(const InvTileLists &l) {
 }
 
 template <int NI>
-__global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const InvArgs a) {
+__global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const InvArgs a0) {
+    InvArgs a = a0;
+    a.coefs += blockIdx.y * a0.coef_stride;
+    a.pixels += blockIdx.y * a0.pixel_stride;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint16_t *img16 = reinterpret_cast<uint16_t *>(lds);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -304,7 +308,10 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
 // width * channels multiples of 16): the launcher falls back to inverse_transform_kernel otherwise.
 constexpr int kInvListPre = 3; // list entries a thread holds in flight per list and tile (more are loaded on demand)
 template <int NI>
-__global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(const InvArgs a) {
+__global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(const InvArgs a0) {
+    InvArgs a = a0;
+    a.coefs += blockIdx.y * a0.coef_stride;
+    a.pixels += blockIdx.y * a0.pixel_stride;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *img = lds;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -431,16 +438,22 @@ static size_t inv_queue_bytes(const DevicePlan &p) {
     return (((quads + kInvThreads - 1) / kInvThreads) * 64 * 2 + 15) & ~(size_t)15;
 }
 size_t inv_lds_bytes(const DevicePlan &p) { return inv_buf_bytes(p) + kInvWaves * inv_queue_bytes(p) + (size_t)p.max_wg_tiles * sizeof(Tile) + (size_t)p.max_wg_cells * sizeof(TileCell); }
-hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, const QMatrix &q, uint8_t *pixels, hipStream_t stream) {
+hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, const int32_t *coefs, size_t coef_stride, const QMatrix &q, uint8_t *pixels, size_t pixel_stride,
+                                    hipStream_t stream) {
+    if (!n_images || n_images > 65535u) return hipErrorInvalidValue;
     // RasterImage::from_wavelet starts from an all-zero raster (wavelet_transform.rs:309-317). When every pixel belongs to a
     // retained cell the kernel writes all of them (zeros included); only a lattice with holes (very thin images) needs the fill.
     if (!p.covers_image) {
-        hipError_t e = hipMemsetAsync(pixels, 0, (size_t)p.width * p.height * p.channels, stream);
-        if (e != hipSuccess) return e;
+        for (uint32_t k = 0; k < n_images; k++) {
+            hipError_t e = hipMemsetAsync(pixels + k * pixel_stride, 0, (size_t)p.width * p.height * p.channels, stream);
+            if (e != hipSuccess) return e;
+        }
     }
     InvArgs a{};
     a.coefs = coefs;
     a.pixels = pixels;
+    a.coef_stride = coef_stride;
+    a.pixel_stride = pixel_stride;
     a.tiles = p.tiles;
     a.tile_meta = p.tile_meta;
     a.wg_tiles = p.wg_tiles;
@@ -460,7 +473,8 @@ hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, c
     const int items_per_wave = (p.max_tile_cells * p.channels + kInvWaves - 1) / kInvWaves;
     if (items_per_wave > kInvMaxItemsPerWave || p.max_wg_tiles > kInvThreads || p.lds_rows > 256 || p.lds_pitch / 16 > 256) return hipErrorInvalidConfiguration;
     // static write-out lists when every image row starts 16-byte aligned
-    const bool lists = p.inv_lists && !p.k3_scan && (reinterpret_cast<uintptr_t>(pixels) & 15) == 0 && (((size_t)p.width * p.channels) & 15) == 0;
+    const bool lists = p.inv_lists && !p.k3_scan && (reinterpret_cast<uintptr_t>(pixels) & 15) == 0 && (((size_t)p.width * p.channels) & 15) == 0 &&
+                       (n_images == 1 || (pixel_stride & 15) == 0);
     if (lists) {
         a.lists = p.inv_lists;
         a.quads = p.inv_quads;
@@ -473,7 +487,7 @@ hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, c
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k2, dim3(p.n_wg), dim3(kInvThreads), lds2, stream, a);
+        hipLaunchKernelGGL(k2, dim3(p.n_wg, n_images), dim3(kInvThreads), lds2, stream, a);
         return hipGetLastError();
     }
     const size_t lds = inv_lds_bytes(p);
@@ -482,7 +496,7 @@ hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, c
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(p.n_wg), dim3(kInvThreads), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(p.n_wg, n_images), dim3(kInvThreads), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -29,13 +29,28 @@ struct FitArgs {
     unsigned long long *wtw;  // [3][21]   (MODE 1)
     double *wtr;              // [3][6]    (MODE 1)
     unsigned long long *acc;  // plan scratch, all zero between launches: [kFitAccInt] integer sums, [18] f64 bit patterns, then the ticket
+    // planes of a batch (grid.y): plane k reads coefs + k * coef_stride, takes its parameters from params[k] (NULL: pp), hands over through
+    // acc + k * kFitAccWords and writes gram / wtw + k * 3 * NI, wtr + k * 18
+    size_t coef_stride;
+    const PredictParams *params;
+    PredictParams pp3[3]; // plane k < 3 of a launch without a params array
 };
 constexpr int kFitAccInt = 3 * 28, kFitAccDbl = kFitAccInt, kFitAccTicket = kFitAccInt + 18;
 static_assert(kFitAccTicket + 1 == (int)kFitAccWords, "fit accumulator layout");
 
 template <int MODE>
-__global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const FitArgs a) {
+__global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const FitArgs a0) {
     constexpr int NI = MODE == 0 ? 28 : 21;
+    FitArgs a = a0;
+    {
+        const uint32_t plane = blockIdx.y;
+        a.coefs += plane * a0.coef_stride;
+        a.acc += (size_t)plane * kFitAccWords;
+        if (a.gram) a.gram += (size_t)plane * 3 * NI;
+        if (a.wtw) a.wtw += (size_t)plane * 3 * NI;
+        if (a.wtr) a.wtr += (size_t)plane * 18;
+        a.pp = a0.params ? a0.params[plane] : a0.pp3[plane < 3 ? plane : 2];
+    }
     __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
     __shared__ int32_t s_slot_cell[kPredSlots];
     __shared__ int32_t s_slot_interior[kPredSlots];
@@ -224,28 +239,35 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
 
 } // namespace
 
-hipError_t launch_fit_accumulate(const DevicePlan &p, uint32_t acc_slot, int mode, const int32_t *coefs_channel, const PredictParams &pp, unsigned long long *sums_int,
-                                 double *sums_dbl, hipStream_t stream) {
-    if (!p.fit_acc || acc_slot >= kPredAccRing) return hipErrorInvalidValue;
+hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl, hipStream_t stream) {
+    if (!acc || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
     FitArgs a{};
-    a.coefs = coefs_channel;
+    a.coefs = b.coefs;
+    a.coef_stride = b.coef_stride;
+    a.params = b.params;
+    for (int k = 0; k < 3; k++) a.pp3[k] = b.pp[k];
     a.pred_slots = p.pred_slots;
     a.nbr_table = p.nbr_table;
     a.pred_off = p.pred_off;
     a.interior = p.interior;
     a.valid_mask = p.valid_mask;
     a.n_tiles = p.n_pred_tiles;
-    a.pp = pp;
-    a.acc = p.fit_acc + (size_t)acc_slot * kFitAccWords;
+    a.acc = acc;
     a.gram = sums_int;
     a.wtw = sums_int;
     a.wtr = sums_dbl;
     uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
+    if (b.n_planes > 1) { // as in launch_predict_histogram: a plane on an eighth of the machine, eight planes side by side
+        const uint32_t share = (p.n_pred_tiles + 7) / 8, eighth = p.hist_blocks / 8 ? p.hist_blocks / 8 : 1;
+        blocks = share < eighth ? eighth : share;
+        if (blocks > p.hist_blocks) blocks = p.hist_blocks;
+        if (blocks > p.n_pred_tiles) blocks = p.n_pred_tiles;
+    }
     if (!blocks) blocks = 1;
     if (mode == 0)
-        hipLaunchKernelGGL(fit_accumulate_kernel<0>, dim3(blocks), dim3(kPredThreads), 0, stream, a);
+        hipLaunchKernelGGL(fit_accumulate_kernel<0>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
     else
-        hipLaunchKernelGGL(fit_accumulate_kernel<1>, dim3(blocks), dim3(kPredThreads), 0, stream, a);
+        hipLaunchKernelGGL(fit_accumulate_kernel<1>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -36,10 +36,7 @@ struct DevicePlan {
     uint32_t *hist_partial = nullptr;     // [hist_blocks][10*1024] scratch for the histogram reduction
     unsigned long long *oob_partial = nullptr; // [hist_blocks]
     uint32_t hist_blocks = 0;
-    uint32_t *inexact = nullptr;          // [2] flag + ticket: K2's fast kernel met a value its LDS image cannot hold; zero between launches
     uint8_t *junk = nullptr;              // [pred_blocks][kPredJunkWaves][kPredJunkBytes]: output lines of block slots without a cell (pipelined K2)
-    uint32_t *pred_acc = nullptr;         // [kPredAccRing][kPredAccWords] K2 histogram accumulators, all zero between launches
-    unsigned long long *fit_acc = nullptr; // [kPredAccRing][kFitAccWords] fit-sum accumulators, all zero between launches
     uint32_t pred_blocks = 0;             // workgroups of the pipelined K2: one 1024-thread workgroup per CU
     bool k2_previous = false;             // tuning: round 1's pipelined K2 (A/B)
     uint32_t n_tiles = 0;
@@ -61,7 +58,7 @@ struct DevicePlan {
 
 constexpr uint32_t kPredJunkWaves = 16, kPredJunkBytes = 2560; // per wave: 512 B of bucket + 2 KiB of prediction
 constexpr uint32_t kFitAccWords = 3 * 28 + 18 + 1;
-constexpr uint32_t kPredAccRing = 8, kPredAccWords = 10 * 1024 + 4;
+constexpr uint32_t kPredAccRing = 8, kPredAccWords = 10 * 1024 + 8; // per plane: counts, out-of-alphabet count (u64), ticket, pad, "inexact" flag, the exact kernel's ticket, pad
 
 struct QMatrix {
     int32_t q[32];
@@ -77,15 +74,27 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
                                       size_t coef_stride, const QMatrix &q, hipStream_t stream);
 // K2: neighbour gather + bucket/prediction + LDS histogram, then the partial-histogram reduction.
 // acc_slot < kPredAccRing selects the plan accumulator the launch hands its sums over through (one per stream, fri_hip.cpp).
+// The planes (image x channel) one K2 / K4 launch works on: plane k reads coefs + k * coef_stride (int32 elements) and writes its
+// per-node outputs at + k * out_stride (elements); params is a DEVICE array of per-plane parameters or NULL (then pp for all).
+struct PredBatch {
+    uint32_t n_planes = 1;
+    const int32_t *coefs = nullptr;
+    size_t coef_stride = 0, out_stride = 0;
+    const PredictParams *params = nullptr;
+    PredictParams pp[3] = {}; // used when params is NULL: plane k takes pp[min(k, 2)] (one image's channels travel as kernel arguments)
+};
+// K2. acc: n_planes accumulators of kPredAccWords words, all zero between launches. hist [n_planes][10][1024], n_oob [n_planes].
 // from_forward_kernel: the coefficients are this library's forward kernel's output (magnitudes <= 255): the exact int32 kernel that
 // backs the fast one up for arbitrary arrays is not enqueued.
-hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t acc_slot, const int32_t *coefs_channel, const PredictParams &pp, uint8_t *bucket,
-                                    int32_t *prediction, uint32_t *hist, unsigned long long *n_oob, bool from_forward_kernel, hipStream_t stream);
-// Fit accumulators: mode 0 = value fit (sums_int[3][28]), mode 1 = width fit (sums_int[3][21], sums_dbl[3][6]).
-hipError_t launch_fit_accumulate(const DevicePlan &p, uint32_t acc_slot, int mode, const int32_t *coefs_channel, const PredictParams &pp, unsigned long long *sums_int,
-                                 double *sums_dbl, hipStream_t stream);
+hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const PredBatch &b, uint8_t *bucket, int32_t *prediction, uint32_t *hist, unsigned long long *n_oob,
+                                    bool from_forward_kernel, hipStream_t stream);
+// Fit accumulators: mode 0 = value fit (sums_int[n_planes][3][28]), mode 1 = width fit (sums_int[n_planes][3][21], sums_dbl[n_planes][3][6]).
+// acc: n_planes accumulators of kFitAccWords words, all zero between launches.
+hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl, hipStream_t stream);
 // K3: (reference-faithful) dequantisation + inverse transform + clamp.
-hipError_t launch_inverse_transform(const DevicePlan &p, const int32_t *coefs, const QMatrix &q, uint8_t *pixels, hipStream_t stream);
+// n_images images of the plan's shape: image k at coefs + k * coef_stride (int32 elements), pixels + k * pixel_stride (bytes)
+hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, const int32_t *coefs, size_t coef_stride, const QMatrix &q, uint8_t *pixels, size_t pixel_stride,
+                                    hipStream_t stream);
 
 // K2's per-node neighbour offsets (LDS halfword offsets relative to the own slot, two per word) from the static neighbour table
 void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out /* [512][4] */);

@@ -155,7 +155,7 @@ static int encode_image_to_file(std::vector<uint8_t> img, uint32_t w, uint32_t h
         std::vector<uint16_t> want, got;
         std::vector<uint8_t> buckets;
         libfri::emit::channel_symbols(order, st.value.image.coefficients.data() + ch * plane,
-                                      st.value.image.bucket[ch].data(), st.value.image.prediction[ch].data(), want, buckets);
+                                      st.value.image.bucket_of(ch), st.value.image.prediction_of(ch), want, buckets);
         err = libfri::emit::decode_symbols(parsed.channels[ch], buckets, got);
         if (err.empty() && got != want) err = "decoded symbols differ";
     }

@@ -41,50 +41,8 @@ fri_hip_plan *Device::plan(uint32_t width, uint32_t height, uint32_t channels, s
 }
 
 std::array<double, 6> ContextModeler::solve_normal_equations(const double (&m)[6][6], const double (&y)[6]) {
-    // cyclic Jacobi: a = V diag(lam) V^T
-    double a[6][6], v[6][6];
-    for (int i = 0; i < 6; i++)
-        for (int j = 0; j < 6; j++) {
-            a[i][j] = m[i][j];
-            v[i][j] = i == j ? 1.0 : 0.0;
-        }
-    for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0.0;
-        for (int i = 0; i < 6; i++)
-            for (int j = i + 1; j < 6; j++) off += a[i][j] * a[i][j];
-        if (off < 1e-300) break;
-        for (int p = 0; p < 6; p++)
-            for (int q = p + 1; q < 6; q++) {
-                if (std::fabs(a[p][q]) < 1e-300) continue;
-                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < 6; k++) {
-                    const double akp = a[k][p], akq = a[k][q];
-                    a[k][p] = c * akp - s * akq;
-                    a[k][q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < 6; k++) {
-                    const double apk = a[p][k], aqk = a[q][k];
-                    a[p][k] = c * apk - s * aqk;
-                    a[q][k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < 6; k++) {
-                    const double vkp = v[k][p], vkq = v[k][q];
-                    v[k][p] = c * vkp - s * vkq;
-                    v[k][q] = s * vkp + c * vkq;
-                }
-            }
-    }
-    double lmax = 0.0;
-    for (int i = 0; i < 6; i++) lmax = std::fmax(lmax, a[i][i]);
     std::array<double, 6> x{};
-    for (int i = 0; i < 6; i++) {
-        if (!(a[i][i] > 1e-12 * lmax)) continue; // rank-deficient direction: minimum-norm solution leaves it at 0
-        double proj = 0.0;
-        for (int k = 0; k < 6; k++) proj += v[k][i] * y[k];
-        for (int k = 0; k < 6; k++) x[k] += v[k][i] * proj / a[i][i];
-    }
+    fri_hip_solve6(m, y, x.data());
     return x;
 }
 
@@ -93,26 +51,14 @@ Result<bool> ContextModeler::optimize_parameters(const WaveletImage &image, uint
     const uint32_t c = num_channels(image.metadata.colorspace);
     fri_hip_plan *plan = dev.plan(image.metadata.width, image.metadata.height, c, r.error);
     if (!plan) return r;
-    auto at = [](int i, int j, int n) { // index into the upper triangle (row major)
-        if (i > j) std::swap(i, j);
-        return i * n - i * (i - 1) / 2 + (j - i);
-    };
     int64_t gram[3][28];
     int rc = fri_hip_fit_value_sums(plan, image.coefficients.data(), channel, gram);
     if (rc != FRI_HIP_OK) {
         r.error = dev.describe(rc);
         return r;
     }
-    float vp[3][6];
-    for (int g = 0; g < 3; g++) { // optimize_value_prediction, context_modeling.rs:175-202
-        double m[6][6], y[6];
-        for (int i = 0; i < 6; i++) {
-            y[i] = (double)gram[g][at(i, 6, 7)];
-            for (int j = 0; j < 6; j++) m[i][j] = (double)gram[g][at(i, j, 7)];
-        }
-        const auto x = solve_normal_equations(m, y);
-        for (int k = 0; k < 6; k++) value_predictors[channel][g][k] = vp[g][k] = (float)x[k];
-    }
+    float vp[3][6], wp[3][6];
+    fri_hip_fit_value_params(gram, vp); // optimize_value_prediction, context_modeling.rs:175-202
     int64_t wtw[3][21];
     double wtr[3][6];
     uint64_t rows[3];
@@ -121,16 +67,9 @@ Result<bool> ContextModeler::optimize_parameters(const WaveletImage &image, uint
         r.error = dev.describe(rc);
         return r;
     }
-    for (int g = 0; g < 3; g++) { // optimize_width_prediction, context_modeling.rs:144-173
-        double m[6][6], y[6];
-        for (int i = 0; i < 6; i++) {
-            y[i] = wtr[g][i];
-            for (int j = 0; j < 6; j++) m[i][j] = (double)wtw[g][at(i, j, 6)];
-        }
-        m[0][0] += (double)rows[g] - (double)wtw[g][0]; // the reference's all-zero rows: constant feature 1, residual 0
-        const auto x = solve_normal_equations(m, y);
-        for (int k = 0; k < 6; k++) width_predictors[channel][g][k] = (float)x[k];
-    }
+    fri_hip_fit_width_params(wtw, wtr, rows, wp); // optimize_width_prediction, context_modeling.rs:144-173
+    for (int g = 0; g < 3; g++)
+        for (int k = 0; k < 6; k++) value_predictors[channel][g][k] = vp[g][k], width_predictors[channel][g][k] = wp[g][k];
     r.ok = r.value = true;
     return r;
 }
@@ -199,43 +138,49 @@ Result<WaveletImage> encode(WaveletImage image) {
 } // namespace quantization
 
 namespace prediction {
+static void contexts_from_hist(const std::vector<uint32_t> &hist, uint32_t channels, std::array<std::vector<AnsContext>, 3> &out) {
+    for (uint32_t ch = 0; ch < channels; ch++) {
+        out[ch].resize(CONTEXT_AMOUNT);
+        for (int b = 0; b < CONTEXT_AMOUNT; b++)
+            for (int s = 0; s < ALPHABET_SIZE; s++) out[ch][b].freqs[s] = hist[((size_t)ch * CONTEXT_AMOUNT + b) * ALPHABET_SIZE + s];
+    }
+}
+static void params_to_flat(const EncoderOpts &opts, uint32_t channels, float (&vp)[3][3][6], float (&wp)[3][3][6]) {
+    for (uint32_t ch = 0; ch < channels; ch++)
+        for (int g = 0; g < 3; g++)
+            for (int k = 0; k < 6; k++) vp[ch][g][k] = opts.value_prediction_params[ch][g][k], wp[ch][g][k] = opts.width_prediction_params[ch][g][k];
+}
+static void params_from_flat(EncoderOpts &opts, uint32_t channels, const float (&vp)[3][3][6], const float (&wp)[3][3][6]) {
+    for (uint32_t ch = 0; ch < channels; ch++)
+        for (int g = 0; g < 3; g++)
+            for (int k = 0; k < 6; k++) opts.value_prediction_params[ch][g][k] = vp[ch][g][k], opts.width_prediction_params[ch][g][k] = wp[ch][g][k];
+}
+
+// One upload of the coefficients, then the fit and the scan of every channel on the device (fri_hip_predict_image).
 Result<std::array<std::vector<AnsContext>, 3>> encode(WaveletImage &image, EncoderOpts &opts, Device &dev) {
     Result<std::array<std::vector<AnsContext>, 3>> r;
-    ContextModeler ctx_mod;
     const uint32_t c = num_channels(image.metadata.colorspace);
     fri_hip_plan *plan = dev.plan(image.metadata.width, image.metadata.height, c, r.error);
     if (!plan) return r;
-    const size_t n = (size_t)image.num_cells * FRI_HIP_CELL_SIZE;
-    std::vector<uint32_t> hist((size_t)CONTEXT_AMOUNT * ALPHABET_SIZE);
-    for (uint32_t ch = 0; ch < c; ch++) {
-        if (opts.fit_parameters) { // prediction.rs:232-235
-            auto fit = ctx_mod.optimize_parameters(image, ch, dev);
-            if (!fit.ok) {
-                r.error = fit.error;
-                return r;
-            }
-            opts.value_prediction_params[ch] = ctx_mod.value_predictors[ch];
-            opts.width_prediction_params[ch] = ctx_mod.width_predictors[ch];
-        }
-        image.bucket[ch].resize(n);
-        image.prediction[ch].resize(n);
-        uint64_t oob = 0;
-        int rc = fri_hip_predict_histogram(plan, image.coefficients.data(), ch,
-                                           reinterpret_cast<const float(*)[6]>(opts.value_prediction_params[ch].data()),
-                                           reinterpret_cast<const float(*)[6]>(opts.width_prediction_params[ch].data()), image.bucket[ch].data(),
-                                           image.prediction[ch].data(), hist.data(), &oob);
-        if (rc != FRI_HIP_OK) {
-            r.error = dev.describe(rc);
-            return r;
-        }
-        if (oob) { // the reference panics here: index out of bounds in bump_freq (entropy_coding.rs:99)
-            r.error = "symbol outside the 1024-entry alphabet";
-            return r;
-        }
-        r.value[ch].resize(CONTEXT_AMOUNT);
-        for (int b = 0; b < CONTEXT_AMOUNT; b++)
-            for (int s = 0; s < ALPHABET_SIZE; s++) r.value[ch][b].freqs[s] = hist[(size_t)b * ALPHABET_SIZE + s];
+    const size_t n = image.plane();
+    std::vector<uint32_t> hist((size_t)c * CONTEXT_AMOUNT * ALPHABET_SIZE);
+    image.bucket.resize(c * n);
+    image.prediction.resize(c * n);
+    float vp[3][3][6], wp[3][3][6];
+    params_to_flat(opts, c, vp, wp);
+    uint64_t oob[3] = {0, 0, 0};
+    const int rc = fri_hip_predict_image(plan, image.coefficients.data(), opts.fit_parameters ? 1 : 0, &vp[0][0][0], &wp[0][0][0], image.bucket.data(), image.prediction.data(),
+                                         hist.data(), oob);
+    if (rc != FRI_HIP_OK) {
+        r.error = dev.describe(rc);
+        return r;
     }
+    params_from_flat(opts, c, vp, wp);
+    if (oob[0] | oob[1] | oob[2]) { // the reference panics here: index out of bounds in bump_freq (entropy_coding.rs:99)
+        r.error = "symbol outside the 1024-entry alphabet";
+        return r;
+    }
+    contexts_from_hist(hist, c, r.value);
     r.ok = true;
     return r;
 }
@@ -250,16 +195,33 @@ Result<EncodedStages> FRIEncoder::encode(std::vector<uint8_t> data, uint32_t hei
     };
     Device dev(opts_.device);
     if (!dev.ok()) return fail(dev.error());
-    RasterImage image{ImageMetadata{height, width, colorspace}, std::move(data)};
-    // RawImage -> ChannelTransform (identity, channel_transform.rs:4-10) -> WaveletTransform -> Quantization -> Prediction
-    auto w = stages::wavelet_transform::encode(image, opts_, dev);
-    if (!w.ok) return fail(w.error);
-    auto q = stages::quantization::encode(std::move(w.value));
-    if (!q.ok) return fail(q.error);
-    auto p = stages::prediction::encode(q.value, opts_, dev);
-    if (!p.ok) return fail(p.error);
-    r.value.image = std::move(q.value);
-    r.value.contexts = std::move(p.value);
+    const uint32_t c = num_channels(colorspace);
+    if (data.size() != (size_t)width * height * c) return fail("raster size does not match its metadata");
+    std::string err;
+    fri_hip_plan *plan = dev.plan(width, height, c, err);
+    if (!plan) return fail(err);
+    // RawImage -> ChannelTransform (identity, channel_transform.rs:4-10) -> WaveletTransform -> Quantization -> Prediction (encoder.rs:19-38) as
+    // ONE device-resident call: the pixels go up once, the coefficients stay in device memory between the stages, every output comes down once.
+    WaveletImage &w = r.value.image;
+    w.metadata = ImageMetadata{height, width, colorspace};
+    w.num_cells = fri_hip_plan_num_cells(plan);
+    w.centers.resize((size_t)w.num_cells * 2);
+    w.coefficients.resize(fri_hip_plan_coef_count(plan));
+    w.bucket.resize(c * w.plane());
+    w.prediction.resize(c * w.plane());
+    std::vector<uint32_t> hist((size_t)c * CONTEXT_AMOUNT * ALPHABET_SIZE);
+    float vp[3][3][6], wp[3][3][6];
+    stages::prediction::params_to_flat(opts_, c, vp, wp);
+    uint64_t oob[3] = {0, 0, 0};
+    int rc = fri_hip_plan_centers(plan, w.centers.data());
+    if (rc == FRI_HIP_OK)
+        rc = fri_hip_encode_image(plan, data.data(), opts_.quantization_matrix.data(), opts_.fit_parameters ? 1 : 0, &vp[0][0][0], &wp[0][0][0], w.coefficients.data(),
+                                  w.bucket.data(), w.prediction.data(), hist.data(), oob);
+    if (rc != FRI_HIP_OK) return fail(dev.describe(rc));
+    w.quantized = true;
+    stages::prediction::params_from_flat(opts_, c, vp, wp);
+    if (oob[0] | oob[1] | oob[2]) return fail("symbol outside the 1024-entry alphabet"); // the reference panics: bump_freq, entropy_coding.rs:99
+    stages::prediction::contexts_from_hist(hist, c, r.value.contexts);
     r.ok = true;
     return r;
 }
@@ -271,8 +233,10 @@ Result<CompressedImage> stages::entropy_coding::encode(const WaveletImage &image
     r.value.metadata = image.metadata;
     r.value.params.resize(channels);
     std::vector<uint32_t> hist((size_t)channels * CONTEXT_AMOUNT * ALPHABET_SIZE);
-    std::vector<uint8_t> bucket(channels * plane);
-    std::vector<int32_t> prediction(channels * plane);
+    if (image.bucket.size() != channels * plane || image.prediction.size() != channels * plane) {
+        r.error = "missing predictors";
+        return r;
+    }
     for (uint32_t ch = 0; ch < channels; ch++) {
         if (contexts[ch].size() != (size_t)CONTEXT_AMOUNT) {
             r.error = "missing contexts";
@@ -280,8 +244,6 @@ Result<CompressedImage> stages::entropy_coding::encode(const WaveletImage &image
         }
         for (int b = 0; b < CONTEXT_AMOUNT; b++)
             std::copy(contexts[ch][b].freqs.begin(), contexts[ch][b].freqs.end(), hist.begin() + ((size_t)ch * CONTEXT_AMOUNT + b) * ALPHABET_SIZE);
-        std::copy(image.bucket[ch].begin(), image.bucket[ch].end(), bucket.begin() + ch * plane);
-        std::copy(image.prediction[ch].begin(), image.prediction[ch].end(), prediction.begin() + ch * plane);
         for (int g = 0; g < 3; g++)
             for (int k = 0; k < 6; k++) {
                 r.value.params[ch].value[g][k] = opts.value_prediction_params[ch][g][k];
@@ -289,7 +251,7 @@ Result<CompressedImage> stages::entropy_coding::encode(const WaveletImage &image
             }
     }
     const emit::SymbolOrder order(image.centers.data(), image.num_cells);
-    const std::string err = emit::encode_channels(order, channels, image.coefficients.data(), bucket.data(), prediction.data(), hist.data(), r.value.channel_data);
+    const std::string err = emit::encode_channels(order, channels, image.coefficients.data(), image.bucket.data(), image.prediction.data(), hist.data(), r.value.channel_data);
     if (!err.empty()) {
         r.error = err;
         return r;

@@ -7,7 +7,9 @@
 //   stages::quantization::{encode,decode}                           stages/quantization.rs:7-45
 //   stages::prediction::encode                                      stages/prediction.rs:224-323 (scan loops only)
 //   stages::entropy_coding::encode + stages::serialize::encode      stages/entropy_coding.rs:266-352, stages/serialize.rs:49-117
-// `encode` stops at the state the reference calls EncoderStage::EntropyEncoding(WaveletImage, contexts) (encoder.rs:38);
+// FRIEncoder::encode runs the device stages as ONE call (fri_hip_encode_image: the coefficients stay in device memory from the transform
+// to the histogram, one upload of the pixels, one download per output) and
+// stops at the state the reference calls EncoderStage::EntropyEncoding(WaveletImage, contexts) (encoder.rs:38);
 // `encode_bytes` runs the two host stages behind it (emit.hpp: symbol order, ANS model, rANS, `frif` container) and returns
 // what the reference's FRIEncoder::encode returns, the file bytes.
 // Errors come back as Result<T>{ok,error} with the reference's "Failed to decode: " prefix (sic, encoder.rs:106).
@@ -62,9 +64,12 @@ struct WaveletImage {
     uint32_t num_cells = 0;
     std::vector<int32_t> centers;      // [F][2] (re, im)
     std::vector<int32_t> coefficients; // [C][F][512], FRI_HIP_NONE = None          (Fractal.coefficients)
-    std::array<std::vector<uint8_t>, 3> bucket;     // [F][512] per channel         (Fractal.parameter_predictors.0)
-    std::array<std::vector<int32_t>, 3> prediction; // [F][512] per channel         (Fractal.parameter_predictors.1)
+    std::vector<uint8_t> bucket;       // [C][F][512]                           (Fractal.parameter_predictors.0)
+    std::vector<int32_t> prediction;   // [C][F][512]                           (Fractal.parameter_predictors.1)
     bool quantized = false;
+    size_t plane() const { return (size_t)num_cells * FRI_HIP_CELL_SIZE; }
+    const uint8_t *bucket_of(uint32_t channel) const { return bucket.data() + channel * plane(); }
+    const int32_t *prediction_of(uint32_t channel) const { return prediction.data() + channel * plane(); }
 };
 
 template <typename T>
@@ -93,14 +98,16 @@ class Device {
 };
 
 // ContextModeler (context_modeling.rs:13-213): the least-squares fit of the value / width predictors. The device
-// accumulates the normal-equation sums (fri_hip_fit_value_sums / fri_hip_fit_width_sums); this class solves the 6 x 6
-// systems (minimum-norm solution via a Jacobi eigen-decomposition, the counterpart of lstsq's SVD with its 1e-14 cut-off).
+// accumulates the normal-equation sums (fri_hip_fit_value_sums / fri_hip_fit_width_sums); the 6 x 6 systems are solved by the
+// library's host functions (fri_hip_fit_value_params / fri_hip_fit_width_params: minimum-norm solution via a Jacobi
+// eigen-decomposition, the counterpart of lstsq's SVD with its 1e-14 cut-off). optimize_parameters is the single-channel, stage-by-stage
+// form; FRIEncoder::encode and stages::prediction::encode fit all channels inside one device-resident call instead.
 struct ContextModeler {
     std::array<PredictionParams, 3> value_predictors{};
     std::array<PredictionParams, 3> width_predictors{};
     // optimize_parameters(&wavelet_image, channel), context_modeling.rs:204-213
     Result<bool> optimize_parameters(const WaveletImage &image, uint32_t channel, Device &dev);
-    // x = pinv(M) y for a symmetric positive semi-definite 6 x 6 matrix
+    // x = pinv(M) y for a symmetric positive semi-definite 6 x 6 matrix (fri_hip_solve6)
     static std::array<double, 6> solve_normal_equations(const double (&m)[6][6], const double (&y)[6]);
 };
 

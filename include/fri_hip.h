@@ -162,6 +162,13 @@ int fri_hip_predict_histogram_dev(fri_hip_plan *plan, const int32_t *d_coefs, ui
                                   const float width_params[3][6], uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist,
                                   uint64_t *d_n_out_of_alphabet, void *stream);
 
+/* The same for n_planes planes (images x channels) in ONE launch - BASELINE config 3's batch of frames, or the channels of one image:
+ * plane k reads d_coefs + k * coef_stride (int32 elements), takes its parameters from d_params[k] - a DEVICE array float[n_planes][2][3][6],
+ * value set then width set - writes d_bucket / d_prediction + k * out_stride (elements; either may be NULL), d_hist[k][10][1024] and
+ * d_n_out_of_alphabet[k]. Replaces the channel loop of prediction::encode (stages/prediction.rs:231) and, across images, the caller's loop. */
+int fri_hip_predict_histogram_batch_dev(fri_hip_plan *plan, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, const float *d_params, uint8_t *d_bucket,
+                                        int32_t *d_prediction, size_t out_stride, uint32_t *d_hist, uint64_t *d_n_out_of_alphabet, void *stream);
+
 /* ---- context-model fit: normal-equation sums ------------------ */
 /* The reference fits the 3 x 6 value and 3 x 6 width parameters of a channel by building n x 6 f32 design matrices
  * (ContextModeler::get_image_neighbour_matrices, context_modeling.rs:79-142) and running an SVD least squares on them
@@ -175,8 +182,7 @@ int fri_hip_predict_histogram_dev(fri_hip_plan *plan, const int32_t *d_coefs, ui
  * Precondition (both fit entry points): Some coefficients lie in [-255, 255], as every output of
  * fri_hip_transform_quant does (differences of 8-bit pixels, divided by a quantiser >= 1). The kernels stage them as
  * int16 and accumulate products of pairs of rows in 32-bit partial sums (v_dot2) that are widened every 1024 cells;
- * larger magnitudes overflow those partial sums silently. fri_hip_predict_histogram's n_out_of_alphabet reports
- * values outside the int16 range. */
+ * larger magnitudes overflow those partial sums silently. */
 int fri_hip_fit_value_sums(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, int64_t gram[3][28]);
 int fri_hip_fit_value_sums_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint32_t channel, int64_t *d_gram, void *stream);
 /* Width fit (optimize_width_prediction, :144-173) for given value parameters x: residual r = |f32(value) - A x| in f32
@@ -189,6 +195,41 @@ int fri_hip_fit_width_sums(fri_hip_plan *plan, const int32_t *coefs, uint32_t ch
 int fri_hip_fit_width_sums_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint32_t channel, const float value_params[3][6], int64_t *d_wtw,
                                double *d_wtr, void *stream);
 
+/* Batch forms, one launch for n_planes planes laid out as in fri_hip_predict_histogram_batch_dev: d_gram[n_planes][3][28];
+ * d_params = DEVICE float[n_planes][2][3][6] of which the value sets are used; d_wtw[n_planes][3][21], d_wtr[n_planes][3][6]. */
+int fri_hip_fit_value_sums_batch_dev(fri_hip_plan *plan, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, int64_t *d_gram, void *stream);
+int fri_hip_fit_width_sums_batch_dev(fri_hip_plan *plan, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, const float *d_params, int64_t *d_wtw, double *d_wtr,
+                                     void *stream);
+/* The 6 x 6 solves behind the fit (host, pure functions): x = pinv(M) y for a symmetric positive semi-definite M (cyclic Jacobi,
+ * eigenvalues <= 1e-12 of the largest are dropped: the minimum-norm solution lstsq's SVD returns, up to rounding); from the sums to
+ * the parameters of optimize_value_prediction (context_modeling.rs:175-202) and optimize_width_prediction (:144-173; rows[g] =
+ * F * {256, 128, 128}, the reference's matrix heights). */
+void fri_hip_solve6(const double m[6][6], const double y[6], double x[6]);
+void fri_hip_fit_value_params(const int64_t gram[3][28], float value_params[3][6]);
+void fri_hip_fit_width_params(const int64_t wtw[3][21], const double wtr[3][6], const uint64_t rows[3], float width_params[3][6]);
+
+/* ---- the device part of FRIEncoder::encode in one call ---------------------------------------------- */
+/* Replaces the stage chain of FRIEncoder::encode (encoder.rs:19-48) up to EncoderStage::EntropyEncoding for one image, all channels:
+ * wavelet_transform::encode + quantization::encode (one kernel), then per channel ContextModeler::optimize_parameters
+ * (prediction.rs:232-235; the sums on the device, the 6 x 6 solves on the host) and the scan loop of prediction::encode
+ * (:237-298) - with the coefficients staying in device memory between the stages, as the reference threads ONE WaveletImage through them.
+ * fit != 0: the parameters are fitted and returned in value_params / width_params (float[channels][3][6] each); fit == 0: they are inputs.
+ * Outputs: coefs [C][F][512], bucket / prediction [C][F][512] (may be NULL), hist [C][10][1024], n_out_of_alphabet [C].
+ * The host form uploads the pixels once and downloads each output once. The device form enqueues on `stream` and, when fit != 0,
+ * synchronises that stream twice (the sums come back to the host for the solves); without fit it returns without synchronising. */
+int fri_hip_encode_image(fri_hip_plan *plan, const uint8_t *pixels, const int32_t qmatrix[32], int fit, float *value_params, float *width_params, int32_t *coefs,
+                         uint8_t *bucket, int32_t *prediction, uint32_t *hist, uint64_t *n_out_of_alphabet);
+int fri_hip_encode_image_dev(fri_hip_plan *plan, const uint8_t *d_pixels, const int32_t qmatrix[32], int fit, float *value_params, float *width_params, int32_t *d_coefs,
+                             uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist, uint64_t *d_n_out_of_alphabet, void *stream);
+
+/* prediction::encode alone (stages/prediction.rs:224-323 minus the host's ANS models) for all channels of an image whose coefficients
+ * already exist: one upload of the coefficients (host form), optional fit, the scan of every channel in one launch. Same argument
+ * meaning as fri_hip_encode_image; any int32 coefficients are accepted (see fri_hip_predict_histogram). */
+int fri_hip_predict_image(fri_hip_plan *plan, const int32_t *coefs, int fit, float *value_params, float *width_params, uint8_t *bucket, int32_t *prediction,
+                          uint32_t *hist, uint64_t *n_out_of_alphabet);
+int fri_hip_predict_image_dev(fri_hip_plan *plan, const int32_t *d_coefs, int fit, float *value_params, float *width_params, uint8_t *d_bucket, int32_t *d_prediction,
+                              uint32_t *d_hist, uint64_t *d_n_out_of_alphabet, void *stream);
+
 /* ---- inverse: dequantisation + inverse transform (decode side) ------------------------------ */
 /* Replaces quantization::decode (stages/quantization.rs:27-45) + wavelet_transform::decode
  * (stages/wavelet_transform.rs:715-717: RasterImage::from_wavelet :308-356, extract_values
@@ -199,6 +240,9 @@ int fri_hip_fit_width_sums_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint3
 int fri_hip_inverse_transform(fri_hip_plan *plan, const int32_t *coefs, const int32_t qmatrix[32], uint8_t *pixels);
 int fri_hip_inverse_transform_dev(fri_hip_plan *plan, const int32_t *d_coefs, const int32_t qmatrix[32], uint8_t *d_pixels,
                                   void *stream);
+/* n independent images in one launch: image k at d_coefs + k * coef_stride (int32 elements), d_pixels + k * pixel_stride (bytes). */
+int fri_hip_inverse_transform_batch_dev(fri_hip_plan *plan, uint32_t n_images, const int32_t *d_coefs, size_t coef_stride, const int32_t qmatrix[32], uint8_t *d_pixels,
+                                        size_t pixel_stride, void *stream);
 
 /* ---- timing helper ---------------------------------------------------------------------------- */
 /* Runs the forward kernel `iters` times on `stream` bracketed by HIP events recorded on that same
