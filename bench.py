@@ -276,15 +276,31 @@ def main():
         k2_us = timed(lambda: plan.predict_histogram_dev(co0, 0, vp, wp, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=stream))
         k3_us = timed(lambda: plan.inverse_transform_dev(co0, d_back.data_ptr(), stream=stream))
         assert torch.equal(d_back, d_px[0]), "K3(K1(x)) != x"
+        d_g = torch.empty(3 * 28, dtype=torch.int64, device="cuda")
+        d_w = torch.empty(18, dtype=torch.float64, device="cuda")
+        k4v_us = timed(lambda: plan.fit_value_sums_dev(co0, 0, d_g.data_ptr(), stream=stream))
+        k4w_us = timed(lambda: plan.fit_width_sums_dev(co0, 0, vp, d_g.data_ptr(), d_w.data_ptr(), stream=stream))
+        # the whole device part of FRIEncoder::encode for one image, coefficients staying in HBM (fri_hip_encode_image_dev): with the
+        # parameters given (K1 -> K2) and with the fit (K1 -> fit sums -> solve -> fit sums -> solve -> K2; two host round trips inside)
+        vp3, wp3 = vp.reshape(1, 3, 6).copy(), wp.reshape(1, 3, 6).copy()
+        enc_given = timed(lambda: plan.encode_image_dev(px0, co0, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), vp3, wp3, fit=False, stream=stream))
+        vpf, wpf = np.zeros((1, 3, 6), np.float32), np.zeros((1, 3, 6), np.float32)
+        enc_fit = timed(lambda: plan.encode_image_dev(px0, co0, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), vpf, wpf, fit=True, stream=stream))
         k2_bytes = F * 512 * (4 + 1 + 4) + 10 * 1024 * 4  # coefficient read + bucket + prediction write + histogram
         out["extras"] = {
             "k2_predict_histogram_us": round(k2_us, 2),
             "k2_Mpixels_per_s": round(W * H / k2_us, 1),
             "k2_algorithmic_GBps": round(k2_bytes / k2_us / 1e3, 1),
+            "k2_note": "through fri_hip_predict_histogram_dev, i.e. the fast kernel + the exact int32 kernel that returns at once for the forward kernel's output",
             "k3_inverse_us": round(k3_us, 2),
             "k3_Mpixels_per_s": round(W * H / k3_us, 1),
             "k3_algorithmic_GBps": round(alg_bytes / k3_us / 1e3, 1),
-            "note": "per channel plane; K2 = 6-neighbour gather + bucket/prediction + histogram, K3 = dequant + inverse transform",
+            "k4_fit_value_sums_us": round(k4v_us, 2),
+            "k4_fit_width_sums_us": round(k4w_us, 2),
+            "encode_device_us": {"parameters_given": round(enc_given, 2), "with_fit": round(enc_fit, 2)},
+            "encode_pcie_bytes_per_image": {"host_to_device": plan.pixel_bytes, "device_to_host": F * 512 * (4 + 1 + 4) + 10 * 1024 * 4 + 8,
+                                            "note": "fri_hip_encode_image: the pixels go up once, coefficients / bucket / prediction / histogram come down once; nothing is uploaded twice"},
+            "note": "per channel plane; K2 = 6-neighbour gather + bucket/prediction + histogram, K3 = dequant + inverse transform, K4 = normal-equation sums of the predictor fit",
         }
 
     if rank == 0:

@@ -76,6 +76,7 @@ struct fri_hip_plan {
     unsigned long long *d_oob_all = nullptr;  // [C]
     unsigned long long *d_sums_int = nullptr; // [C][3][28]
     double *d_sums_dbl = nullptr;             // [C][3][6]
+    void *h_sums = nullptr;                   // pinned: the fit sums on their way to the host's 6 x 6 solves (a pageable target makes each of the two round trips several times longer)
     uint32_t acc_next = 0;
     bool acc_dirty = false; // a launch on this plan failed: the accumulators are re-zeroed before the next use
     hipEvent_t ev_begin = nullptr, ev_end = nullptr; // timing helper's events, created with the plan (creating an event is not work to be timed)
@@ -453,6 +454,7 @@ int fri_hip_plan_destroy(fri_hip_plan *p) {
         for (void *d : p->retired_acc) (void)hipFree(d);
         for (void *d : {(void *)p->d_bucket_all, (void *)p->d_prediction_all, (void *)p->d_hist_all, (void *)p->d_oob_all, (void *)p->d_sums_int, (void *)p->d_sums_dbl})
             if (d) (void)hipFree(d);
+        if (p->h_sums) (void)hipHostFree(p->h_sums);
         if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
         if (p->ev_end) (void)hipEventDestroy(p->ev_end);
     }
@@ -876,6 +878,7 @@ static int ensure_encode_staging(fri_hip_plan *p) {
     if (!p->d_oob_all) HIP_TRY(c, hipMalloc((void **)&p->d_oob_all, C * sizeof(unsigned long long)));
     if (!p->d_sums_int) HIP_TRY(c, hipMalloc((void **)&p->d_sums_int, C * 3 * 28 * sizeof(unsigned long long)));
     if (!p->d_sums_dbl) HIP_TRY(c, hipMalloc((void **)&p->d_sums_dbl, C * 18 * sizeof(double)));
+    if (!p->h_sums) HIP_TRY(c, hipHostMalloc(&p->h_sums, 3 * (3 * 28 * sizeof(int64_t) + 18 * sizeof(double)), hipHostMallocDefault));
     return FRI_HIP_OK;
 }
 
@@ -893,8 +896,9 @@ static int predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, f
     b.coef_stride = plane;
     b.out_stride = plane;
     if (fit) { // ContextModeler::optimize_parameters per channel (prediction.rs:232-235, context_modeling.rs:204-213)
-        int64_t sums[3][3][28], wtw[3][3][21];
-        double wtr[3][3][6];
+        int64_t(*sums)[3][28] = static_cast<int64_t(*)[3][28]>(p->h_sums);
+        int64_t(*wtw)[3][21] = static_cast<int64_t(*)[3][21]>(p->h_sums);
+        double(*wtr)[3][6] = reinterpret_cast<double(*)[3][6]>(static_cast<int64_t *>(p->h_sums) + 3 * 3 * 28);
         if (int rc = fit_launch(p, 0, b, (int64_t *)p->d_sums_int, nullptr, s)) return rc;
         HIP_TRY(c, hipMemcpyAsync(sums, p->d_sums_int, (size_t)C * 3 * 28 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));

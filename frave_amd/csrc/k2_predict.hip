@@ -621,8 +621,18 @@ __global__ void __launch_bounds__(kCell) exact_predict_kernel(const ExactArgs a0
         a.hist += (size_t)plane * kHistBins;
         a.n_oob += plane;
         a.acc += (size_t)plane * kPredAccWords;
-        a.pp = a0.params ? a0.params[plane] : a0.pp3[plane < 3 ? plane : 2];
     }
+    // this plane's parameters as scalars (static indices only: a dynamic index into the argument struct would keep all of it in scratch memory);
+    // a thread then picks its layer group's set with selects
+    PredictParams pp;
+    if (a0.params)
+        pp = a0.params[blockIdx.y];
+    else if (blockIdx.y == 0)
+        pp = a0.pp3[0];
+    else if (blockIdx.y == 1)
+        pp = a0.pp3[1];
+    else
+        pp = a0.pp3[2];
     uint32_t *const inexact = a.acc + kAccInexact;
     __shared__ uint32_t s_go;
     if (threadIdx.x == 0) s_go = __hip_atomic_load(inexact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -652,7 +662,12 @@ __global__ void __launch_bounds__(kCell) exact_predict_kernel(const ExactArgs a0
             bucket = bucket_of_rt(w);
         } else { // get_hf_context_bucket, prediction.rs:165-206
             const int g = p >= 256 ? 0 : p >= 128 ? 1 : 2;
-            const float *wp = a.pp.width[g], *vp = a.pp.value[g];
+            float wp[6], vp[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                wp[k] = g == 0 ? pp.width[0][k] : g == 1 ? pp.width[1][k] : pp.width[2][k];
+                vp[k] = g == 0 ? pp.value[0][k] : g == 1 ? pp.value[1][k] : pp.value[2][k];
+            }
             float width = wp[0];
             width = __fadd_rn(width, __fmul_rn(wp[1], (float)iabs_w(sub_w(v[0], v[3]))));
             width = __fadd_rn(width, __fmul_rn(wp[2], (float)iabs_w(sub_w(v[1], v[2]))));
@@ -950,7 +965,17 @@ __device__ __forceinline__ PredArgs pred_plane_view(const PredArgs &a0, uint32_t
     a.n_oob += plane;
     a.acc += (size_t)plane * kPredAccWords;
     a.inexact = a.acc + kAccInexact;
-    a.pp = a0.params ? a0.params[plane] : a0.pp3[plane < 3 ? plane : 2];
+    // two branches with their own loads (caller's array / argument segment): a select between the two sources would be a select between
+    // address spaces, and the copy behind it would go through scratch memory
+    // (and no dynamic index into the argument struct either: that alone keeps the whole struct in scratch memory)
+    if (a0.params)
+        a.pp = a0.params[plane];
+    else if (plane == 0)
+        a.pp = a0.pp3[0];
+    else if (plane == 1)
+        a.pp = a0.pp3[1];
+    else
+        a.pp = a0.pp3[2];
     return a;
 }
 

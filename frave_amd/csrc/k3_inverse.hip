@@ -117,13 +117,13 @@ __device__ __forceinline__ bool inv_has_none(const InvRegs &c) {
 // The loads of one tile's items for this wave. Slots past the tile's items re-load its last item (no conditional loads:
 // a load the compiler cannot prove executed costs an immediate wait).
 template <int NI>
-__device__ __forceinline__ void inv_prefetch(const InvArgs &a, const Tile &t, const TileCell *cells, int wave, int lane, InvRegs (&r)[NI]) {
+__device__ __forceinline__ void inv_prefetch(const InvArgs &a, const int32_t *img_coefs, const Tile &t, const TileCell *cells, int wave, int lane, InvRegs (&r)[NI]) {
     const int C = a.channels, n_items = t.cell_count * C;
 #pragma unroll
     for (int s = 0; s < NI; s++) {
         const int item = min(wave + kInvWaves * s, n_items - 1);
         const int cl = item / C, ch = item - cl * C;
-        r[s] = inv_load(a.coefs + ((size_t)ch * a.F + (uint32_t)cells[cl].cell) * kCell, lane);
+        r[s] = inv_load(img_coefs + ((size_t)ch * a.F + (uint32_t)cells[cl].cell) * kCell, lane);
     }
 }
 
@@ -151,10 +151,11 @@ __device__ __forceinline__ InvTileLists scalar_lists(const InvTileLists &l) {
 }
 
 template <int NI>
-__global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const InvArgs a0) {
-    InvArgs a = a0;
-    a.coefs += blockIdx.y * a0.coef_stride;
-    a.pixels += blockIdx.y * a0.pixel_stride;
+__global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const InvArgs a) {
+    // this image of the batch (grid.y). Scalars, not a modified copy of the argument struct: a copy would live in scratch memory
+    // (the quantiser array inside is indexed dynamically) and every argument access with it.
+    const int32_t *const img_coefs = a.coefs + blockIdx.y * a.coef_stride;
+    uint8_t *const img_pixels = a.pixels + blockIdx.y * a.pixel_stride;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint16_t *img16 = reinterpret_cast<uint16_t *>(lds);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
     const uint32_t wg = xcd_contiguous_share(blockIdx.x, a.n_wg);
     const int tb = a.wg_tiles[wg], te = a.wg_tiles[wg + 1];
     const int C = a.channels;
-    const uint32_t base_lo = (uint32_t)reinterpret_cast<uintptr_t>(a.pixels);
+    const uint32_t base_lo = (uint32_t)reinterpret_cast<uintptr_t>(img_pixels);
     const uint32_t wc = (uint32_t)a.width * (uint32_t)C;
     trace_stamp(a.trace, wg, 0, tid);
     {
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
     trace_stamp(a.trace, wg, 1, tid);
 
     InvRegs pre[NI];
-    inv_prefetch<NI>(a, scalar_tile(lds_tiles[0]), lds_cells, wave, lane, pre);
+    inv_prefetch<NI>(a, img_coefs, scalar_tile(lds_tiles[0]), lds_cells, wave, lane, pre);
     for (int ti = tb; ti < te; ti++) {
         const Tile t = scalar_tile(lds_tiles[ti - tb]);
         InvRegs cur[NI];
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
         for (int s = 0; s < NI; s++) cur[s] = pre[s];
         {
             const Tile tn = scalar_tile(lds_tiles[min(ti + 1, te - 1) - tb]);
-            inv_prefetch<NI>(a, tn, lds_cells + (tn.cell_begin - cell0), wave, lane, pre);
+            inv_prefetch<NI>(a, img_coefs, tn, lds_cells + (tn.cell_begin - cell0), wave, lane, pre);
         }
         const int n_items = t.cell_count * C;
         // Staged rows start at the 16-byte boundary at or below their first byte (lead-in 0..15), so every global quad is an
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
                 src[0] = u32x4{0u, 0u, 0u, 0u};
                 src[1] = u32x4{0u, 0u, 0u, 0u};
                 const size_t g = ((size_t)(t.y_lo + r) * (size_t)a.width + (size_t)t.x_lo) * (size_t)C;
-                uint8_t *p = a.pixels + g - (int)((base_lo + (uint32_t)g) & 15u) + 16 * k; // 16-byte aligned
+                uint8_t *p = img_pixels + g - (int)((base_lo + (uint32_t)g) & 15u) + 16 * k; // 16-byte aligned
                 const u32x4 out{__builtin_amdgcn_perm(lo.y, lo.x, 0x06040200u), __builtin_amdgcn_perm(lo.w, lo.z, 0x06040200u),
                                 __builtin_amdgcn_perm(hi.y, hi.x, 0x06040200u), __builtin_amdgcn_perm(hi.w, hi.z, 0x06040200u)};
                 if (!(ablate_flags(a.ablate) & 1)) *reinterpret_cast<u32x4 *>(p) = out;
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
             if (e < qn) {
                 const int rk = queue[e], r = rk >> 8, k = rk & 255;
                 const size_t g = ((size_t)(t.y_lo + r) * (size_t)a.width + (size_t)t.x_lo) * (size_t)C;
-                uint8_t *p = a.pixels + g - (int)((base_lo + (uint32_t)g) & 15u) + 16 * k;
+                uint8_t *p = img_pixels + g - (int)((base_lo + (uint32_t)g) & 15u) + 16 * k;
                 u32x4 *src = reinterpret_cast<u32x4 *>(img16 + r * pitch16) + 2 * k;
                 const u32x4 lo = src[0], hi = src[1];
                 src[0] = u32x4{0u, 0u, 0u, 0u};
@@ -308,10 +309,9 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
 // width * channels multiples of 16): the launcher falls back to inverse_transform_kernel otherwise.
 constexpr int kInvListPre = 3; // list entries a thread holds in flight per list and tile (more are loaded on demand)
 template <int NI>
-__global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(const InvArgs a0) {
-    InvArgs a = a0;
-    a.coefs += blockIdx.y * a0.coef_stride;
-    a.pixels += blockIdx.y * a0.pixel_stride;
+__global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(const InvArgs a) {
+    const int32_t *const img_coefs = a.coefs + blockIdx.y * a.coef_stride; // this image of the batch, see inverse_transform_kernel
+    uint8_t *const img_pixels = a.pixels + blockIdx.y * a.pixel_stride;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *img = lds;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(co
     trace_stamp(a.trace, wg, 1, tid);
 
     InvRegs pre[NI];
-    inv_prefetch<NI>(a, scalar_tile(lds_tiles[0]), lds_cells, wave, lane, pre);
+    inv_prefetch<NI>(a, img_coefs, scalar_tile(lds_tiles[0]), lds_cells, wave, lane, pre);
     for (int ti = tb; ti < te; ti++) {
         const Tile t = scalar_tile(lds_tiles[ti - tb]);
         const InvTileLists L = scalar_lists(lds_lists[ti - tb]);
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(co
         for (int s = 0; s < NI; s++) cur[s] = pre[s];
         {
             const Tile tn = scalar_tile(lds_tiles[min(ti + 1, te - 1) - tb]);
-            inv_prefetch<NI>(a, tn, lds_cells + (tn.cell_begin - cell0), wave, lane, pre);
+            inv_prefetch<NI>(a, img_coefs, tn, lds_cells + (tn.cell_begin - cell0), wave, lane, pre);
         }
         // this thread's first entries of the three lists, in flight across the transform (indices clamped: the loads must be
         // unconditional; a tile without entries of one kind re-reads entry 0 of the array, which always exists)
@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(co
             }
         }
         lds_barrier(); // the rectangle holds every byte this tile owns
-        uint8_t *out0 = a.pixels + (size_t)t.y_lo * wc + (size_t)a0; // quad (r, k) -> out0 + r * wc + 16 k, 16-byte aligned
+        uint8_t *out0 = img_pixels + (size_t)t.y_lo * wc + (size_t)a0; // quad (r, k) -> out0 + r * wc + 16 k, 16-byte aligned
         for (uint32_t e = tid, m = 0; e < L.quad_count; e += kInvThreads, m++) { // whole quads
             const uint32_t rk = m < kInvListPre ? (m == 0 ? qe[0] : m == 1 ? qe[1] : qe[2]) : a.quads[L.quad_begin + e];
             const uint32_t r = rk >> 8, k = rk & 255u;

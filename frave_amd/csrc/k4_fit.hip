@@ -41,15 +41,34 @@ static_assert(kFitAccTicket + 1 == (int)kFitAccWords, "fit accumulator layout");
 template <int MODE>
 __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const FitArgs a0) {
     constexpr int NI = MODE == 0 ? 28 : 21;
-    FitArgs a = a0;
+    // This plane of the batch (grid.y). The view is a struct of scalars and ONE parameter set: a copy of the whole argument struct with
+    // its three parameter sets would be indexed dynamically and therefore live in scratch memory, and every argument access with it.
+    struct {
+        const int32_t *coefs;
+        unsigned long long *acc, *gram, *wtw;
+        double *wtr;
+        const int32_t *pred_slots;
+        const uint32_t *pred_off, *valid_mask;
+        uint32_t n_tiles;
+        PredictParams pp;
+    } a;
     {
         const uint32_t plane = blockIdx.y;
-        a.coefs += plane * a0.coef_stride;
-        a.acc += (size_t)plane * kFitAccWords;
-        if (a.gram) a.gram += (size_t)plane * 3 * NI;
-        if (a.wtw) a.wtw += (size_t)plane * 3 * NI;
-        if (a.wtr) a.wtr += (size_t)plane * 18;
-        a.pp = a0.params ? a0.params[plane] : a0.pp3[plane < 3 ? plane : 2];
+        a.coefs = a0.coefs + plane * a0.coef_stride;
+        a.acc = a0.acc + (size_t)plane * kFitAccWords;
+        a.gram = a0.gram ? a0.gram + (size_t)plane * 3 * NI : nullptr;
+        a.wtw = a0.wtw ? a0.wtw + (size_t)plane * 3 * NI : nullptr;
+        a.wtr = a0.wtr ? a0.wtr + (size_t)plane * 18 : nullptr;
+        a.pred_slots = a0.pred_slots, a.pred_off = a0.pred_off, a.valid_mask = a0.valid_mask, a.n_tiles = a0.n_tiles;
+        // static indices only: a dynamic index into the argument struct would keep all of it in scratch memory
+        if (a0.params)
+            a.pp = a0.params[plane];
+        else if (plane == 0)
+            a.pp = a0.pp3[0];
+        else if (plane == 1)
+            a.pp = a0.pp3[1];
+        else
+            a.pp = a0.pp3[2];
     }
     __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
     __shared__ int32_t s_slot_cell[kPredSlots];
@@ -79,7 +98,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
     }
     float vp[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) vp[k] = a.pp.value[g][k];
+    for (int k = 0; k < 6; k++) vp[k] = g == 0 ? a.pp.value[0][k] : g == 1 ? a.pp.value[1][k] : a.pp.value[2][k]; // selects, not a dynamic index
 
     int acc[NI];
     double dacc[6];

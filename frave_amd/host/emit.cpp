@@ -1,6 +1,10 @@
 // emit.cpp -- see emit.hpp. Citations are relative to /root/reference/crates/libfri/src/.
 #include "emit.hpp"
 
+#include <atomic>
+#include <memory>
+#include <mutex>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -66,6 +70,35 @@ std::vector<uint32_t> symbol_order(const int32_t *centers, uint32_t n_cells, int
         key.swap(key2), id.swap(id2);
     }
     return id;
+}
+
+std::shared_ptr<const SymbolOrder> shared_symbol_order(const int32_t *centers, uint32_t n_cells) {
+    // The order depends on the cell centres alone, i.e. on (width, height): every image of a size shares one. A small process-wide
+    // cache keyed by the centres themselves (hash + full compare); 68 MB per 4096^2 entry, four entries.
+    struct Entry {
+        uint64_t hash;
+        std::vector<int32_t> centers;
+        std::shared_ptr<const SymbolOrder> order;
+    };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < (size_t)n_cells * 2; i++) h = (h ^ (uint32_t)centers[i]) * 1099511628211ull;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (size_t i = 0; i < cache.size(); i++)
+            if (cache[i].hash == h && cache[i].centers.size() == (size_t)n_cells * 2 && std::equal(cache[i].centers.begin(), cache[i].centers.end(), centers)) {
+                Entry e = std::move(cache[i]); // most recently used last
+                cache.erase(cache.begin() + (long)i);
+                cache.push_back(std::move(e));
+                return cache.back().order;
+            }
+    }
+    auto order = std::make_shared<const SymbolOrder>(centers, n_cells); // built outside the lock: two threads may build the same order once
+    std::lock_guard<std::mutex> lock(mu);
+    if (cache.size() >= 4) cache.erase(cache.begin());
+    cache.push_back(Entry{h, std::vector<int32_t>(centers, centers + (size_t)n_cells * 2), order});
+    return order;
 }
 
 SymbolOrder::SymbolOrder(const int32_t *centers, uint32_t n_cells) {
@@ -170,6 +203,33 @@ void RansEncoderMulti::put_at(int s, uint32_t start, uint32_t freq, uint32_t sca
     }
     x_[s] = ((x / freq) << scale_bits) + (x % freq) + start;
 }
+// ryg_rans' Rans64EncSymbol: the division and the remainder of put_at replaced by a multiplication with a precomputed 64-bit
+// reciprocal (rans64.h, Rans64EncSymbolInit / Rans64EncPutSymbol). Exact: q below equals x / freq for every state x < 2^63, so
+// x + bias + q * cmpl_freq is the same new state as ((x / freq) << scale_bits) + x % freq + start.
+RansEncoderMulti::EncSymbol RansEncoderMulti::make_symbol(uint32_t start, uint32_t freq, uint32_t scale_bits) {
+    EncSymbol s;
+    s.freq = freq;
+    s.cmpl_freq = (uint32_t)((1ull << scale_bits) - freq);
+    s.x_max = ((((uint64_t)1 << 31) >> scale_bits) << 32) * freq;
+    if (freq < 2) { // q = mul_hi(x, ~0) = x - 1 for x > 0; new state = x + start + (2^scale - 1) + (x - 1) * (2^scale - 1) = (x << scale) + start
+        s.rcp_freq = ~0ull;
+        s.rcp_shift = 0;
+        s.bias = start + (uint32_t)((1ull << scale_bits) - 1);
+    } else {
+        uint32_t shift = 0;
+        while (freq > (1u << shift)) shift++;
+        // ceil(2^(shift + 63) / freq) by long division in two 32-bit digits
+        uint64_t x0 = freq - 1;
+        const uint64_t x1 = 1ull << (shift + 31);
+        const uint64_t t1 = x1 / freq;
+        x0 += (x1 % freq) << 32;
+        const uint64_t t0 = x0 / freq;
+        s.rcp_freq = t0 + (t1 << 32);
+        s.rcp_shift = shift - 1;
+        s.bias = start;
+    }
+    return s;
+}
 void RansEncoderMulti::flush_all() {
     for (int s = 0; s < kContexts; s++) { // each flush prepends two words: state kContexts-1 ends up first in the stream
         rev_.push_back((uint32_t)(x_[s] >> 32));
@@ -214,20 +274,62 @@ void RansDecoderMulti::advance_at(int s, uint32_t start, uint32_t freq, uint32_t
 // ---- one channel -------------------------------------------------------------------------------------------------------
 void channel_symbols(const SymbolOrder &order, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction, std::vector<uint16_t> &symbols,
                      std::vector<uint8_t> &buckets) {
-    symbols.clear();
-    buckets.clear();
-    symbols.reserve(order.level[0].size() * kNodes);
-    buckets.reserve(order.level[0].size() * kNodes);
-    auto push = [&](uint32_t cell, uint32_t heap) {
-        const size_t at = (size_t)cell * kNodes + heap;
-        if (coefs[at] == kNone) return; // `if let Some(value)`, entropy_coding.rs:288, :300, :317
-        symbols.push_back((uint16_t)pack_signed((int32_t)((uint32_t)coefs[at] - (uint32_t)prediction[at])));
-        buckets.push_back(bucket[at]);
+    // The stream is the concatenation of ten scans (DC, root, levels 1..8), each a gather through the order. The gather is cut into
+    // chunks that threads fill on their own (a None coefficient yields no symbol, so a chunk's output length is known only afterwards),
+    // then the chunks are laid end to end: same sequence as the reference's single loop (entropy_coding.rs:285-330).
+    struct Scan {
+        const uint32_t *list;
+        size_t n;
+        int fixed_heap; // >= 0: every entry is a cell whose node `fixed_heap` is taken (the two level-0 scans)
     };
-    for (uint32_t e : order.level[0]) push(e >> 9, 0); // first scan: DC
-    for (uint32_t e : order.level[0]) push(e >> 9, 1); // second scan: root
-    for (int level = 1; level < kDepth; level++)
-        for (uint32_t e : order.level[level]) push(e >> 9, e & 511u);
+    std::vector<Scan> scans;
+    scans.push_back({order.level[0].data(), order.level[0].size(), 0});
+    scans.push_back({order.level[0].data(), order.level[0].size(), 1});
+    for (int level = 1; level < kDepth; level++) scans.push_back({order.level[level].data(), order.level[level].size(), -1});
+    constexpr size_t kChunk = 1u << 18;
+    struct Chunk {
+        size_t scan, begin, end;
+        std::vector<uint16_t> sym;
+        std::vector<uint8_t> bkt;
+    };
+    std::vector<Chunk> chunks;
+    for (size_t sc = 0; sc < scans.size(); sc++)
+        for (size_t b = 0; b < scans[sc].n; b += kChunk) chunks.push_back(Chunk{sc, b, std::min(scans[sc].n, b + kChunk), {}, {}});
+    auto fill = [&](Chunk &c) {
+        const Scan &sc = scans[c.scan];
+        c.sym.reserve(c.end - c.begin);
+        c.bkt.reserve(c.end - c.begin);
+        for (size_t k = c.begin; k < c.end; k++) {
+            const uint32_t e = sc.list[k];
+            const size_t at = (size_t)(e >> 9) * kNodes + (sc.fixed_heap >= 0 ? (uint32_t)sc.fixed_heap : (e & 511u));
+            if (coefs[at] == kNone) continue; // `if let Some(value)`, entropy_coding.rs:288, :300, :317
+            c.sym.push_back((uint16_t)pack_signed((int32_t)((uint32_t)coefs[at] - (uint32_t)prediction[at])));
+            c.bkt.push_back(bucket[at]);
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_threads = std::min<size_t>(chunks.size(), hw ? std::min(hw, 8u) : 4u);
+    if (n_threads <= 1) {
+        for (Chunk &c : chunks) fill(c);
+    } else {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> workers;
+        for (size_t t = 0; t < n_threads; t++)
+            workers.emplace_back([&] {
+                for (size_t i; (i = next.fetch_add(1)) < chunks.size();) fill(chunks[i]);
+            });
+        for (std::thread &t : workers) t.join();
+    }
+    size_t total = 0;
+    for (const Chunk &c : chunks) total += c.sym.size();
+    symbols.resize(total);
+    buckets.resize(total);
+    size_t at = 0;
+    for (const Chunk &c : chunks) {
+        std::copy(c.sym.begin(), c.sym.end(), symbols.begin() + (long)at);
+        std::copy(c.bkt.begin(), c.bkt.end(), buckets.begin() + (long)at);
+        at += c.sym.size();
+    }
 }
 
 std::string encode_channel(const SymbolOrder &order, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction, const uint32_t *hist,
@@ -249,12 +351,19 @@ std::string encode_channel(const SymbolOrder &order, const int32_t *coefs, const
     channel_symbols(order, coefs, bucket, prediction, symbols, buckets);
     RansEncoderMulti enc;
     enc.reserve(symbols.size());
+    // per (context, symbol): the coder step with its division precomputed; a zero-frequency symbol keeps freq = 0 and is an error when met
+    std::vector<RansEncoderMulti::EncSymbol> tab((size_t)kContexts * kAlphabet);
+    for (int b = 0; b < kContexts; b++)
+        for (int j = 0; j < kAlphabet; j++) {
+            const AnsContext &c = out.contexts[b];
+            tab[(size_t)b * kAlphabet + j] = c.freqs[j] ? RansEncoderMulti::make_symbol(c.cdf[j], c.freqs[j], c.max_freq_bits) : RansEncoderMulti::EncSymbol{0, 0, 0, 0, 0, 0};
+        }
     for (size_t k = symbols.size(); k-- > 0;) { // fed in reverse, :332-334
-        const AnsContext &c = out.contexts[buckets[k]];
         const uint32_t sym = symbols[k];
         if (sym >= (uint32_t)kAlphabet) return "symbol outside the alphabet (libfri panics, entropy_coding.rs:99)";
-        if (c.freqs[sym] == 0) return "symbol with zero model frequency";
-        enc.put_at(buckets[k], c.cdf[sym], c.freqs[sym], c.max_freq_bits);
+        const RansEncoderMulti::EncSymbol &e = tab[(size_t)buckets[k] * kAlphabet + sym];
+        if (e.freq == 0) return "symbol with zero model frequency";
+        enc.put_symbol(buckets[k], e);
     }
     enc.flush_all();
     out.data = enc.data();
@@ -426,7 +535,8 @@ std::string decode_parsed(const ParsedImage &img, DecodedImage &out) {
     for (size_t c = 0; c < F; c++) out.centers[2 * c] = g.centers[c].x, out.centers[2 * c + 1] = g.centers[c].y;
     out.coefs.assign(channels * plane, 0);
     out.params = img.params;
-    const SymbolOrder order(out.centers.data(), (uint32_t)F);
+    const auto order_ptr = shared_symbol_order(out.centers.data(), (uint32_t)F);
+    const SymbolOrder &order = *order_ptr;
     std::vector<std::string> errs(channels);
     std::vector<std::thread> workers;
     for (uint32_t ch = 1; ch < channels; ch++)

@@ -13,6 +13,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,9 @@ struct SymbolOrder {
     SymbolOrder() = default;
     SymbolOrder(const int32_t *centers_re_im, uint32_t n_cells);
 };
+// The order of this set of centres from a small process-wide cache (built on first use): what encoders and decoders of many
+// images of one size share.
+std::shared_ptr<const SymbolOrder> shared_symbol_order(const int32_t *centers_re_im, uint32_t n_cells);
 
 // ---- ANS model --------------------------------------------------------------------------------------------------
 struct AnsContext {
@@ -60,6 +64,21 @@ int32_t unpack_signed(uint32_t k);                         // utils.rs:42-48
 class RansEncoderMulti {
   public:
     void put_at(int state, uint32_t start, uint32_t freq, uint32_t scale_bits);
+    // the same step with the division precomputed per (model, symbol): see make_symbol in emit.cpp
+    struct EncSymbol {
+        uint64_t x_max, rcp_freq;
+        uint32_t freq, bias, cmpl_freq, rcp_shift;
+    };
+    static EncSymbol make_symbol(uint32_t start, uint32_t freq, uint32_t scale_bits);
+    void put_symbol(int state, const EncSymbol &s) {
+        uint64_t x = x_[state];
+        if (x >= s.x_max) {
+            rev_.push_back((uint32_t)x);
+            x >>= 32;
+        }
+        const uint64_t q = (uint64_t)(((unsigned __int128)x * s.rcp_freq) >> 64) >> s.rcp_shift;
+        x_[state] = x + s.bias + q * s.cmpl_freq;
+    }
     void reserve(size_t n_symbols) { rev_.reserve(n_symbols / 2 + 64); }
     void flush_all();
     std::vector<uint8_t> data() const; // little-endian words, first word of the stream first

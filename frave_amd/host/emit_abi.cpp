@@ -56,7 +56,7 @@ int fri_emit_channel_symbols(const int32_t *centers_re_im, uint32_t n_cells, con
     if (!centers_re_im || !coefs || !bucket || !prediction || !symbols || !buckets || !n) return -1;
     std::vector<uint16_t> s;
     std::vector<uint8_t> b;
-    channel_symbols(SymbolOrder(centers_re_im, n_cells), coefs, bucket, prediction, s, b);
+    channel_symbols(*shared_symbol_order(centers_re_im, n_cells), coefs, bucket, prediction, s, b);
     std::memcpy(symbols, s.data(), s.size() * sizeof(uint16_t));
     std::memcpy(buckets, b.data(), b.size());
     *n = s.size();
@@ -72,7 +72,8 @@ int fri_emit_encode_image(uint32_t width, uint32_t height, uint32_t channels, co
         return fail(err, err_cap, "invalid argument");
     std::vector<ChannelStream> streams;
     std::vector<ChannelParams> params(channels);
-    const SymbolOrder order(centers_re_im, n_cells); // geometry only: once for all channels
+    const auto order_ptr = shared_symbol_order(centers_re_im, n_cells); // geometry only: once for all channels, cached per image size
+    const SymbolOrder &order = *order_ptr;
     const std::string e = encode_channels(order, channels, coefs, bucket, prediction, hist, streams);
     if (!e.empty()) return fail(err, err_cap, e, -2);
     for (uint32_t ch = 0; ch < channels; ch++) {
@@ -96,7 +97,8 @@ int fri_emit_check_image(const uint8_t *frv, size_t len, uint32_t channels, cons
     if (!e.empty()) return fail(err, err_cap, e, -2);
     if (img.channels.size() != channels) return fail(err, err_cap, "channel count", -2);
     const size_t plane = (size_t)n_cells * kNodes;
-    const SymbolOrder order(centers_re_im, n_cells);
+    const auto order_ptr = shared_symbol_order(centers_re_im, n_cells);
+    const SymbolOrder &order = *order_ptr;
     for (uint32_t ch = 0; ch < channels; ch++) {
         std::vector<uint16_t> want, got;
         std::vector<uint8_t> buckets;

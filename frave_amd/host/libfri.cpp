@@ -250,7 +250,8 @@ Result<CompressedImage> stages::entropy_coding::encode(const WaveletImage &image
                 r.value.params[ch].width[g][k] = opts.width_prediction_params[ch][g][k];
             }
     }
-    const emit::SymbolOrder order(image.centers.data(), image.num_cells);
+    const auto order_ptr = emit::shared_symbol_order(image.centers.data(), image.num_cells); // geometry only: cached per image size
+    const emit::SymbolOrder &order = *order_ptr;
     const std::string err = emit::encode_channels(order, channels, image.coefficients.data(), image.bucket.data(), image.prediction.data(), hist.data(), r.value.channel_data);
     if (!err.empty()) {
         r.error = err;

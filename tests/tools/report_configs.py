@@ -62,6 +62,25 @@ def kernels(w, h, c, slots, label):
     pk = d_back.data_ptr()
     k3 = timed(lambda: P.inverse_transform_dev(co0, pk, stream=s), 30)
     line("K3 inverse (all channels)", k3, w * h, alg1)
+    d_g = torch.empty(3 * 28, dtype=torch.int64, device="cuda")
+    d_w = torch.empty(18, dtype=torch.float64, device="cuda")
+    pg, pw = d_g.data_ptr(), d_w.data_ptr()
+    k4v = timed(lambda: P.fit_value_sums_dev(co0, 0, pg, stream=s), 30)
+    k4w = timed(lambda: P.fit_width_sums_dev(co0, 0, vp, pg, pw, stream=s), 30)
+    line("K4 fit value sums (per channel)", k4v, w * h, F * 512 * 4)
+    line("K4 fit width sums (per channel)", k4w, w * h, F * 512 * 4)
+    # the device part of FRIEncoder::encode in one call, all channels, coefficients staying in HBM
+    d_ba = torch.empty(c * F * 512, dtype=torch.uint8, device="cuda")
+    d_pa = torch.empty(c * F * 512, dtype=torch.int32, device="cuda")
+    d_ha = torch.empty(c * 10 * 1024, dtype=torch.int32, device="cuda")
+    d_oa = torch.empty(c, dtype=torch.int64, device="cuda")
+    vpc, wpc = np.stack([vp] * c).astype(np.float32), np.stack([wp] * c).astype(np.float32)
+    px0 = d_px[0].data_ptr()
+    enc = timed(lambda: P.encode_image_dev(px0, co0, d_ba.data_ptr(), d_pa.data_ptr(), d_ha.data_ptr(), d_oa.data_ptr(), vpc, wpc, fit=False, stream=s), 20)
+    line("encode chain K1 -> K2 (params given)", enc, w * h, alg1 + c * (F * 512 * 9 + 40960))
+    vpf, wpf = np.zeros((c, 3, 6), np.float32), np.zeros((c, 3, 6), np.float32)
+    encf = timed(lambda: P.encode_image_dev(px0, co0, d_ba.data_ptr(), d_pa.data_ptr(), d_ha.data_ptr(), d_oa.data_ptr(), vpf, wpf, fit=True, stream=s), 20)
+    line("encode chain with the fit (2 host syncs)", encf, w * h, alg1 + c * (F * 512 * 17 + 40960))
     ok = bool(torch.equal(d_back, d_px[0]))
     tot = int(d_h.sum()) + int(d_o.item())
     print(f"    lossless K3(K1(x)) == x: {ok};  histogram total {tot} == Some coefficients {P.num_some}: {tot == P.num_some}")
@@ -101,7 +120,26 @@ d_px = torch.randint(0, 256, (n, P.pixel_bytes), dtype=torch.uint8, device="cuda
 d_co = torch.empty((n, P.coef_count), dtype=torch.int32, device="cuda")
 us = timed(lambda: P.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=s, n_images=n, pixel_stride=P.pixel_bytes, coef_stride=P.coef_count), 5)
 line(f"K1, one launch over {n} frames", us, n * 1920 * 1080, n * (P.pixel_bytes + P.coef_count * 4))
-del d_px, d_co
+# the whole device chain over the batch: fit sums of all planes in one launch each (the 6 x 6 solves of 256 planes on the host in between), K2 for all planes in one launch
+F3, plane3 = P.num_cells, P.num_cells * 512
+d_gram = torch.empty((n, 3, 28), dtype=torch.int64, device="cuda")
+d_wtw = torch.empty((n, 3, 21), dtype=torch.int64, device="cuda")
+d_wtr = torch.empty((n, 3, 6), dtype=torch.float64, device="cuda")
+d_par = torch.from_numpy(np.tile(np.stack([KAT_VALUE_PARAMS, KAT_WIDTH_PARAMS]).astype(np.float32), (n, 1, 1, 1))).cuda()
+d_b3 = torch.empty((n, plane3), dtype=torch.uint8, device="cuda")
+d_p3 = torch.empty((n, plane3), dtype=torch.int32, device="cuda")
+d_h3 = torch.empty((n, 10, 1024), dtype=torch.int32, device="cuda")
+d_o3 = torch.empty(n, dtype=torch.int64, device="cuda")
+k1b = us
+k4vb = timed(lambda: P.fit_value_sums_batch_dev(n, d_co.data_ptr(), plane3, d_gram.data_ptr(), stream=s), 5)
+k4wb = timed(lambda: P.fit_width_sums_batch_dev(n, d_co.data_ptr(), plane3, d_par.data_ptr(), d_wtw.data_ptr(), d_wtr.data_ptr(), stream=s), 5)
+k2b = timed(lambda: P.predict_histogram_batch_dev(n, d_co.data_ptr(), plane3, d_par.data_ptr(), d_b3.data_ptr(), d_p3.data_ptr(), plane3, d_h3.data_ptr(), d_o3.data_ptr(), stream=s), 5)
+line(f"K4 value sums, one launch over {n} planes", k4vb, n * 1920 * 1080, n * plane3 * 4)
+line(f"K4 width sums, one launch over {n} planes", k4wb, n * 1920 * 1080, n * plane3 * 4)
+line(f"K2, one launch over {n} planes", k2b, n * 1920 * 1080, n * (plane3 * 9 + 40960))
+print(f"    device chain per frame: K1 {k1b / n:.2f} + K4 {k4vb / n:.2f} + {k4wb / n:.2f} + K2 {k2b / n:.2f} = {(k1b + k4vb + k4wb + k2b) / n:.2f} us/frame ({n * 1920 * 1080 / (k1b + k4vb + k4wb + k2b):.0f} Mpix/s), "
+      f"without the fit {(k1b + k2b) / n:.2f} us/frame")
+del d_b3, d_p3, d_px, d_co
 drv = os.path.join(ROOT, "frave_amd", "host", "fri_driver")
 if os.path.exists(drv):
     print("   ", subprocess.run([drv, "batch", "1920", "1080", "1", "256"], capture_output=True, text=True).stdout.strip())
