@@ -253,6 +253,7 @@ const char *fri_hip_strerror(int code) {
     case FRI_HIP_ERR_OUT_OF_MEMORY: return "out of device or pinned memory";
     case FRI_HIP_ERR_DIVIDE_BY_ZERO: return "quantisation matrix has a zero divisor";
     case FRI_HIP_ERR_EMPTY_LATTICE: return "no cell of the lattice touches the image";
+    case FRI_HIP_ERR_OUT_OF_RANGE: return "a Some coefficient lies outside [-256, 255]: the fit sums would overflow (the forward transform never produces one)";
     default: return "unknown error";
     }
 }
@@ -660,10 +661,11 @@ static int predict_launch(fri_hip_plan *p, const PredBatch &b, uint8_t *d_bucket
     }
     return FRI_HIP_OK;
 }
-static int fit_launch(fri_hip_plan *p, int mode, const PredBatch &b, int64_t *d_int, double *d_dbl, hipStream_t stream) {
+// d_range (may be NULL): per plane, how many waves staged a Some coefficient outside [-256, 255] (include/fri_hip.h: the fit's precondition)
+static int fit_launch(fri_hip_plan *p, int mode, const PredBatch &b, int64_t *d_int, double *d_dbl, unsigned long long *d_range, hipStream_t stream) {
     const int slot = acquire_acc(p, stream, b.n_planes);
     if (slot < 0) return slot;
-    if (hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, stream)) {
+    if (hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream)) {
         p->acc_dirty = true;
         return fail_hip(p->ctx, e, "launch_fit_accumulate");
     }
@@ -726,7 +728,7 @@ int fri_hip_fit_value_sums_batch_dev(fri_hip_plan *p, uint32_t n_planes, const i
     b.n_planes = n_planes;
     b.coefs = d_coefs;
     b.coef_stride = coef_stride;
-    return fit_launch(p, 0, b, d_gram, nullptr, (hipStream_t)stream);
+    return fit_launch(p, 0, b, d_gram, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int fri_hip_fit_width_sums_batch_dev(fri_hip_plan *p, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, const float *d_params, int64_t *d_wtw, double *d_wtr,
@@ -739,7 +741,7 @@ int fri_hip_fit_width_sums_batch_dev(fri_hip_plan *p, uint32_t n_planes, const i
     b.coefs = d_coefs;
     b.coef_stride = coef_stride;
     b.params = reinterpret_cast<const PredictParams *>(d_params);
-    return fit_launch(p, 1, b, d_wtw, d_wtr, (hipStream_t)stream);
+    return fit_launch(p, 1, b, d_wtw, d_wtr, nullptr, (hipStream_t)stream);
 }
 
 int fri_hip_fit_value_sums_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t channel, int64_t *d_gram, void *stream) {
@@ -747,7 +749,7 @@ int fri_hip_fit_value_sums_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t
     if (!d_coefs || !d_gram || channel >= p->geo.channels) return FRI_HIP_ERR_INVALID_ARGUMENT;
     PredBatch b;
     b.coefs = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
-    return fit_launch(p, 0, b, d_gram, nullptr, (hipStream_t)stream);
+    return fit_launch(p, 0, b, d_gram, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int fri_hip_fit_width_sums_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t channel, const float value_params[3][6], int64_t *d_wtw, double *d_wtr,
@@ -757,7 +759,7 @@ int fri_hip_fit_width_sums_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t
     PredBatch b;
     std::memcpy(b.pp[0].value, value_params, sizeof(b.pp[0].value));
     b.coefs = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
-    return fit_launch(p, 1, b, d_wtw, d_wtr, (hipStream_t)stream);
+    return fit_launch(p, 1, b, d_wtw, d_wtr, nullptr, (hipStream_t)stream);
 }
 
 int fri_hip_fit_value_sums(fri_hip_plan *p, const int32_t *coefs, uint32_t channel, int64_t gram[3][28]) {
@@ -766,9 +768,15 @@ int fri_hip_fit_value_sums(fri_hip_plan *p, const int32_t *coefs, uint32_t chann
     HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
     if (int rc = ensure_staging(p)) return rc;
     HIP_TRY(p->ctx, hipMemcpy(p->d_coefs, coefs, fri_hip_plan_coef_count(p) * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (int rc = fri_hip_fit_value_sums_dev(p, p->d_coefs, channel, (int64_t *)p->d_fit_int, nullptr)) return rc;
+    {
+        PredBatch b;
+        b.coefs = p->d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
+        if (int rc = fit_launch(p, 0, b, (int64_t *)p->d_fit_int, nullptr, p->d_oob, nullptr)) return rc;
+    }
     HIP_TRY(p->ctx, hipMemcpy(gram, p->d_fit_int, 3 * 28 * sizeof(int64_t), hipMemcpyDeviceToHost));
-    return FRI_HIP_OK;
+    unsigned long long out_of_range = 0;
+    HIP_TRY(p->ctx, hipMemcpy(&out_of_range, p->d_oob, sizeof(out_of_range), hipMemcpyDeviceToHost));
+    return out_of_range ? FRI_HIP_ERR_OUT_OF_RANGE : FRI_HIP_OK;
 }
 
 int fri_hip_fit_width_sums(fri_hip_plan *p, const int32_t *coefs, uint32_t channel, const float value_params[3][6], int64_t wtw[3][21], double wtr[3][6],
@@ -778,7 +786,15 @@ int fri_hip_fit_width_sums(fri_hip_plan *p, const int32_t *coefs, uint32_t chann
     HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
     if (int rc = ensure_staging(p)) return rc;
     HIP_TRY(p->ctx, hipMemcpy(p->d_coefs, coefs, fri_hip_plan_coef_count(p) * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (int rc = fri_hip_fit_width_sums_dev(p, p->d_coefs, channel, value_params, (int64_t *)p->d_fit_int, p->d_fit_dbl, nullptr)) return rc;
+    {
+        PredBatch b;
+        std::memcpy(b.pp[0].value, value_params, sizeof(b.pp[0].value));
+        b.coefs = p->d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
+        if (int rc = fit_launch(p, 1, b, (int64_t *)p->d_fit_int, p->d_fit_dbl, p->d_oob, nullptr)) return rc;
+    }
+    unsigned long long out_of_range = 0;
+    HIP_TRY(p->ctx, hipMemcpy(&out_of_range, p->d_oob, sizeof(out_of_range), hipMemcpyDeviceToHost));
+    if (out_of_range) return FRI_HIP_ERR_OUT_OF_RANGE;
     HIP_TRY(p->ctx, hipMemcpy(wtw, p->d_fit_int, 3 * 21 * sizeof(int64_t), hipMemcpyDeviceToHost));
     HIP_TRY(p->ctx, hipMemcpy(wtr, p->d_fit_dbl, 18 * sizeof(double), hipMemcpyDeviceToHost));
     if (rows) { // num_ctx_last_layer / num_ctx_middle_layer, context_modeling.rs:84-85
@@ -878,7 +894,7 @@ static int ensure_encode_staging(fri_hip_plan *p) {
     if (!p->d_oob_all) HIP_TRY(c, hipMalloc((void **)&p->d_oob_all, C * sizeof(unsigned long long)));
     if (!p->d_sums_int) HIP_TRY(c, hipMalloc((void **)&p->d_sums_int, C * 3 * 28 * sizeof(unsigned long long)));
     if (!p->d_sums_dbl) HIP_TRY(c, hipMalloc((void **)&p->d_sums_dbl, C * 18 * sizeof(double)));
-    if (!p->h_sums) HIP_TRY(c, hipHostMalloc(&p->h_sums, 3 * (3 * 28 * sizeof(int64_t) + 18 * sizeof(double)), hipHostMallocDefault));
+    if (!p->h_sums) HIP_TRY(c, hipHostMalloc(&p->h_sums, 3 * (3 * 28 * sizeof(int64_t) + 18 * sizeof(double)) + 3 * sizeof(unsigned long long), hipHostMallocDefault));
     return FRI_HIP_OK;
 }
 
@@ -899,14 +915,18 @@ static int predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, f
         int64_t(*sums)[3][28] = static_cast<int64_t(*)[3][28]>(p->h_sums);
         int64_t(*wtw)[3][21] = static_cast<int64_t(*)[3][21]>(p->h_sums);
         double(*wtr)[3][6] = reinterpret_cast<double(*)[3][6]>(static_cast<int64_t *>(p->h_sums) + 3 * 3 * 28);
-        if (int rc = fit_launch(p, 0, b, (int64_t *)p->d_sums_int, nullptr, s)) return rc;
+        unsigned long long *h_range = reinterpret_cast<unsigned long long *>(static_cast<char *>(p->h_sums) + 3 * (3 * 28 * sizeof(int64_t) + 18 * sizeof(double)));
+        if (int rc = fit_launch(p, 0, b, (int64_t *)p->d_sums_int, nullptr, p->d_oob_all, s)) return rc;
         HIP_TRY(c, hipMemcpyAsync(sums, p->d_sums_int, (size_t)C * 3 * 28 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(h_range, p->d_oob_all, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
+        for (uint32_t ch = 0; ch < C; ch++)
+            if (h_range[ch]) return FRI_HIP_ERR_OUT_OF_RANGE; // a Some coefficient outside [-256, 255]: the fit's 32-bit partial sums would overflow
         for (uint32_t ch = 0; ch < C; ch++) {
             fri_hip_fit_value_params(sums[ch], reinterpret_cast<float(*)[6]>(value_params + ch * 18));
             std::memcpy(b.pp[ch].value, value_params + ch * 18, sizeof(b.pp[ch].value));
         }
-        if (int rc = fit_launch(p, 1, b, (int64_t *)p->d_sums_int, p->d_sums_dbl, s)) return rc;
+        if (int rc = fit_launch(p, 1, b, (int64_t *)p->d_sums_int, p->d_sums_dbl, nullptr, s)) return rc;
         HIP_TRY(c, hipMemcpyAsync(wtw, p->d_sums_int, (size_t)C * 3 * 21 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipMemcpyAsync(wtr, p->d_sums_dbl, (size_t)C * 18 * sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));

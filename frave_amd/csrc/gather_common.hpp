@@ -80,8 +80,10 @@ __device__ __forceinline__ bool pred_is_block_slot(int slot) {
 // Stages the 36 cells of a tile: 64 lanes x 8 coefficients per cell, int32 -> int16 by truncation. Every Some coefficient
 // fits, and None (INT32_MIN = 0x80000000) truncates to 0, which is what the reference's .unwrap_or(0) reads; a slot without
 // a retained cell is all zeros. One v_perm_b32 packs two low halves.
+// range_counter (may be NULL): incremented once per wave that stages, into a BLOCK slot, a Some coefficient outside [-256, 255] - the
+// precondition of the fit kernels' 32-bit partial sums (every cell is a block cell of exactly one tile).
 __device__ __forceinline__ void pred_stage_tile(const int32_t *__restrict__ coefs, const int32_t *s_slot_cell, uint8_t *s_cells, int lane, int wave,
-                                                uint32_t *outlier_counter = nullptr) {
+                                                uint32_t *range_counter = nullptr) {
     for (int slot = wave; slot < kPredSlots; slot += kPredWaves) {
         const int cell = s_slot_cell[slot];
         int4 lo = make_int4(0, 0, 0, 0), hi = lo;
@@ -89,10 +91,12 @@ __device__ __forceinline__ void pred_stage_tile(const int32_t *__restrict__ coef
             const int4 *src = reinterpret_cast<const int4 *>(coefs + (size_t)cell * kCell + 8 * lane);
             lo = src[0];
             hi = src[1];
-            if (outlier_counter && pred_is_block_slot(slot)) { // every cell is a block cell of exactly one tile
+            if (range_counter && pred_is_block_slot(slot)) {
                 const int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                const uint32_t n = pred_count_outliers(v);
-                if (n) atomicAdd(outlier_counter, n);
+                uint32_t m = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) m |= v[i] == kNone ? 0u : ((uint32_t)v[i] + 256u) & 0xFFFFFE00u;
+                if (__any(m != 0) && lane == 0) atomicAdd(range_counter, 1u);
             }
         }
         auto pk = [](int lo16, int hi16) -> uint32_t { return __builtin_amdgcn_perm((uint32_t)hi16, (uint32_t)lo16, 0x05040100u); };
@@ -107,6 +111,23 @@ __device__ __forceinline__ void pred_stage_tile(const int32_t *__restrict__ coef
     }
 }
 
+// ---- the tile skeleton of round 2's gather kernel (K2 kernel3) -------------------------------------------------------------------------
+// One 1024-thread workgroup per CU, 16 waves. A tile's 36 cells sit in LDS as 16-bit values, 1 KiB per cell, halfword pairs permuted
+// inside their tree level's region (gather_layout.inc, tools/lds_layout_search.py). Two images: tile i + 1 is staged while tile i is worked on.
+constexpr int kP3Threads = 1024;
+constexpr int kP3Waves = kP3Threads / 64;
+static_assert(kP3Waves == kPredBlock * kPredBlock, "one wave per block cell");
+constexpr int kP3SlotBytes = 1024;
+constexpr int kP3ZeroOff = kPredSlots * kP3SlotBytes;          // zero words behind the 36 cells: what "never a node" entries read (one per block cell of a wave, 1 KiB apart)
+constexpr int kP3ImageBytes = kP3ZeroOff + kP3SlotBytes + 64;  // 37 952
+constexpr int kP3Halo = kPredSlots - kPredBlock * kPredBlock;  // 20 halo slots: one whole cell per wave + a quarter of one of the last four
+static_assert(kP3Halo == kP3Waves + kP3Waves / 4, "halo staging: a whole cell per wave, the remaining cells in quarters");
+static_assert(kP3ImageBytes + kP3SlotBytes < 65536, "image + cell offset must fit a DS instruction's 16-bit offset field");
+
+// h-th halo slot of a tile (h < 20): top row, bottom row, left column, right column
+__device__ __forceinline__ int p3_halo_slot(int h) {
+    return h < 6 ? h : h < 12 ? 5 * kPredSide + (h - 6) : h < 16 ? (h - 11) * kPredSide : (h - 15) * kPredSide + 5;
+}
 
 } // namespace
 } // namespace fri

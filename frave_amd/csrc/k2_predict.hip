@@ -378,12 +378,6 @@ __global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const
 //  * lane L owns heap nodes 4L..4L+3 and 256+4L..256+4L+3: its own values come straight from the registers of the staging
 //    loads (exact int32), and a cell leaves as 2 x dwordx4 (predictions) + 2 x dword (bucket bytes) store instructions.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kP3Threads = 1024;
-constexpr int kP3Waves = kP3Threads / 64;
-static_assert(kP3Waves == kPredBlock * kPredBlock, "one wave per block cell");
-constexpr int kP3SlotBytes = 1024;
-constexpr int kP3ZeroOff = kPredSlots * kP3SlotBytes;          // zero words behind the 36 cells: what "never a node" entries read (one per block cell of a wave, 1 KiB apart)
-constexpr int kP3ImageBytes = kP3ZeroOff + kP3SlotBytes + 64;  // 37 952
 struct P3Lds { // static LDS: every address below is a compile-time constant that folds into the DS instructions' offset fields
     uint32_t hist[kHistBins + 4];                       // 10 x 1024 counters + the out-of-alphabet counter (+ pad)
     uint8_t cells[2][kP3ImageBytes];                    // two images of a tile's 36 cells (+ zero words)
@@ -393,14 +387,6 @@ struct P3Lds { // static LDS: every address below is a compile-time constant tha
     uint32_t lf_rel[2][4];                              // the LF pass's offsets (p3_lf_pass), per heap node 0 / 1
 };
 static_assert(sizeof(P3Lds) <= 160 * 1024 && kP3ImageBytes + kP3SlotBytes < 65536, "LDS budget / image + cell offset must fit a DS instruction's 16-bit offset field");
-constexpr int kP3Halo = kPredSlots - kPredBlock * kPredBlock;  // 20 halo slots: one whole cell per wave + a quarter of one of the last four
-static_assert(kP3Halo == kP3Waves + kP3Waves / 4, "halo staging: a whole cell per wave, the remaining cells in quarters");
-
-// h-th halo slot of a tile (h < 20): top row, bottom row, left column, right column
-__device__ __forceinline__ int p3_halo_slot(int h) {
-    return h < 6 ? h : h < 12 ? 5 * kPredSide + (h - 6) : h < 16 ? (h - 11) * kPredSide : (h - 15) * kPredSide + 5;
-}
-
 struct P3Group { // the parameters of one layer group (prediction.rs:165-179)
     float w[6], v[6];
 };

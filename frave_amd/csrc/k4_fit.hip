@@ -28,6 +28,7 @@ struct FitArgs {
     unsigned long long *gram; // [3][28]   (MODE 0)
     unsigned long long *wtw;  // [3][21]   (MODE 1)
     double *wtr;              // [3][6]    (MODE 1)
+    unsigned long long *out_range; // [n_planes] or NULL: waves that staged a Some coefficient outside [-256, 255] (the sums are then not to be trusted)
     unsigned long long *acc;  // plan scratch, all zero between launches: [kFitAccInt] integer sums, [18] f64 bit patterns, then the ticket
     // planes of a batch (grid.y): plane k reads coefs + k * coef_stride, takes its parameters from params[k] (NULL: pp), hands over through
     // acc + k * kFitAccWords and writes gram / wtw + k * 3 * NI, wtr + k * 18
@@ -35,8 +36,8 @@ struct FitArgs {
     const PredictParams *params;
     PredictParams pp3[3]; // plane k < 3 of a launch without a params array
 };
-constexpr int kFitAccInt = 3 * 28, kFitAccDbl = kFitAccInt, kFitAccTicket = kFitAccInt + 18;
-static_assert(kFitAccTicket + 1 == (int)kFitAccWords, "fit accumulator layout");
+constexpr int kFitAccInt = 3 * 28, kFitAccDbl = kFitAccInt, kFitAccTicket = kFitAccInt + 18, kFitAccRange = kFitAccTicket + 1;
+static_assert(kFitAccRange + 1 == (int)kFitAccWords, "fit accumulator layout");
 
 template <int MODE>
 __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const FitArgs a0) {
@@ -45,7 +46,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
     // its three parameter sets would be indexed dynamically and therefore live in scratch memory, and every argument access with it.
     struct {
         const int32_t *coefs;
-        unsigned long long *acc, *gram, *wtw;
+        unsigned long long *acc, *gram, *wtw, *out_range;
         double *wtr;
         const int32_t *pred_slots;
         const uint32_t *pred_off, *valid_mask;
@@ -59,6 +60,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
         a.gram = a0.gram ? a0.gram + (size_t)plane * 3 * NI : nullptr;
         a.wtw = a0.wtw ? a0.wtw + (size_t)plane * 3 * NI : nullptr;
         a.wtr = a0.wtr ? a0.wtr + (size_t)plane * 18 : nullptr;
+        a.out_range = a0.out_range ? a0.out_range + plane : nullptr;
         a.pred_slots = a0.pred_slots, a.pred_off = a0.pred_off, a.valid_mask = a0.valid_mask, a.n_tiles = a0.n_tiles;
         // static indices only: a dynamic index into the argument struct would keep all of it in scratch memory
         if (a0.params)
@@ -73,13 +75,14 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
     __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
     __shared__ int32_t s_slot_cell[kPredSlots];
     __shared__ int32_t s_slot_interior[kPredSlots];
-    __shared__ uint32_t s_flag;
+    __shared__ uint32_t s_flag, s_range;
     __shared__ unsigned long long s_int[3][28];
     __shared__ double s_dbl[3][6];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: slot, cell and the own-slot address become wave-uniform
     if (tid < 3 * 28) (&s_int[0][0])[tid] = 0;
     if (tid < 18) (&s_dbl[0][0])[tid] = 0.0;
+    if (tid == 0) s_range = 0;
 
     const int g = lane < 32 ? 0 : lane < 48 ? 1 : 2;
     const int p0 = lane < 32 ? 256 + lane : lane < 48 ? 128 + (lane - 32) : lane - 48;
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
             s_slot_interior[tid] = pred_slot_interior(raw) ? 1 : 0;
         }
         __syncthreads();
-        pred_stage_tile(a.coefs, s_slot_cell, s_cells, lane, wave);
+        pred_stage_tile(a.coefs, s_slot_cell, s_cells, lane, wave, &s_range);
         __syncthreads();
         for (int r = wave; r < kPredBlock * kPredBlock; r += kPredWaves) {
             const int slot = (1 + r / kPredBlock) * kPredSide + 1 + (r % kPredBlock);
@@ -239,6 +242,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
         __hip_atomic_fetch_add(a.acc + tid, s_int[gg][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (MODE == 1 && tid < 18) __hip_atomic_fetch_add(reinterpret_cast<double *>(a.acc + kFitAccDbl) + tid, (&s_dbl[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && s_range) __hip_atomic_fetch_add(a.acc + kFitAccRange, (unsigned long long)s_range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads(); // vmcnt(0) in every wave: the adds are performed
     if (tid == 0) s_flag = __hip_atomic_fetch_add(a.acc + kFitAccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
@@ -252,13 +256,18 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
         a.wtr[tid] = __builtin_bit_cast(double, u);
         __hip_atomic_store(a.acc + kFitAccDbl + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid == 0) __hip_atomic_store(a.acc + kFitAccTicket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        const unsigned long long r = __hip_atomic_exchange(a.acc + kFitAccRange, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.out_range) *a.out_range = r;
+        __hip_atomic_store(a.acc + kFitAccTicket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 
 } // namespace
 
-hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl, hipStream_t stream) {
+hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
+                                 unsigned long long *out_of_range, hipStream_t stream) {
     if (!acc || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
     FitArgs a{};
     a.coefs = b.coefs;
@@ -275,6 +284,7 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
     a.gram = sums_int;
     a.wtw = sums_int;
     a.wtr = sums_dbl;
+    a.out_range = out_of_range;
     uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
     if (b.n_planes > 1) { // as in launch_predict_histogram: a plane on an eighth of the machine, eight planes side by side
         const uint32_t share = (p.n_pred_tiles + 7) / 8, eighth = p.hist_blocks / 8 ? p.hist_blocks / 8 : 1;

@@ -57,7 +57,7 @@ struct DevicePlan {
 };
 
 constexpr uint32_t kPredJunkWaves = 16, kPredJunkBytes = 2560; // per wave: 512 B of bucket + 2 KiB of prediction
-constexpr uint32_t kFitAccWords = 3 * 28 + 18 + 1;
+constexpr uint32_t kFitAccWords = 3 * 28 + 18 + 2; // integer sums, f64 sums, ticket, out-of-range count
 constexpr uint32_t kPredAccRing = 8, kPredAccWords = 10 * 1024 + 8; // per plane: counts, out-of-alphabet count (u64), ticket, pad, "inexact" flag, the exact kernel's ticket, pad
 
 struct QMatrix {
@@ -90,7 +90,9 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const Pr
                                     bool from_forward_kernel, hipStream_t stream);
 // Fit accumulators: mode 0 = value fit (sums_int[n_planes][3][28]), mode 1 = width fit (sums_int[n_planes][3][21], sums_dbl[n_planes][3][6]).
 // acc: n_planes accumulators of kFitAccWords words, all zero between launches.
-hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl, hipStream_t stream);
+// out_of_range (may be NULL): per plane, the number of waves that staged a Some coefficient outside [-256, 255] - the sums are then not to be trusted.
+hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
+                                 unsigned long long *out_of_range, hipStream_t stream);
 // K3: (reference-faithful) dequantisation + inverse transform + clamp.
 // n_images images of the plan's shape: image k at coefs + k * coef_stride (int32 elements), pixels + k * pixel_stride (bytes)
 hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, const int32_t *coefs, size_t coef_stride, const QMatrix &q, uint8_t *pixels, size_t pixel_stride,

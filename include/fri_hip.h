@@ -54,6 +54,7 @@ extern "C" {
 #define FRI_HIP_ERR_OUT_OF_MEMORY (-4)
 #define FRI_HIP_ERR_DIVIDE_BY_ZERO (-5) /* a used qmatrix entry is 0 (Rust: division panic, quantization.rs:17) */
 #define FRI_HIP_ERR_EMPTY_LATTICE (-6)  /* no retained cell (Rust: index panic, wavelet_transform.rs:664) */
+#define FRI_HIP_ERR_OUT_OF_RANGE (-7)   /* fit sums: a Some coefficient outside [-256, 255] (see fri_hip_fit_value_sums) */
 
 typedef struct fri_hip_ctx fri_hip_ctx;
 typedef struct fri_hip_plan fri_hip_plan;
@@ -179,10 +180,12 @@ int fri_hip_predict_histogram_batch_dev(fri_hip_plan *plan, uint32_t n_planes, c
  * heap index >= 2 only; None rows are all zero in the reference (:109-134).
  * gram[g][28] = upper triangle (row major) of sum u u^T with u = [v0..v5, value], v = get_neighbour_values:
  *              A^T A = rows/columns 0..5, A^T b = column 6, b^T b = entry (6,6). Exact integers.
- * Precondition (both fit entry points): Some coefficients lie in [-255, 255], as every output of
+ * Precondition (all fit entry points): Some coefficients lie in [-256, 255], as every output of
  * fri_hip_transform_quant does (differences of 8-bit pixels, divided by a quantiser >= 1). The kernels stage them as
- * int16 and accumulate products of pairs of rows in 32-bit partial sums (v_dot2) that are widened every 1024 cells;
- * larger magnitudes overflow those partial sums silently. */
+ * int16 and accumulate products of pairs of rows in 32-bit partial sums (v_dot2). The kernels check the range while staging:
+ * the host-pointer forms, fri_hip_encode_image and fri_hip_predict_image (with fit) return FRI_HIP_ERR_OUT_OF_RANGE instead of
+ * sums that overflowed; the _dev forms cannot report it (use fri_hip_predict_histogram's n_out_of_alphabet-style checks on the
+ * host side, or the host forms, for coefficients of unknown origin). */
 int fri_hip_fit_value_sums(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, int64_t gram[3][28]);
 int fri_hip_fit_value_sums_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint32_t channel, int64_t *d_gram, void *stream);
 /* Width fit (optimize_width_prediction, :144-173) for given value parameters x: residual r = |f32(value) - A x| in f32

@@ -4,7 +4,7 @@ compared with a tolerance (summation order is not fixed on the device)."""
 import numpy as np
 import pytest
 
-from tests.common import gen_image, random_params
+from tests.common import KAT_VALUE_PARAMS, gen_image, random_params
 
 pytestmark = pytest.mark.gpu
 
@@ -113,3 +113,28 @@ def test_fitted_parameters_reduce_the_residual(ctx, oracle):
     W.quantize(np.ones(32, np.int32))
     wb, wpred, whist, woob = W.predict(0, vp, wp)
     assert np.array_equal(hist, whist) and np.array_equal(b_, wb) and np.array_equal(p_, wpred) and oob == woob
+
+
+def test_fit_reports_coefficients_outside_its_range(ctx, oracle):
+    """The fit kernels' 32-bit partial sums need |coefficient| <= 256 (everything the forward transform produces). A larger Some value is
+    an error (FRI_HIP_ERR_OUT_OF_RANGE), not silently overflowed sums; None entries and in-range arrays pass; the plan stays usable."""
+    import frave_amd as fa
+
+    w, h, c = 200, 150, 1
+    img = gen_image("noise", w, h, c, 4)
+    P = fa.Plan(ctx, w, h, c)
+    co = P.transform_quant(img)
+    good = P.fit_value_sums(co, 0)
+    bad = co.copy()
+    some = np.flatnonzero(bad.reshape(-1) != fa.NONE)
+    bad.reshape(-1)[some[1234]] = 300
+    with pytest.raises(fa.FriHipError) as e:
+        P.fit_value_sums(bad, 0)
+    assert e.value.code == -7
+    with pytest.raises(fa.FriHipError) as e:
+        P.fit_width_sums(bad, 0, KAT_VALUE_PARAMS)
+    assert e.value.code == -7
+    with pytest.raises(fa.FriHipError) as e:
+        P.predict_image(bad, fit=True)
+    assert e.value.code == -7
+    assert np.array_equal(P.fit_value_sums(co, 0), good)  # and the accumulators were left clean
