@@ -404,6 +404,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             d.junk = static_cast<uint8_t *>(j);
         }
         d.k2_previous = env_int("FRI_HIP_K2_PREVIOUS") > 0;
+        d.k4_previous = env_int("FRI_HIP_K4_PREVIOUS") > 0;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
         d.k2_ablate = env_int("FRI_HIP_K2_ABLATE");

@@ -264,6 +264,253 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 2: the same sums with a third of the instructions. What the kernel above spends per pair of nodes: 14 sign-extending LDS
+// reads, 7 packs, the unpacking and adding of 12 neighbour offsets kept in LDS (~30 instructions), 7 masks, 28 (21) multiply-adds.
+// Here a wave owns ONE pair of a lane's nodes - PG = wave & 3: heap 4 lane + {0, 1}, 4 lane + {2, 3} (levels 0..7),
+// 256 + 4 lane + {0, 1}, 256 + 4 lane + {2, 3} (level 8) - in the eight block cells of two block rows, whose LDS slots lie at fixed
+// distances: twelve precomputed LDS addresses serve all eight cells (the distance rides in the instructions' offset field), and the
+// two nodes of the pair share every register - the first is gathered with ds_read_u16_d16 into the low halves, the second with
+// ds_read_u16_d16_hi into the high halves of the SAME six registers, so the packed operands of v_dot2c_i32_i16 arrive without a pack
+// instruction, and the pair's own values are one aligned dword of the staged cell. Lanes stay bound to layer groups (one set of
+// accumulators per lane): level 8 is group 0; below, lanes 0..31 are group 2 (levels 0..6), lanes 32..63 group 1 (level 7).
+// Staging, tile walk and hand-over are the kernel above's.
+// ---------------------------------------------------------------------------------------------------------------------
+// The six neighbour values of the lane's two nodes in one cell, packed {first node, second node} per register. Plain loads: a d16 load
+// into one half of a register does not keep the other half on this chip (the register's unused half comes back as zero - d16 writes
+// are whole-register when the memories run with ECC), so two 16-bit loads and one v_lshl_or_b32 per packed operand it is.
+template <int OFFSET>
+__device__ __forceinline__ void fit2_gather(uint32_t (&g)[6], const uint32_t (&a)[6], const uint32_t (&b)[6]) {
+    typedef __attribute__((address_space(3))) const uint16_t *lds_u16;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint32_t lo = *(lds_u16)(uintptr_t)(a[k] + OFFSET), hi = *(lds_u16)(uintptr_t)(b[k] + OFFSET);
+        g[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u); // v_perm_b32: the two low halves side by side
+    }
+}
+
+// One pair of nodes of one cell: 28 (value fit) or 21 + 6 (width fit) sums. g: the six packed neighbour values; own: the pair's own
+// values packed the same way; mask: 0xFFFF per Some node of the pair (a None row is all zeros in the reference, :109-134).
+template <int MODE>
+__device__ __forceinline__ void fit2_pair(const uint32_t (&g)[6], uint32_t own, uint32_t mask, const float (&vp)[6], int (&acc)[28], float (&facc)[6]) {
+    s16x2 u[7];
+#pragma unroll
+    for (int k = 0; k < 6; k++) u[k] = __builtin_bit_cast(s16x2, g[k] & mask);
+    u[6] = __builtin_bit_cast(s16x2, own & mask);
+    if (MODE == 0) {
+        int n = 0;
+#pragma unroll
+        for (int r0 = 0; r0 < 7; r0++)
+#pragma unroll
+            for (int c0 = r0; c0 < 7; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(u[r0], u[c0], acc[n], false);
+    } else {
+        // residual r = |f32(value) - A x| in f32, left to right like nalgebra's gemv (context_modeling.rs:150-160), for both nodes; a None row
+        // has every u masked to 0, hence every feature, and contributes nothing
+        float fa[7], fb[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) fa[k] = (float)u[k].x, fb[k] = (float)u[k].y;
+        float pa = __fmul_rn(fa[0], vp[0]), pb = __fmul_rn(fb[0], vp[0]);
+#pragma unroll
+        for (int k = 1; k < 6; k++) pa = __fadd_rn(pa, __fmul_rn(fa[k], vp[k])), pb = __fadd_rn(pb, __fmul_rn(fb[k], vp[k]));
+        const float ra = fabsf(__fsub_rn(fa[6], pa)), rb = fabsf(__fsub_rn(fb[6], pb));
+        // features w = [1, |v0-v3|, |v1-v2|, |v4-v5|, |v1-v5|, |v2-v4|]: packed int16 for the exact integer sums W^T W ...
+        auto absdiff = [&](int k0, int k1) {
+            const s16x2 d = u[k0] - u[k1];
+            return __builtin_elementwise_max(d, -d);
+        };
+        const s16x2 one = __builtin_bit_cast(s16x2, 0x00010001u & mask);
+        const s16x2 w[6] = {one, absdiff(0, 3), absdiff(1, 2), absdiff(4, 5), absdiff(1, 5), absdiff(2, 4)};
+        int n = 0;
+#pragma unroll
+        for (int r0 = 0; r0 < 6; r0++)
+#pragma unroll
+            for (int c0 = r0; c0 < 6; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(w[r0], w[c0], acc[n], false);
+        // ... and floats for W^T r: f32 partial sums over the nodes a lane has in a tile, f64 from there on
+        facc[0] += (float)one.x * ra + (float)one.y * rb;
+        facc[1] += fabsf(fa[0] - fa[3]) * ra + fabsf(fb[0] - fb[3]) * rb;
+        facc[2] += fabsf(fa[1] - fa[2]) * ra + fabsf(fb[1] - fb[2]) * rb;
+        facc[3] += fabsf(fa[4] - fa[5]) * ra + fabsf(fb[4] - fb[5]) * rb;
+        facc[4] += fabsf(fa[1] - fa[5]) * ra + fabsf(fb[1] - fb[5]) * rb;
+        facc[5] += fabsf(fa[2] - fa[4]) * ra + fabsf(fb[2] - fb[4]) * rb;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void fit2_cells(const int32_t *s_slot_cell, const int32_t *s_slot_interior, const uint32_t *mask_word, uint32_t mask_shift, uint32_t keep, int half,
+                                           const uint32_t (&addr)[2][6], uint32_t own_addr, const float (&vp)[6], int (&acc)[28], float (&facc)[6]) {
+    const int slot0 = (1 + 2 * half) * kPredSide + 1; // first block cell of the wave's two block rows
+#define FRI_FIT2_CELL(C)                                                                                                                       \
+    {                                                                                                                                          \
+        constexpr int kOff = ((C >> 2) * kPredSide + (C & 3)) * kSlotStride;                                                                    \
+        const int slot = slot0 + (C >> 2) * kPredSide + (C & 3);                                                                               \
+        const int cell = __builtin_amdgcn_readfirstlane(s_slot_cell[slot]);                                                                    \
+        if (cell >= 0) {                                                                                                                       \
+            const uint32_t own = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(own_addr + kOff);                             \
+            uint32_t g[6];                                                                                                                     \
+            fit2_gather<kOff>(g, addr[0], addr[1]);                                                                                            \
+            uint32_t mask = keep;                                                                                                              \
+            if (__builtin_amdgcn_readfirstlane(s_slot_interior[slot]) == 0) { /* boundary cell: node p is bit (p & 31) of mask word p >> 5 */   \
+                const uint32_t bits = mask_word[(size_t)cell * 16] >> mask_shift;                                                              \
+                mask &= ((bits & 1u) ? 0x0000FFFFu : 0u) | ((bits & 2u) ? 0xFFFF0000u : 0u);                                                   \
+            }                                                                                                                                  \
+            fit2_pair<MODE>(g, own, mask, vp, acc, facc);                                                                                      \
+        }                                                                                                                                      \
+    }
+    FRI_FIT2_CELL(0) FRI_FIT2_CELL(1) FRI_FIT2_CELL(2) FRI_FIT2_CELL(3) FRI_FIT2_CELL(4) FRI_FIT2_CELL(5) FRI_FIT2_CELL(6) FRI_FIT2_CELL(7)
+#undef FRI_FIT2_CELL
+}
+
+// Sum of v over the 16 lanes of the lane's DPP row, in every lane of the row: quad_perm(1,0,3,2), quad_perm(2,3,0,1), row_half_mirror, row_mirror
+__device__ __forceinline__ int fit2_row_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    return v;
+}
+template <int NI>
+__device__ __forceinline__ void fit2_wave_sums(int (&acc)[28], int role, int lane, unsigned long long (*s_int)[28]) {
+#pragma unroll
+    for (int k = 0; k < NI; k++) {
+        const int r = fit2_row_sum(acc[k]);
+        acc[k] = 0;
+        const long long lo = (long long)__builtin_amdgcn_readlane(r, 0) + __builtin_amdgcn_readlane(r, 16);
+        const long long hi = (long long)__builtin_amdgcn_readlane(r, 32) + __builtin_amdgcn_readlane(r, 48);
+        if (lane == 0) {
+            if (role) {
+                atomicAdd(&s_int[0][k], (unsigned long long)(lo + hi));
+            } else {
+                atomicAdd(&s_int[2][k], (unsigned long long)lo);
+                atomicAdd(&s_int[1][k], (unsigned long long)hi);
+            }
+        }
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kPredThreads, MODE == 0 ? 6 : 4) fit_accumulate_kernel2(const FitArgs a0) {
+    constexpr int NI = MODE == 0 ? 28 : 21;
+    const uint32_t plane = blockIdx.y;
+    const int32_t *const coefs = a0.coefs + plane * a0.coef_stride;
+    unsigned long long *const accp = a0.acc + (size_t)plane * kFitAccWords;
+    PredictParams pp; // static indices only: a dynamic index into the argument struct would keep all of it in scratch memory
+    if (a0.params)
+        pp = a0.params[plane];
+    else if (plane == 0)
+        pp = a0.pp3[0];
+    else if (plane == 1)
+        pp = a0.pp3[1];
+    else
+        pp = a0.pp3[2];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
+    __shared__ int32_t s_slot_cell[kPredSlots];
+    __shared__ int32_t s_slot_interior[kPredSlots];
+    __shared__ uint32_t s_flag, s_range;
+    __shared__ unsigned long long s_int[3][28];
+    __shared__ double s_dbl[3][6];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = wave & 3, half = wave >> 2;
+    if (tid < 3 * 28) (&s_int[0][0])[tid] = 0;
+    if (tid < 18) (&s_dbl[0][0])[tid] = 0.0;
+    if (tid == 0) s_range = 0;
+
+    // loop invariants of the lane: LDS addresses (first of the wave's eight cells) of the six neighbours of its two nodes, and of the pair itself
+    const int role = pg >> 1, n0 = 256 * role + 4 * lane + 2 * (pg & 1);
+    const int slot0 = (1 + 2 * half) * kPredSide + 1;
+    const uint32_t cells_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_cells;
+    uint32_t addr[2][6];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const u32x4 o = reinterpret_cast<const u32x4 *>(a0.pred_off)[n0 + j];
+        const uint32_t rel[3] = {o.x, o.y, o.z};
+#pragma unroll
+        for (int k = 0; k < 6; k++) addr[j][k] = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * (int)(short)((rel[k >> 1] >> (16 * (k & 1))) & 0xFFFFu));
+    }
+    const uint32_t own_addr = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * n0);
+    const int group = role ? 0 : lane < 32 ? 2 : 1;
+    // the pair's two bits of a boundary cell's mask (node p is bit p & 31 of word p >> 5); heap index 0 and 1 are coded by the LF predictor
+    // and are not rows of the fit
+    const uint32_t *const mask_word = a0.valid_mask + 8 * role + (lane >> 3);
+    const uint32_t mask_shift = 4 * (lane & 7) + 2 * (pg & 1);
+    const uint32_t keep = (pg == 0 && lane == 0) ? 0u : 0xFFFFFFFFu;
+    float vp[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) vp[k] = group == 0 ? pp.value[0][k] : group == 1 ? pp.value[1][k] : pp.value[2][k]; // selects, not a dynamic index
+    int acc[28];
+    double dacc[6];
+#pragma unroll
+    for (int k = 0; k < 28; k++) acc[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) dacc[k] = 0.0;
+    int tiles_since_flush = 0;
+
+    const PredTileWalk walk(a0.n_tiles);
+    for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step) {
+        __syncthreads();
+        if (tid < kPredSlots) {
+            const int raw = a0.pred_slots[(size_t)tile * kPredSlots + tid];
+            s_slot_cell[tid] = pred_slot_cell(raw);
+            s_slot_interior[tid] = pred_slot_interior(raw) ? 1 : 0;
+        }
+        __syncthreads();
+        pred_stage_tile(coefs, s_slot_cell, s_cells, lane, wave, &s_range);
+        __syncthreads();
+        float facc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        fit2_cells<MODE>(s_slot_cell, s_slot_interior, mask_word, mask_shift, keep, half, addr, own_addr, vp, acc, facc);
+        if (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) dacc[k] += (double)facc[k];
+        }
+        if (++tiles_since_flush >= 16) { // 16 nodes x 256^2 x 2 per tile and lane: a row of 16 lanes stays below 2^31 for 16 tiles
+            fit2_wave_sums<NI>(acc, role, lane, s_int);
+            tiles_since_flush = 0;
+        }
+    }
+    // A wave's sums go to the workgroup's in two steps: across the 16 lanes of a DPP row in registers (4 adds per sum, 32-bit: see the
+    // bound above), the four row totals through readlane into scalars, and lane 0 adds the group totals to LDS - 28 sums cost a wave
+    // ~250 instructions. (The first kernel parks all lanes' sums in LDS and lets one thread per sum walk 32-64 of them: ~6 us per
+    // workgroup, a tenth of the kernel.) Waves of level 8: all four rows are group 0; the others: rows 0, 1 group 2, rows 2, 3 group 1.
+    fit2_wave_sums<NI>(acc, role, lane, s_int);
+    if (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            double v = dacc[k];
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64); // halves of 32 lanes: the layer groups of the role-0 waves
+            if ((lane & 31) == 0) atomicAdd(&s_dbl[role ? 0 : lane ? 1 : 2][k], v);
+        }
+    }
+    __syncthreads();
+    // hand-over: add into the plane's accumulator, draw a ticket, the last workgroup moves the totals out and re-zeroes
+    if (tid < 3 * NI) {
+        const int gg = tid / NI, k = tid % NI;
+        __hip_atomic_fetch_add(accp + tid, s_int[gg][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (MODE == 1 && tid < 18) __hip_atomic_fetch_add(reinterpret_cast<double *>(accp + kFitAccDbl) + tid, (&s_dbl[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && s_range) __hip_atomic_fetch_add(accp + kFitAccRange, (unsigned long long)s_range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads(); // vmcnt(0) in every wave: the adds are performed
+    if (tid == 0) s_flag = __hip_atomic_fetch_add(accp + kFitAccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_flag == 0) return;
+    unsigned long long *const out_int = (MODE == 0 ? a0.gram : a0.wtw) + (size_t)plane * 3 * NI;
+    if (tid < 3 * NI) {
+        out_int[tid] = __hip_atomic_load(accp + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(accp + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (MODE == 1 && tid < 18) {
+        const unsigned long long u = __hip_atomic_load(accp + kFitAccDbl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a0.wtr[(size_t)plane * 18 + tid] = __builtin_bit_cast(double, u);
+        __hip_atomic_store(accp + kFitAccDbl + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+        const unsigned long long r = __hip_atomic_exchange(accp + kFitAccRange, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a0.out_range) a0.out_range[plane] = r;
+        __hip_atomic_store(accp + kFitAccTicket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 } // namespace
 
 hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
@@ -293,10 +540,17 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
         if (blocks > p.n_pred_tiles) blocks = p.n_pred_tiles;
     }
     if (!blocks) blocks = 1;
+    if (p.k4_previous) { // FRI_HIP_TUNING=1 FRI_HIP_K4_PREVIOUS=1: round 1's kernel (A/B on one box)
+        if (mode == 0)
+            hipLaunchKernelGGL(fit_accumulate_kernel<0>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
+        else
+            hipLaunchKernelGGL(fit_accumulate_kernel<1>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
+        return hipGetLastError();
+    }
     if (mode == 0)
-        hipLaunchKernelGGL(fit_accumulate_kernel<0>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
+        hipLaunchKernelGGL(fit_accumulate_kernel2<0>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
     else
-        hipLaunchKernelGGL(fit_accumulate_kernel<1>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
+        hipLaunchKernelGGL(fit_accumulate_kernel2<1>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -39,6 +39,7 @@ struct DevicePlan {
     uint8_t *junk = nullptr;              // [pred_blocks][kPredJunkWaves][kPredJunkBytes]: output lines of block slots without a cell (pipelined K2)
     uint32_t pred_blocks = 0;             // workgroups of the pipelined K2: one 1024-thread workgroup per CU
     bool k2_previous = false;             // tuning: round 1's pipelined K2 (A/B)
+    bool k4_previous = false;             // tuning: round 1's fit kernel (A/B)
     uint32_t n_tiles = 0;
     uint32_t F = 0;
     int32_t width = 0, height = 0, channels = 0;

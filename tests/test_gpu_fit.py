@@ -71,7 +71,8 @@ def test_fit_sums_match_cpu(ctx, oracle, shape, kind):
         assert np.array_equal(gram, want_gram)
         wtw, wtr, rows = P.fit_width_sums(co, ch, vp)
         assert np.array_equal(wtw, want_wtw)
-        assert np.allclose(wtr, want_wtr, rtol=1e-10, atol=1e-6)
+        # W^T r: f32 partial sums over the 16 nodes a lane has in a tile, f64 from there on (the reference's whole fit is f32)
+        assert np.allclose(wtr, want_wtr, rtol=1e-6, atol=1e-3)
         assert rows.tolist() == [P.num_cells * 256, P.num_cells * 128, P.num_cells * 128]
 
 
