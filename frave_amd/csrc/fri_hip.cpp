@@ -410,6 +410,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.k2_ablate = env_int("FRI_HIP_K2_ABLATE");
         if (const char *e = env_str("FRI_HIP_K1_BATCH_SHARES")) d.k1_batch_shares = std::atoi(e) != 0;
         d.k3_ablate = env_int("FRI_HIP_K3_ABLATE");
+        d.k4_ablate = env_int("FRI_HIP_K4_ABLATE");
         d.k3_scan = env_int("FRI_HIP_K3_SCAN") > 0;
         if (!g.inv_lists.empty()) {
             if ((rc = upload(p, g.inv_lists, d.inv_lists)) || (rc = upload(p, g.inv_quads, d.inv_quads)) || (rc = upload(p, g.inv_dwords, d.inv_dwords)) ||

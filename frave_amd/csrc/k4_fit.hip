@@ -35,6 +35,7 @@ struct FitArgs {
     size_t coef_stride;
     const PredictParams *params;
     PredictParams pp3[3]; // plane k < 3 of a launch without a params array
+    int32_t ablate;       // timing-only (tuning build, FRI_HIP_K4_ABLATE): 1 = no sums, 2 = tiles after the first are staged without their global loads
 };
 constexpr int kFitAccInt = 3 * 28, kFitAccDbl = kFitAccInt, kFitAccTicket = kFitAccInt + 18, kFitAccRange = kFitAccTicket + 1;
 static_assert(kFitAccRange + 1 == (int)kFitAccWords, "fit accumulator layout");
@@ -336,29 +337,82 @@ __device__ __forceinline__ void fit2_pair(const uint32_t (&g)[6], uint32_t own, 
     }
 }
 
-template <int MODE>
-__device__ __forceinline__ void fit2_cells(const int32_t *s_slot_cell, const int32_t *s_slot_interior, const uint32_t *mask_word, uint32_t mask_shift, uint32_t keep, int half,
-                                           const uint32_t (&addr)[2][6], uint32_t own_addr, const float (&vp)[6], int (&acc)[28], float (&facc)[6]) {
-    const int slot0 = (1 + 2 * half) * kPredSide + 1; // first block cell of the wave's two block rows
-#define FRI_FIT2_CELL(C)                                                                                                                       \
-    {                                                                                                                                          \
-        constexpr int kOff = ((C >> 2) * kPredSide + (C & 3)) * kSlotStride;                                                                    \
-        const int slot = slot0 + (C >> 2) * kPredSide + (C & 3);                                                                               \
-        const int cell = __builtin_amdgcn_readfirstlane(s_slot_cell[slot]);                                                                    \
-        if (cell >= 0) {                                                                                                                       \
-            const uint32_t own = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(own_addr + kOff);                             \
-            uint32_t g[6];                                                                                                                     \
-            fit2_gather<kOff>(g, addr[0], addr[1]);                                                                                            \
-            uint32_t mask = keep;                                                                                                              \
-            if (__builtin_amdgcn_readfirstlane(s_slot_interior[slot]) == 0) { /* boundary cell: node p is bit (p & 31) of mask word p >> 5 */   \
-                const uint32_t bits = mask_word[(size_t)cell * 16] >> mask_shift;                                                              \
-                mask &= ((bits & 1u) ? 0x0000FFFFu : 0u) | ((bits & 2u) ? 0xFFFF0000u : 0u);                                                   \
-            }                                                                                                                                  \
-            fit2_pair<MODE>(g, own, mask, vp, acc, facc);                                                                                      \
-        }                                                                                                                                      \
+// Staging in two steps, so that a tile's global loads fly while the tile before it is worked on: the loads of a wave's cells (five
+// slots at most, 40 registers), and - behind the sums of the current tile - the conversion to int16 and the LDS writes into the OTHER of
+// two cell images. Layout and range check are pred_stage_tile's (gather_common.hpp).
+constexpr int kFit2Image = kPredSlots * kSlotStride; // 37 440 B; image 1 sits behind image 0, inside the gathers' 16-bit offset field
+static_assert(kFit2Image + (kPredSide + kPredBlock) * kSlotStride < 65536, "image + cell offset must fit a DS instruction's offset field");
+constexpr int kFit2StageSlots = (kPredSlots + kPredWaves - 1) / kPredWaves; // 5: slots wave, wave + 8, ...
+constexpr int kFit2StageSplit = 3; // the first three behind the barrier, the last two halfway through the tile's sums: 24 registers at most
+template <int N>
+struct Fit2Stage {
+    int4 lo[N], hi[N];
+};
+template <int I0, int N>
+__device__ __forceinline__ void fit2_stage_load(Fit2Stage<N> &r, const int32_t *__restrict__ coefs, const int32_t *s_slot_cell, int lane, int wave, bool skip = false) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int slot = wave + kPredWaves * (I0 + i);
+        r.lo[i] = make_int4(0, 0, 0, 0), r.hi[i] = r.lo[i];
+        const int cell = slot < kPredSlots && !skip ? s_slot_cell[slot] : -1;
+        if (cell >= 0) {
+            const int4 *src = reinterpret_cast<const int4 *>(coefs + (size_t)cell * kCell + 8 * lane);
+            r.lo[i] = src[0];
+            r.hi[i] = src[1];
+        }
     }
-    FRI_FIT2_CELL(0) FRI_FIT2_CELL(1) FRI_FIT2_CELL(2) FRI_FIT2_CELL(3) FRI_FIT2_CELL(4) FRI_FIT2_CELL(5) FRI_FIT2_CELL(6) FRI_FIT2_CELL(7)
-#undef FRI_FIT2_CELL
+}
+template <int I0, int N>
+__device__ __forceinline__ void fit2_stage_commit(const Fit2Stage<N> &r, const int32_t *s_slot_cell, uint8_t *image, int lane, int wave, uint32_t *range_counter) {
+    auto pk = [](int lo16, int hi16) -> uint32_t { return __builtin_amdgcn_perm((uint32_t)hi16, (uint32_t)lo16, 0x05040100u); };
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int slot = wave + kPredWaves * (I0 + i);
+        if (slot >= kPredSlots) break;
+        const int4 lo = r.lo[i], hi = r.hi[i];
+        if (pred_is_block_slot(slot) && s_slot_cell[slot] >= 0) { // a None is 0x80000000: its low half stages as 0, and it is not an outlier
+            const int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) m |= v[j] == kNone ? 0u : ((uint32_t)v[j] + 256u) & 0xFFFFFE00u;
+            if (__any(m != 0) && lane == 0) atomicAdd(range_counter, 1u);
+        }
+        uint4 packed;
+        packed.x = pk(lo.x, lo.y);
+        packed.y = pk(lo.z, lo.w);
+        packed.z = pk(hi.x, hi.y);
+        packed.w = pk(hi.z, hi.w);
+        uint8_t *dst = image + slot * kSlotStride;
+        *reinterpret_cast<uint4 *>(dst + 16 * lane) = packed;
+        if (lane == 0) *reinterpret_cast<uint4 *>(dst + 1024) = make_uint4(0, 0, 0, 0);
+    }
+}
+
+template <int MODE, int IMG, int C>
+__device__ __forceinline__ void fit2_cell(const int32_t *s_slot_cell, const int32_t *s_slot_interior, const uint32_t *mask_word, uint32_t mask_shift, uint32_t keep, int slot0,
+                                          const uint32_t (&addr)[2][6], uint32_t own_addr, const float (&vp)[6], int (&acc)[28], float (&facc)[6]) {
+    constexpr int kOff = IMG * kFit2Image + ((C >> 2) * kPredSide + (C & 3)) * kSlotStride;
+    const int slot = slot0 + (C >> 2) * kPredSide + (C & 3);
+    const int cell = __builtin_amdgcn_readfirstlane(s_slot_cell[slot]);
+    if (cell < 0) return;
+    const uint32_t own = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(own_addr + kOff);
+    uint32_t g[6];
+    fit2_gather<kOff>(g, addr[0], addr[1]);
+    uint32_t mask = keep;
+    if (__builtin_amdgcn_readfirstlane(s_slot_interior[slot]) == 0) { // boundary cell: node p is bit (p & 31) of mask word p >> 5
+        const uint32_t bits = mask_word[(size_t)cell * 16] >> mask_shift;
+        mask &= ((bits & 1u) ? 0x0000FFFFu : 0u) | ((bits & 2u) ? 0xFFFF0000u : 0u);
+    }
+    fit2_pair<MODE>(g, own, mask, vp, acc, facc);
+    asm volatile("" ::: "memory"); // one cell's gathers at a time: the next cell's would cost 13 more registers
+}
+template <int MODE, int IMG, int C0>
+__device__ __forceinline__ void fit2_cells(const int32_t *s_slot_cell, const int32_t *s_slot_interior, const uint32_t *mask_word, uint32_t mask_shift, uint32_t keep, int slot0,
+                                           const uint32_t (&addr)[2][6], uint32_t own_addr, const float (&vp)[6], int (&acc)[28], float (&facc)[6]) {
+    fit2_cell<MODE, IMG, C0 + 0>(s_slot_cell, s_slot_interior, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
+    fit2_cell<MODE, IMG, C0 + 1>(s_slot_cell, s_slot_interior, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
+    fit2_cell<MODE, IMG, C0 + 2>(s_slot_cell, s_slot_interior, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
+    fit2_cell<MODE, IMG, C0 + 3>(s_slot_cell, s_slot_interior, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
 }
 
 // Sum of v over the 16 lanes of the lane's DPP row, in every lane of the row: quad_perm(1,0,3,2), quad_perm(2,3,0,1), row_half_mirror, row_mirror
@@ -370,26 +424,19 @@ __device__ __forceinline__ int fit2_row_sum(int v) {
     return v;
 }
 template <int NI>
-__device__ __forceinline__ void fit2_wave_sums(int (&acc)[28], int role, int lane, unsigned long long (*s_int)[28]) {
+__device__ __forceinline__ void fit2_wave_sums(int (&acc)[28], int group, int lane, unsigned long long (*s_int)[28]) {
 #pragma unroll
     for (int k = 0; k < NI; k++) {
         const int r = fit2_row_sum(acc[k]);
         acc[k] = 0;
-        const long long lo = (long long)__builtin_amdgcn_readlane(r, 0) + __builtin_amdgcn_readlane(r, 16);
-        const long long hi = (long long)__builtin_amdgcn_readlane(r, 32) + __builtin_amdgcn_readlane(r, 48);
-        if (lane == 0) {
-            if (role) {
-                atomicAdd(&s_int[0][k], (unsigned long long)(lo + hi));
-            } else {
-                atomicAdd(&s_int[2][k], (unsigned long long)lo);
-                atomicAdd(&s_int[1][k], (unsigned long long)hi);
-            }
-        }
+        const long long sum = ((long long)__builtin_amdgcn_readlane(r, 0) + __builtin_amdgcn_readlane(r, 16)) +
+                              ((long long)__builtin_amdgcn_readlane(r, 32) + __builtin_amdgcn_readlane(r, 48));
+        if (lane == 0) atomicAdd(&s_int[group][k], (unsigned long long)sum);
     }
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(kPredThreads, MODE == 0 ? 6 : 4) fit_accumulate_kernel2(const FitArgs a0) {
+__global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const FitArgs a0) {
     constexpr int NI = MODE == 0 ? 28 : 21;
     const uint32_t plane = blockIdx.y;
     const int32_t *const coefs = a0.coefs + plane * a0.coef_stride;
@@ -403,9 +450,9 @@ __global__ void __launch_bounds__(kPredThreads, MODE == 0 ? 6 : 4) fit_accumulat
         pp = a0.pp3[1];
     else
         pp = a0.pp3[2];
-    __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
-    __shared__ int32_t s_slot_cell[kPredSlots];
-    __shared__ int32_t s_slot_interior[kPredSlots];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cells[2 * kFit2Image]; // two cell images: tile i + 1 is staged while tile i is worked on
+    __shared__ int32_t s_slot_cell[2][kPredSlots];
+    __shared__ int32_t s_slot_interior[2][kPredSlots];
     __shared__ uint32_t s_flag, s_range;
     __shared__ unsigned long long s_int[3][28];
     __shared__ double s_dbl[3][6];
@@ -416,9 +463,12 @@ __global__ void __launch_bounds__(kPredThreads, MODE == 0 ? 6 : 4) fit_accumulat
     if (tid < 18) (&s_dbl[0][0])[tid] = 0.0;
     if (tid == 0) s_range = 0;
 
-    // loop invariants of the lane: LDS addresses (first of the wave's eight cells) of the six neighbours of its two nodes, and of the pair itself
-    const int role = pg >> 1, n0 = 256 * role + 4 * lane + 2 * (pg & 1);
-    const int slot0 = (1 + 2 * half) * kPredSide + 1;
+    // The wave's pair of nodes per lane: wave & 3 = 0: level 7 (128 + 2 lane, + 1), 1: levels 0..6 (2 lane, + 1), 2 and 3: level 8 (256 + 4 lane +
+    // {0, 1} and {2, 3}) - one layer group per wave, so the value parameters are scalars and a wave's sums have one destination.
+    // Loop invariants of the lane: LDS addresses (first of the wave's eight cells) of the six neighbours of its two nodes, and of the pair itself.
+    const int n0 = pg == 0 ? 128 + 2 * lane : pg == 1 ? 2 * lane : 256 + 4 * lane + 2 * (pg & 1);
+    const int group = pg == 0 ? 1 : pg == 1 ? 2 : 0;
+    const int slot0 = (1 + 2 * half) * kPredSide + 1; // first block cell of the wave's two block rows
     const uint32_t cells_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_cells;
     uint32_t addr[2][6];
 #pragma unroll
@@ -429,12 +479,11 @@ __global__ void __launch_bounds__(kPredThreads, MODE == 0 ? 6 : 4) fit_accumulat
         for (int k = 0; k < 6; k++) addr[j][k] = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * (int)(short)((rel[k >> 1] >> (16 * (k & 1))) & 0xFFFFu));
     }
     const uint32_t own_addr = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * n0);
-    const int group = role ? 0 : lane < 32 ? 2 : 1;
     // the pair's two bits of a boundary cell's mask (node p is bit p & 31 of word p >> 5); heap index 0 and 1 are coded by the LF predictor
     // and are not rows of the fit
-    const uint32_t *const mask_word = a0.valid_mask + 8 * role + (lane >> 3);
-    const uint32_t mask_shift = 4 * (lane & 7) + 2 * (pg & 1);
-    const uint32_t keep = (pg == 0 && lane == 0) ? 0u : 0xFFFFFFFFu;
+    const uint32_t *const mask_word = a0.valid_mask + (n0 >> 5);
+    const uint32_t mask_shift = n0 & 31;
+    const uint32_t keep = n0 == 0 ? 0u : 0xFFFFFFFFu;
     float vp[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) vp[k] = group == 0 ? pp.value[0][k] : group == 1 ? pp.value[1][k] : pp.value[2][k]; // selects, not a dynamic index
@@ -446,40 +495,76 @@ __global__ void __launch_bounds__(kPredThreads, MODE == 0 ? 6 : 4) fit_accumulat
     for (int k = 0; k < 6; k++) dacc[k] = 0.0;
     int tiles_since_flush = 0;
 
+    const int ablate = ablate_flags(a0.ablate);
     const PredTileWalk walk(a0.n_tiles);
-    for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step) {
+    uint32_t tile = walk.first;
+    int next_raw = -1; // thread t < 36: slot t of the tile after the current one, requested a tile ahead
+    auto slot_table = [&](int img, int raw) {
+        s_slot_cell[img][tid] = pred_slot_cell(raw);
+        s_slot_interior[img][tid] = pred_slot_interior(raw) ? 1 : 0;
+    };
+    // One tile with image IMG current: publish the next tile's slot table, request its coefficients, do this tile's sums, convert and
+    // write the next tile into the other image. Two barriers per tile.
+#define FRI_FIT2_PHASE(IMG)                                                                                                                       \
+    {                                                                                                                                            \
+        /* behind the last tile an empty table: the staging steps run unconditionally (a conditional definition would make the staged */       \
+        /* registers loop-carried - 80 of them live through the whole loop) and find no cell */                                                  \
+        if (tid < kPredSlots) slot_table(IMG ^ 1, tile + walk.step < walk.end ? next_raw : -1);                                                  \
+        __syncthreads();                                                                                                                         \
+        float facc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                                                                          \
+        {                                                                                                                                        \
+            Fit2Stage<kFit2StageSplit> st;                                                                                                       \
+            fit2_stage_load<0>(st, coefs, s_slot_cell[IMG ^ 1], lane, wave, ablate & 2);                                                         \
+            if (tid < kPredSlots && tile + 2 * walk.step < walk.end) next_raw = a0.pred_slots[(size_t)(tile + 2 * walk.step) * kPredSlots + tid]; \
+            if (!(ablate & 1)) fit2_cells<MODE, IMG, 0>(s_slot_cell[IMG], s_slot_interior[IMG], mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
+            fit2_stage_commit<0>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, lane, wave, &s_range);                               \
+        }                                                                                                                                        \
+        {                                                                                                                                        \
+            Fit2Stage<kFit2StageSlots - kFit2StageSplit> st;                                                                                     \
+            fit2_stage_load<kFit2StageSplit>(st, coefs, s_slot_cell[IMG ^ 1], lane, wave, ablate & 2);                                           \
+            if (!(ablate & 1)) fit2_cells<MODE, IMG, 4>(s_slot_cell[IMG], s_slot_interior[IMG], mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
+            fit2_stage_commit<kFit2StageSplit>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, lane, wave, &s_range);                 \
+        }                                                                                                                                        \
+        if (MODE == 1) {                                                                                                                         \
+            _Pragma("unroll") for (int k = 0; k < 6; k++) dacc[k] += (double)facc[k];                                                            \
+        }                                                                                                                                        \
+        if (++tiles_since_flush >= 16) { /* 16 nodes x 256^2 x 2 per tile and lane: a row of 16 lanes stays below 2^31 for 16 tiles */            \
+            fit2_wave_sums<NI>(acc, group, lane, s_int);                                                                                         \
+            tiles_since_flush = 0;                                                                                                               \
+        }                                                                                                                                        \
+        __syncthreads();                                                                                                                         \
+        tile += walk.step;                                                                                                                       \
+    }
+    if (tile < walk.end) {
+        if (tid < kPredSlots) slot_table(0, a0.pred_slots[(size_t)tile * kPredSlots + tid]);
+        if (tid < kPredSlots && tile + walk.step < walk.end) next_raw = a0.pred_slots[(size_t)(tile + walk.step) * kPredSlots + tid];
         __syncthreads();
-        if (tid < kPredSlots) {
-            const int raw = a0.pred_slots[(size_t)tile * kPredSlots + tid];
-            s_slot_cell[tid] = pred_slot_cell(raw);
-            s_slot_interior[tid] = pred_slot_interior(raw) ? 1 : 0;
+        {
+            Fit2Stage<kFit2StageSlots> st;
+            fit2_stage_load<0>(st, coefs, s_slot_cell[0], lane, wave);
+            fit2_stage_commit<0>(st, s_slot_cell[0], s_cells, lane, wave, &s_range);
         }
         __syncthreads();
-        pred_stage_tile(coefs, s_slot_cell, s_cells, lane, wave, &s_range);
-        __syncthreads();
-        float facc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        fit2_cells<MODE>(s_slot_cell, s_slot_interior, mask_word, mask_shift, keep, half, addr, own_addr, vp, acc, facc);
-        if (MODE == 1) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) dacc[k] += (double)facc[k];
-        }
-        if (++tiles_since_flush >= 16) { // 16 nodes x 256^2 x 2 per tile and lane: a row of 16 lanes stays below 2^31 for 16 tiles
-            fit2_wave_sums<NI>(acc, role, lane, s_int);
-            tiles_since_flush = 0;
+        while (true) {
+            FRI_FIT2_PHASE(0)
+            if (tile >= walk.end) break;
+            FRI_FIT2_PHASE(1)
+            if (tile >= walk.end) break;
         }
     }
+#undef FRI_FIT2_PHASE
     // A wave's sums go to the workgroup's in two steps: across the 16 lanes of a DPP row in registers (4 adds per sum, 32-bit: see the
     // bound above), the four row totals through readlane into scalars, and lane 0 adds the group totals to LDS - 28 sums cost a wave
     // ~250 instructions. (The first kernel parks all lanes' sums in LDS and lets one thread per sum walk 32-64 of them: ~6 us per
-    // workgroup, a tenth of the kernel.) Waves of level 8: all four rows are group 0; the others: rows 0, 1 group 2, rows 2, 3 group 1.
-    fit2_wave_sums<NI>(acc, role, lane, s_int);
+    // workgroup, a tenth of the kernel.)
+    fit2_wave_sums<NI>(acc, group, lane, s_int);
     if (MODE == 1) {
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             double v = dacc[k];
 #pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64); // halves of 32 lanes: the layer groups of the role-0 waves
-            if ((lane & 31) == 0) atomicAdd(&s_dbl[role ? 0 : lane ? 1 : 2][k], v);
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == 0) atomicAdd(&s_dbl[group][k], v);
         }
     }
     __syncthreads();
@@ -532,6 +617,7 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
     a.wtw = sums_int;
     a.wtr = sums_dbl;
     a.out_range = out_of_range;
+    a.ablate = p.k4_ablate;
     uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
     if (b.n_planes > 1) { // as in launch_predict_histogram: a plane on an eighth of the machine, eight planes side by side
         const uint32_t share = (p.n_pred_tiles + 7) / 8, eighth = p.hist_blocks / 8 ? p.hist_blocks / 8 : 1;

@@ -55,6 +55,7 @@ struct DevicePlan {
     int32_t inv_rect_bytes = 0;
     bool k3_scan = false; // FRI_HIP_K3_SCAN=1: always use the scanning kernel (A/B)
     int32_t k3_ablate = 0; // same for the inverse kernel, see InvArgs::ablate
+    int32_t k4_ablate = 0; // same for the fit kernel, see FitArgs::ablate
 };
 
 constexpr uint32_t kPredJunkWaves = 16, kPredJunkBytes = 2560; // per wave: 512 B of bucket + 2 KiB of prediction

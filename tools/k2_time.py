@@ -1,4 +1,4 @@
-"""Time K2 (predict + histogram) and K3 (inverse) at 4096x4096. GPU only."""
+"""Time K2 (predict + histogram), K3 (inverse) and K4 (fit sums) at K2_SIZE x K2_SIZE (default 4096). GPU only."""
 import os
 os.environ.setdefault("FRI_HIP_TUNING", "1")  # opt in to the library's tuning knobs (ablations / trace need `make -C frave_amd/csrc tuning` + FRI_HIP_LIBRARY)
 import sys
@@ -12,13 +12,14 @@ import frave_amd
 C = int(os.environ.get("SWEEP_C", "1"))
 kind = os.environ.get("K2_DATA", "noise")
 ctx = frave_amd.Context(0)
-plan = frave_amd.Plan(ctx, 4096, 4096, C)
+SIZE = int(os.environ.get("K2_SIZE", "4096"))
+plan = frave_amd.Plan(ctx, SIZE, SIZE, C)
 F = plan.num_cells
 if kind == "noise":
     d_px = torch.randint(0, 256, (plan.pixel_bytes,), dtype=torch.uint8, device="cuda")
 else:  # smooth: hot histogram bins
-    y, x = torch.meshgrid(torch.arange(4096, device="cuda"), torch.arange(4096, device="cuda"), indexing="ij")
-    d_px = (((x + 2 * y) >> 3) + torch.randint(0, 8, (4096, 4096), device="cuda")).to(torch.uint8).reshape(-1).repeat_interleave(C)
+    y, x = torch.meshgrid(torch.arange(SIZE, device="cuda"), torch.arange(SIZE, device="cuda"), indexing="ij")
+    d_px = (((x + 2 * y) >> 3) + torch.randint(0, 8, (SIZE, SIZE), device="cuda")).to(torch.uint8).reshape(-1).repeat_interleave(C)
 d_co = torch.empty(plan.coef_count, dtype=torch.int32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 plan.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=s)
