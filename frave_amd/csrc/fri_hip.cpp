@@ -1051,7 +1051,17 @@ int fri_hip_time_transform_quant_dev(fri_hip_plan *p, uint32_t n_images, const u
         HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, 1, d_pixels + (size_t)k * pixel_stride, 0, d_coefs + (size_t)k * coef_stride, 0, q, s));
     }
     HIP_TRY(p->ctx, hipEventRecord(e1, s));
-    HIP_TRY(p->ctx, hipEventSynchronize(e1));
+    // Poll instead of hipEventSynchronize: after a few hundred microseconds the runtime's wait goes to sleep, and the wake-up (15-20 us,
+    // plus as much again in the caller's next synchronize) would be charged to a measurement of twenty 17-us launches.
+    for (uint64_t spins = 0;; spins++) {
+        const hipError_t q = hipEventQuery(e1);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIP_TRY(p->ctx, q);
+        if (spins > (1ull << 22)) { // seconds: not a measurement any more
+            HIP_TRY(p->ctx, hipEventSynchronize(e1));
+            break;
+        }
+    }
     float ms = 0.f;
     HIP_TRY(p->ctx, hipEventElapsedTime(&ms, e0, e1));
     *mean_us = (double)ms * 1000.0 / iters;

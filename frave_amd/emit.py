@@ -29,6 +29,7 @@ def load_library():
         L.fri_emit_encode_image.argtypes = [u32, u32, u32, vp, u32, vp, vp, vp, vp, vp, vp, vp, sz, vp, C.c_char_p, sz]
         L.fri_emit_check_image.argtypes = [vp, sz, u32, vp, u32, vp, vp, vp, C.c_char_p, sz]
         L.fri_emit_decode_image.argtypes = [vp, sz, vp, vp, sz, vp, C.c_char_p, sz]
+        L.fri_emit_rans_selfcheck.argtypes = [C.c_uint64, C.c_uint64, C.c_char_p, sz]
         _lib = L
     return _lib
 
@@ -104,6 +105,14 @@ def check_image(frv, centers, coefs, bucket, prediction):
     rc = load_library().fri_emit_check_image(_p(data), data.size, channels, _p(c), len(c), _p(co), _p(b), _p(p), err, 256)
     if rc != 0:
         raise EmitError(err.value.decode() or f"fri_emit_check_image: {rc}")
+
+
+def rans_selfcheck(n_symbols, seed=1):
+    """The context-parallel rANS coder against the plain one-loop coder on n_symbols pseudo-random symbols. Raises on a difference."""
+    err = C.create_string_buffer(256)
+    rc = load_library().fri_emit_rans_selfcheck(n_symbols, seed, err, 256)
+    if rc != 0:
+        raise EmitError(err.value.decode() or f"fri_emit_rans_selfcheck: {rc}")
 
 
 def decode_image(frv):

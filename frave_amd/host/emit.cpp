@@ -2,6 +2,9 @@
 #include "emit.hpp"
 
 #include <atomic>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <memory>
 #include <mutex>
 
@@ -286,6 +289,36 @@ void channel_symbols(const SymbolOrder &order, const int32_t *coefs, const uint8
     scans.push_back({order.level[0].data(), order.level[0].size(), 0});
     scans.push_back({order.level[0].data(), order.level[0].size(), 1});
     for (int level = 1; level < kDepth; level++) scans.push_back({order.level[level].data(), order.level[level].size(), -1});
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t max_threads = hw ? std::min(hw, 8u) : 4u;
+    auto parallel_for = [&](size_t n_items, auto &&body) { // body(i) for i < n_items, items handed out one at a time
+        const size_t n_threads = std::min(n_items, max_threads);
+        if (n_threads <= 1) {
+            for (size_t i = 0; i < n_items; i++) body(i);
+            return;
+        }
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> workers;
+        for (size_t t = 0; t < n_threads; t++)
+            workers.emplace_back([&] {
+                for (size_t i; (i = next.fetch_add(1)) < n_items;) body(i);
+            });
+        for (std::thread &t : workers) t.join();
+    };
+    // First a streaming pass that folds a node's three arrays into one word - bucket << 16 | symbol, all ones for a None - so that the
+    // gather below takes one cache miss per symbol instead of three (the order jumps from cell to cell).
+    size_t n_nodes = 0; // every retained cell is in the level-0 list
+    for (uint32_t e : order.level[0]) n_nodes = std::max(n_nodes, ((size_t)(e >> 9) + 1) * kNodes);
+    constexpr uint32_t kNoSymbol = 0xFFFFFFFFu;
+    std::vector<uint32_t> packed(n_nodes);
+    constexpr size_t kPackChunk = 1u << 18;
+    parallel_for((n_nodes + kPackChunk - 1) / kPackChunk, [&](size_t i) {
+        const size_t end = std::min(n_nodes, (i + 1) * kPackChunk);
+        for (size_t at = i * kPackChunk; at < end; at++) {
+            const uint32_t sym = pack_signed((int32_t)((uint32_t)coefs[at] - (uint32_t)prediction[at]));
+            packed[at] = coefs[at] == kNone ? kNoSymbol : ((uint32_t)bucket[at] << 16) | std::min(sym, 0xFFFFu); // (a symbol >= 1024 is an error later on)
+        }
+    });
     constexpr size_t kChunk = 1u << 18;
     struct Chunk {
         size_t scan, begin, end;
@@ -295,31 +328,21 @@ void channel_symbols(const SymbolOrder &order, const int32_t *coefs, const uint8
     std::vector<Chunk> chunks;
     for (size_t sc = 0; sc < scans.size(); sc++)
         for (size_t b = 0; b < scans[sc].n; b += kChunk) chunks.push_back(Chunk{sc, b, std::min(scans[sc].n, b + kChunk), {}, {}});
-    auto fill = [&](Chunk &c) {
+    parallel_for(chunks.size(), [&](size_t i) {
+        Chunk &c = chunks[i];
         const Scan &sc = scans[c.scan];
-        c.sym.reserve(c.end - c.begin);
-        c.bkt.reserve(c.end - c.begin);
+        c.sym.resize(c.end - c.begin);
+        c.bkt.resize(c.end - c.begin);
+        size_t n = 0;
         for (size_t k = c.begin; k < c.end; k++) {
             const uint32_t e = sc.list[k];
-            const size_t at = (size_t)(e >> 9) * kNodes + (sc.fixed_heap >= 0 ? (uint32_t)sc.fixed_heap : (e & 511u));
-            if (coefs[at] == kNone) continue; // `if let Some(value)`, entropy_coding.rs:288, :300, :317
-            c.sym.push_back((uint16_t)pack_signed((int32_t)((uint32_t)coefs[at] - (uint32_t)prediction[at])));
-            c.bkt.push_back(bucket[at]);
+            const uint32_t v = packed[(size_t)(e >> 9) * kNodes + (sc.fixed_heap >= 0 ? (uint32_t)sc.fixed_heap : (e & 511u))];
+            c.sym[n] = (uint16_t)v, c.bkt[n] = (uint8_t)(v >> 16);
+            n += v != kNoSymbol; // `if let Some(value)`, entropy_coding.rs:288, :300, :317: a None yields no symbol
         }
-    };
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t n_threads = std::min<size_t>(chunks.size(), hw ? std::min(hw, 8u) : 4u);
-    if (n_threads <= 1) {
-        for (Chunk &c : chunks) fill(c);
-    } else {
-        std::atomic<size_t> next{0};
-        std::vector<std::thread> workers;
-        for (size_t t = 0; t < n_threads; t++)
-            workers.emplace_back([&] {
-                for (size_t i; (i = next.fetch_add(1)) < chunks.size();) fill(chunks[i]);
-            });
-        for (std::thread &t : workers) t.join();
-    }
+        c.sym.resize(n);
+        c.bkt.resize(n);
+    });
     size_t total = 0;
     for (const Chunk &c : chunks) total += c.sym.size();
     symbols.resize(total);
@@ -330,6 +353,191 @@ void channel_symbols(const SymbolOrder &order, const int32_t *coefs, const uint8
         std::copy(c.bkt.begin(), c.bkt.end(), buckets.begin() + (long)at);
         at += c.sym.size();
     }
+}
+
+// Highest index i in [lo, hi) with bytes[i] == value, SIZE_MAX if there is none: 16 bytes per step where SSE2 is there (x86-64 always).
+static inline size_t prev_equal(const uint8_t *bytes, size_t lo, size_t hi, uint8_t value) {
+#if defined(__SSE2__)
+    const __m128i needle = _mm_set1_epi8((char)value);
+    while (hi - lo >= 16) {
+        const unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(bytes + hi - 16)), needle));
+        if (m) return hi - 16 + (31u - (unsigned)__builtin_clz(m));
+        hi -= 16;
+    }
+#endif
+    while (hi > lo)
+        if (bytes[--hi] == value) return hi;
+    return SIZE_MAX;
+}
+
+// The symbols fed in reverse (entropy_coding.rs:332-334) into ten rANS states, one per context, that share one word stream. A state's
+// history depends on its own symbols only, and a step emits at most one 32-bit word, so the coder runs context by context on
+// threads of its own - each context notes AT WHICH symbols it emitted a word - and the shared stream is put together afterwards: the
+// words in order of decreasing symbol index, then the flush. Byte for byte what the one-loop coder (`sequential`) produces.
+std::string encode_symbols(const std::vector<uint16_t> &symbols, const std::vector<uint8_t> &buckets, const std::vector<RansEncoderMulti::EncSymbol> &tab,
+                           std::vector<uint8_t> &data, bool sequential) {
+    const size_t n = symbols.size();
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_threads = std::min<size_t>(kContexts, hw ? std::min(hw, 8u) : 4u);
+    if (sequential || n < (1u << 16) || n >= (1ull << 32) || n_threads <= 1) {
+        RansEncoderMulti enc;
+        enc.reserve(n);
+        for (size_t k = n; k-- > 0;) {
+            const uint32_t sym = symbols[k];
+            if (sym >= (uint32_t)kAlphabet) return "symbol outside the alphabet (libfri panics, entropy_coding.rs:99)";
+            if (buckets[k] >= kContexts) return "bucket outside 0..9";
+            const RansEncoderMulti::EncSymbol &e = tab[(size_t)buckets[k] * kAlphabet + sym];
+            if (e.freq == 0) return "symbol with zero model frequency";
+            enc.put_symbol(buckets[k], e);
+        }
+        enc.flush_all();
+        data = enc.data();
+        return "";
+    }
+    constexpr size_t kSpan = 1u << 16; // symbols per span of the stitching pass
+    const size_t n_spans = (n + kSpan - 1) / kSpan;
+    struct PerContext {
+        std::vector<uint32_t> words;  // emitted words, in emission order (decreasing symbol index)
+        std::vector<uint32_t> before; // [span]: words emitted before the coder entered the span (spans are entered last to first)
+        uint64_t x = 1ull << 31;
+        size_t n_symbols = 0, error_at = SIZE_MAX;
+        const char *error = nullptr;
+    };
+    std::vector<PerContext> ctx(kContexts);
+    std::vector<uint8_t> emitted(n, 0); // 1: the step of symbol k emitted a word
+    auto run_context = [&](int b) {
+        PerContext &c = ctx[(size_t)b];
+        c.before.assign(n_spans, 0);
+        const RansEncoderMulti::EncSymbol *t = tab.data() + (size_t)b * kAlphabet;
+        uint64_t x = c.x;
+        for (size_t sp = n_spans; sp-- > 0;) {
+            c.before[sp] = (uint32_t)c.words.size();
+            const size_t lo = sp * kSpan, hi = std::min(n, lo + kSpan);
+            size_t k = hi;
+            while (k > lo) {
+                k = prev_equal(buckets.data(), lo, k, (uint8_t)b); // the context's next symbol below k
+                if (k == SIZE_MAX) break;
+                c.n_symbols++;
+                const uint32_t sym = symbols[k];
+                if (sym >= (uint32_t)kAlphabet) {
+                    c.error_at = k, c.error = "symbol outside the alphabet (libfri panics, entropy_coding.rs:99)";
+                    return;
+                }
+                const RansEncoderMulti::EncSymbol &e = t[sym];
+                if (e.freq == 0) {
+                    c.error_at = k, c.error = "symbol with zero model frequency";
+                    return;
+                }
+                if (x >= e.x_max) {
+                    c.words.push_back((uint32_t)x);
+                    emitted[k] = 1;
+                    x >>= 32;
+                }
+                const uint64_t q = (uint64_t)(((unsigned __int128)x * e.rcp_freq) >> 64) >> e.rcp_shift;
+                x = x + e.bias + q * e.cmpl_freq;
+            }
+        }
+        c.x = x;
+    };
+    {
+        std::atomic<int> next{0};
+        std::vector<std::thread> workers;
+        for (size_t t = 0; t < n_threads; t++)
+            workers.emplace_back([&] {
+                for (int b; (b = next.fetch_add(1)) < kContexts;) run_context(b);
+            });
+        for (std::thread &t : workers) t.join();
+    }
+    // the error the one-loop coder would have met first: the one at the highest symbol index
+    const PerContext *bad = nullptr;
+    size_t seen = 0;
+    for (const PerContext &c : ctx) {
+        seen += c.n_symbols;
+        if (c.error && (!bad || c.error_at > bad->error_at)) bad = &c;
+    }
+    if (bad) return bad->error;
+    if (seen != n) return "bucket outside 0..9";
+    // stitching: span sp's words start at position (words of all later spans) in emission order; inside a span the contexts' words
+    // interleave as their symbols do
+    std::vector<size_t> first(n_spans + 1, 0); // first[sp]: emission-order position of span sp's first word; spans are emitted last to first
+    size_t total = 0;
+    for (size_t sp = n_spans; sp-- > 0;) {
+        first[sp] = total;
+        for (const PerContext &c : ctx) total += (sp ? c.before[sp - 1] : c.words.size()) - c.before[sp];
+    }
+    const size_t n_words = total + 2 * kContexts;
+    data.assign(n_words * 4, 0);
+    auto put = [&](size_t emission_pos, uint32_t w) { // the stream is the emission order backwards (RansEncoderMulti::data)
+        uint8_t *d = data.data() + 4 * (n_words - 1 - emission_pos);
+        d[0] = (uint8_t)w, d[1] = (uint8_t)(w >> 8), d[2] = (uint8_t)(w >> 16), d[3] = (uint8_t)(w >> 24);
+    };
+    auto stitch = [&](size_t sp) {
+        size_t cur[kContexts];
+        for (int b = 0; b < kContexts; b++) cur[b] = ctx[(size_t)b].before[sp];
+        size_t pos = first[sp];
+        const size_t lo = sp * kSpan, hi = std::min(n, lo + kSpan);
+        for (size_t k = hi; k > lo;) {
+            k = prev_equal(emitted.data(), lo, k, 1);
+            if (k == SIZE_MAX) break;
+            const int b = buckets[k];
+            put(pos++, ctx[(size_t)b].words[cur[b]++]);
+        }
+    };
+    {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> workers;
+        for (size_t t = 0; t < n_threads; t++)
+            workers.emplace_back([&] {
+                for (size_t sp; (sp = next.fetch_add(1)) < n_spans;) stitch(sp);
+            });
+        for (std::thread &t : workers) t.join();
+    }
+    size_t pos = total;
+    for (int b = 0; b < kContexts; b++) { // flush_all: each flush prepends two words, state kContexts - 1 ends up first in the stream
+        put(pos++, (uint32_t)(ctx[(size_t)b].x >> 32));
+        put(pos++, (uint32_t)ctx[(size_t)b].x);
+    }
+    return "";
+}
+
+// The context-parallel rANS coder against the plain one-loop coder on pseudo-random symbols (see fri_emit.h).
+int rans_selfcheck(uint64_t n_symbols, uint64_t seed, std::string &err) {
+    if (n_symbols == 0 || n_symbols >= (1ull << 31)) return err = "invalid argument", -1;
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
+    auto rnd = [&]() {
+        s ^= s << 13, s ^= s >> 7, s ^= s << 17;
+        return (uint32_t)(s >> 24);
+    };
+    std::vector<uint16_t> symbols(n_symbols);
+    std::vector<uint8_t> buckets(n_symbols);
+    std::vector<uint32_t> hist((size_t)kContexts * kAlphabet, 0);
+    for (uint64_t k = 0; k < n_symbols; k++) {
+        const uint32_t r = rnd();
+        const int b = (int)((r >> 8) % 13u < 10u ? (r >> 8) % 13u : (r >> 12) % 3u); // uneven context sizes
+        const uint32_t spread = 1u << (2 + b % 8);                                   // narrow and wide distributions
+        const uint32_t sym = std::min<uint32_t>((rnd() % spread) + (rnd() % spread) * (rnd() & 1u), kAlphabet - 1);
+        symbols[k] = (uint16_t)sym, buckets[k] = (uint8_t)b;
+        hist[(size_t)b * kAlphabet + sym]++;
+    }
+    std::vector<RansEncoderMulti::EncSymbol> tab((size_t)kContexts * kAlphabet, RansEncoderMulti::EncSymbol{0, 0, 0, 0, 0, 0});
+    for (int b = 0; b < kContexts; b++) {
+        AnsContext c;
+        uint64_t sum = 0;
+        for (int j = 0; j < kAlphabet; j++) c.freqs[j] = hist[(size_t)b * kAlphabet + j], sum += c.freqs[j];
+        if (sum == 0) continue; // (a context without symbols is never looked up)
+        c.max_freq_bits = trailing_zeros64(prev_power_two(sum));
+        const std::string e = c.finalize(b);
+        if (!e.empty()) return err = "context " + std::to_string(b) + ": " + e, -2;
+        for (int j = 0; j < kAlphabet; j++)
+            if (c.freqs[j]) tab[(size_t)b * kAlphabet + j] = RansEncoderMulti::make_symbol(c.cdf[j], c.freqs[j], c.max_freq_bits);
+    }
+    std::vector<uint8_t> plain, parallel;
+    std::string e = encode_symbols(symbols, buckets, tab, plain, true);
+    if (!e.empty()) return err = "one-loop coder: " + e, -2;
+    e = encode_symbols(symbols, buckets, tab, parallel, false);
+    if (!e.empty()) return err = "context-parallel coder: " + e, -2;
+    if (plain != parallel) return err = "the two coders' streams differ (" + std::to_string(plain.size()) + " / " + std::to_string(parallel.size()) + " bytes)", -4;
+    return 0;
 }
 
 std::string encode_channel(const SymbolOrder &order, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction, const uint32_t *hist,
@@ -349,8 +557,6 @@ std::string encode_channel(const SymbolOrder &order, const int32_t *coefs, const
     std::vector<uint16_t> symbols;
     std::vector<uint8_t> buckets;
     channel_symbols(order, coefs, bucket, prediction, symbols, buckets);
-    RansEncoderMulti enc;
-    enc.reserve(symbols.size());
     // per (context, symbol): the coder step with its division precomputed; a zero-frequency symbol keeps freq = 0 and is an error when met
     std::vector<RansEncoderMulti::EncSymbol> tab((size_t)kContexts * kAlphabet);
     for (int b = 0; b < kContexts; b++)
@@ -358,15 +564,8 @@ std::string encode_channel(const SymbolOrder &order, const int32_t *coefs, const
             const AnsContext &c = out.contexts[b];
             tab[(size_t)b * kAlphabet + j] = c.freqs[j] ? RansEncoderMulti::make_symbol(c.cdf[j], c.freqs[j], c.max_freq_bits) : RansEncoderMulti::EncSymbol{0, 0, 0, 0, 0, 0};
         }
-    for (size_t k = symbols.size(); k-- > 0;) { // fed in reverse, :332-334
-        const uint32_t sym = symbols[k];
-        if (sym >= (uint32_t)kAlphabet) return "symbol outside the alphabet (libfri panics, entropy_coding.rs:99)";
-        const RansEncoderMulti::EncSymbol &e = tab[(size_t)buckets[k] * kAlphabet + sym];
-        if (e.freq == 0) return "symbol with zero model frequency";
-        enc.put_symbol(buckets[k], e);
-    }
-    enc.flush_all();
-    out.data = enc.data();
+    const std::string err = encode_symbols(symbols, buckets, tab, out.data);
+    if (!err.empty()) return err;
     out.n_symbols = symbols.size();
     return "";
 }

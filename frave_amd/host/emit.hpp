@@ -111,6 +111,10 @@ std::string encode_channel(const SymbolOrder &order, const int32_t *coefs, const
                            ChannelStream &out);
 // All channels of an image, one thread per channel (they only share the read-only order). planes: [channels][n_cells][512],
 // hist: [channels][10][1024]. Returns "" or "channel c: reason".
+// the rANS stream of a channel's symbols (fed in reverse); sequential = the plain one-loop coder (the check of the per-context one)
+std::string encode_symbols(const std::vector<uint16_t> &symbols, const std::vector<uint8_t> &buckets, const std::vector<RansEncoderMulti::EncSymbol> &tab,
+                           std::vector<uint8_t> &data, bool sequential = false);
+int rans_selfcheck(uint64_t n_symbols, uint64_t seed, std::string &err); // fri_emit_rans_selfcheck, fri_emit.h
 std::string encode_channels(const SymbolOrder &order, uint32_t channels, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction,
                             const uint32_t *hist, std::vector<ChannelStream> &out);
 // The (symbol, bucket) sequence in stream order (what encode_channel feeds to the coder); for self-checks.

@@ -110,6 +110,13 @@ int fri_emit_check_image(const uint8_t *frv, size_t len, uint32_t channels, cons
     return 0;
 }
 
+// The context-parallel rANS coder against the plain one-loop coder on pseudo-random symbols (see fri_emit.h).
+int fri_emit_rans_selfcheck(uint64_t n_symbols, uint64_t seed, char *err, size_t err_cap) {
+    std::string e;
+    const int rc = rans_selfcheck(n_symbols, seed, e);
+    return rc == 0 ? 0 : fail(err, err_cap, e, rc);
+}
+
 // A .frv back to coefficient planes. info = {width, height, channels, n_cells}; coefs: [channels][n_cells][512] (None = INT32_MIN),
 // centers: [n_cells][2] or null. Returns -3 with `info` filled if coef_cap (in elements) is too small: call once with coef_cap = 0.
 int fri_emit_decode_image(const uint8_t *frv, size_t len, uint32_t info[4], int32_t *coefs, size_t coef_cap, int32_t *centers, char *err, size_t err_cap) {

@@ -60,6 +60,11 @@ int fri_emit_check_image(const uint8_t *frv, size_t len, uint32_t channels, cons
  * (in elements) is too small: call once with coefs = NULL to size the buffer. */
 int fri_emit_decode_image(const uint8_t *frv, size_t len, uint32_t info[4], int32_t *coefs, size_t coef_cap, int32_t *centers, char *err, size_t err_cap);
 
+/* Self-check of the rANS stage: n_symbols pseudo-random symbols (seed) over ten contexts with finalised random models, coded once by the
+ * plain one-loop coder (the reference's order of operations, entropy_coding.rs:332-347) and once by the library's context-parallel
+ * coder; 0 = the two streams are byte-identical, -4 = they differ, -1 = invalid argument. Host only. */
+int fri_emit_rans_selfcheck(uint64_t n_symbols, uint64_t seed, char *err, size_t err_cap);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

@@ -23,7 +23,7 @@ def test_emit_library_exports_every_declared_symbol():
 
     lib = emit.load_library()
     names = declared_symbols("fri_emit.h", "fri_emit_")
-    assert len(names) == 6
+    assert len(names) == 7
     for name in names:
         assert hasattr(lib, name), name
         assert ctypes.cast(getattr(lib, name), ctypes.c_void_p).value

@@ -203,6 +203,13 @@ def test_golden_frv_files_decode(name):
     assert (dw, dh, dc) == (w, h, c) and np.array_equal(got.reshape(-1), np.asarray(coefs).reshape(-1))
 
 
+@pytest.mark.parametrize("n,seed", [(1, 1), (1000, 2), (65535, 3), (65536, 4), (65537, 5), (300000, 6), (3000001, 7)])
+def test_context_parallel_rans_coder_equals_the_one_loop_coder(n, seed):
+    """Large channels are coded context by context on threads and stitched (emit.cpp encode_symbols); the stream must be byte for byte
+    what the reference's single loop over the symbols (entropy_coding.rs:332-347) gives - also around the span size of the stitching pass."""
+    emit.rans_selfcheck(n, seed)
+
+
 def test_full_decode_rejects_damaged_files():
     w, h, c = 129, 65, 1
     W, coefs, bucket, pred, hist, vp, wp = _arrays(w, h, c, 3)

@@ -1,0 +1,35 @@
+"""Host emit (symbol order, ANS models, rANS, container) timed on the CPU alone: the inputs come from the CPU oracle instead of the device
+kernels (same arrays), so this runs without a GPU. First call of a geometry builds and caches the symbol order; the following ones are
+what every further image of that size costs.   python tools/emit_time.py [width height channels]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from frave_amd import emit
+from oracle import fri_oracle
+from tests.common import KAT_VALUE_PARAMS, KAT_WIDTH_PARAMS, gen_image
+
+w, h, c = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (4096, 4096, 1)
+fri_oracle.build()
+img = gen_image("noise", w, h, c, 5)
+img[:, : w // 2] = gen_image("smooth", w // 2, h, c, 6)
+t0 = time.perf_counter()
+W = fri_oracle.Wavelet(img, h, w, c)
+W.quantize(np.ones(32, np.int32))
+co = W.coefficients()
+vp = np.stack([KAT_VALUE_PARAMS] * c)
+wp = np.stack([KAT_WIDTH_PARAMS] * c)
+per = [W.predict(ch, vp[ch], wp[ch]) for ch in range(c)]
+centers = W.centers()
+W.close()
+b = np.stack([p[0] for p in per])
+pr = np.stack([p[1] for p in per])
+hist = np.stack([p[2] for p in per])
+print(f"oracle inputs for {w}x{h}x{c}: {time.perf_counter() - t0:.1f} s, {len(centers)} cells")
+for k in range(5):
+    t0 = time.perf_counter()
+    frv = emit.encode_image(w, h, centers, co, b, pr, hist, vp, wp)
+    print(f"encode_image call {k}: {time.perf_counter() - t0:.3f} s, {len(frv)} bytes")

@@ -11,8 +11,9 @@ import frave_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 C = int(os.environ.get("SWEEP_C", "1"))
 ctx = frave_amd.Context(0)
-plan = frave_amd.Plan(ctx, 4096, 4096, C)
-slots = 8
+SIZE = int(os.environ.get("K1_SIZE", "4096"))
+plan = frave_amd.Plan(ctx, SIZE, SIZE, C)
+slots = int(os.environ.get("K1_SLOTS", "8" if SIZE <= 4096 else "1"))
 d_px = torch.randint(0, 256, (slots, plan.pixel_bytes), dtype=torch.uint8, device="cuda")
 d_co = torch.empty((slots, plan.coef_count), dtype=torch.int32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
@@ -20,4 +21,4 @@ spin = int(os.environ.get("K1_SPIN_UP", "3000"))  # untimed: a fresh GPU needs t
 if spin:
     plan.time_transform_quant_dev(slots, d_px.data_ptr(), plan.pixel_bytes, d_co.data_ptr(), plan.coef_count, spin, stream=s)
 us = plan.time_transform_quant_dev(slots, d_px.data_ptr(), plan.pixel_bytes, d_co.data_ptr(), plan.coef_count, n, stream=s)
-print(f"K1 {us:.2f} us/launch over {n} launches")
+print(f"K1 {SIZE}x{SIZE}x{C}: {us:.2f} us/launch over {n} launches, {slots} rotating slot(s)")
