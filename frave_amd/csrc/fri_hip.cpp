@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <string>
@@ -76,6 +77,8 @@ struct fri_hip_plan {
     unsigned long long *d_oob_all = nullptr;  // [C]
     unsigned long long *d_sums_int = nullptr; // [C][3][28]
     double *d_sums_dbl = nullptr;             // [C][3][6]
+    void *d_h_sums = nullptr;                 // the device's address of h_sums: the fit kernels of the encode chain write their sums straight into it
+    uint64_t fit_seq = 0;                     // value of the next hand-over flag (h_sums' last words)
     void *h_sums = nullptr;                   // pinned: the fit sums on their way to the host's 6 x 6 solves (a pageable target makes each of the two round trips several times longer)
     uint32_t acc_next = 0;
     bool acc_dirty = false; // a launch on this plan failed: the accumulators are re-zeroed before the next use
@@ -405,6 +408,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         }
         d.k2_previous = env_int("FRI_HIP_K2_PREVIOUS") > 0;
         d.k4_previous = env_int("FRI_HIP_K4_PREVIOUS") > 0;
+        d.fit_no_poll = env_int("FRI_HIP_FIT_NO_POLL") > 0;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
         d.k2_ablate = env_int("FRI_HIP_K2_ABLATE");
@@ -664,10 +668,11 @@ static int predict_launch(fri_hip_plan *p, const PredBatch &b, uint8_t *d_bucket
     return FRI_HIP_OK;
 }
 // d_range (may be NULL): per plane, how many waves staged a Some coefficient outside [-256, 255] (include/fri_hip.h: the fit's precondition)
-static int fit_launch(fri_hip_plan *p, int mode, const PredBatch &b, int64_t *d_int, double *d_dbl, unsigned long long *d_range, hipStream_t stream) {
+static int fit_launch(fri_hip_plan *p, int mode, const PredBatch &b, int64_t *d_int, double *d_dbl, unsigned long long *d_range, hipStream_t stream,
+                      unsigned long long *d_done_flag = nullptr, unsigned long long done_value = 0) {
     const int slot = acquire_acc(p, stream, b.n_planes);
     if (slot < 0) return slot;
-    if (hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream)) {
+    if (hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream, d_done_flag, done_value)) {
         p->acc_dirty = true;
         return fail_hip(p->ctx, e, "launch_fit_accumulate");
     }
@@ -810,6 +815,43 @@ int fri_hip_fit_width_sums(fri_hip_plan *p, const int32_t *coefs, uint32_t chann
 
 /* ---- the 6 x 6 solves behind the fit -------------------------------------------------------------- */
 void fri_hip_solve6(const double m[6][6], const double y[6], double x[6]) {
+    // A system that is positive definite with room to spare (every Cholesky pivot above 1e-8 of the largest diagonal entry - any image with
+    // texture in the layer group) has one solution and no direction for a cut-off to drop: Cholesky, ~150 flops instead of the
+    // eigen-decomposition's ~15 000 (six of these solves per channel sit between the encode chain's kernels).
+    {
+        double l[6][6], dmax = 0.0;
+        for (int i = 0; i < 6; i++) dmax = std::fmax(dmax, m[i][i]);
+        bool ok = dmax > 0.0 && std::isfinite(dmax);
+        for (int j = 0; j < 6 && ok; j++) {
+            double d = m[j][j];
+            for (int k = 0; k < j; k++) d -= l[j][k] * l[j][k];
+            if (!(d > 1e-8 * dmax)) {
+                ok = false;
+                break;
+            }
+            l[j][j] = std::sqrt(d);
+            for (int i = j + 1; i < 6; i++) {
+                double t = m[i][j];
+                for (int k = 0; k < j; k++) t -= l[i][k] * l[j][k];
+                l[i][j] = t / l[j][j];
+            }
+        }
+        if (ok) {
+            double z[6];
+            for (int i = 0; i < 6; i++) { // L z = y
+                double t = y[i];
+                for (int k = 0; k < i; k++) t -= l[i][k] * z[k];
+                z[i] = t / l[i][i];
+            }
+            for (int i = 5; i >= 0; i--) { // L^T x = z
+                double t = z[i];
+                for (int k = i + 1; k < 6; k++) t -= l[k][i] * x[k];
+                x[i] = t / l[i][i];
+            }
+            return;
+        }
+    }
+    // Otherwise (rank-deficient or nearly so: flat regions, a feature that is zero everywhere) the minimum-norm solution, as lstsq's SVD gives it.
     // cyclic Jacobi: a = V diag(lam) V^T; x = sum over the eigen-directions above the cut-off of v (v . y) / lam
     double a[6][6], v[6][6];
     for (int i = 0; i < 6; i++)
@@ -887,6 +929,9 @@ void fri_hip_fit_width_params(const int64_t wtw[3][21], const double wtr[3][6], 
 }
 
 /* ---- the device part of FRIEncoder::encode in one call ------------------------------------------------ */
+// h_sums (pinned, device-visible): [3][3][28] int64 sums | [3][3][6] f64 sums | [3] out-of-range counts | [3] hand-over flags
+constexpr size_t kHostSumsInt = 0, kHostSumsDbl = 3 * 3 * 28 * sizeof(int64_t), kHostSumsRange = kHostSumsDbl + 3 * 18 * sizeof(double),
+                 kHostSumsFlag = kHostSumsRange + 3 * sizeof(unsigned long long), kHostSumsBytes = kHostSumsFlag + 3 * sizeof(unsigned long long);
 static int ensure_encode_staging(fri_hip_plan *p) {
     fri_hip_ctx *c = p->ctx;
     const size_t C = p->geo.channels, plane = p->geo.centers.size() * kCell;
@@ -896,7 +941,11 @@ static int ensure_encode_staging(fri_hip_plan *p) {
     if (!p->d_oob_all) HIP_TRY(c, hipMalloc((void **)&p->d_oob_all, C * sizeof(unsigned long long)));
     if (!p->d_sums_int) HIP_TRY(c, hipMalloc((void **)&p->d_sums_int, C * 3 * 28 * sizeof(unsigned long long)));
     if (!p->d_sums_dbl) HIP_TRY(c, hipMalloc((void **)&p->d_sums_dbl, C * 18 * sizeof(double)));
-    if (!p->h_sums) HIP_TRY(c, hipHostMalloc(&p->h_sums, 3 * (3 * 28 * sizeof(int64_t) + 18 * sizeof(double)) + 3 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!p->h_sums) {
+        HIP_TRY(c, hipHostMalloc(&p->h_sums, kHostSumsBytes, hipHostMallocMapped));
+        std::memset(p->h_sums, 0, kHostSumsBytes);
+        HIP_TRY(c, hipHostGetDevicePointer(&p->d_h_sums, p->h_sums, 0));
+    }
     return FRI_HIP_OK;
 }
 
@@ -914,24 +963,64 @@ static int predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, f
     b.coef_stride = plane;
     b.out_stride = plane;
     if (fit) { // ContextModeler::optimize_parameters per channel (prediction.rs:232-235, context_modeling.rs:204-213)
-        int64_t(*sums)[3][28] = static_cast<int64_t(*)[3][28]>(p->h_sums);
-        int64_t(*wtw)[3][21] = static_cast<int64_t(*)[3][21]>(p->h_sums);
-        double(*wtr)[3][6] = reinterpret_cast<double(*)[3][6]>(static_cast<int64_t *>(p->h_sums) + 3 * 3 * 28);
-        unsigned long long *h_range = reinterpret_cast<unsigned long long *>(static_cast<char *>(p->h_sums) + 3 * (3 * 28 * sizeof(int64_t) + 18 * sizeof(double)));
-        if (int rc = fit_launch(p, 0, b, (int64_t *)p->d_sums_int, nullptr, p->d_oob_all, s)) return rc;
-        HIP_TRY(c, hipMemcpyAsync(sums, p->d_sums_int, (size_t)C * 3 * 28 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(h_range, p->d_oob_all, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        char *const hs = static_cast<char *>(p->h_sums), *const ds = static_cast<char *>(p->d_h_sums);
+        int64_t(*sums)[3][28] = reinterpret_cast<int64_t(*)[3][28]>(hs + kHostSumsInt);
+        int64_t(*wtw)[3][21] = reinterpret_cast<int64_t(*)[3][21]>(hs + kHostSumsInt);
+        double(*wtr)[3][6] = reinterpret_cast<double(*)[3][6]>(hs + kHostSumsDbl);
+        unsigned long long *h_range = reinterpret_cast<unsigned long long *>(hs + kHostSumsRange);
+        volatile unsigned long long *h_flag = reinterpret_cast<volatile unsigned long long *>(hs + kHostSumsFlag);
+        // Two round trips to the host's 6 x 6 solves. The fit kernel's last workgroup writes the sums straight into pinned host memory
+        // and raises a flag behind them (system-scope release); the host polls the flag - no copy command, no stream synchronisation
+        // (those cost ~60 us per round trip, more than the kernel in front of them). The tuning build's first fit kernel has no such
+        // hand-over: copy + synchronise there.
+        const bool poll = !p->dev.k4_previous && !p->dev.fit_no_poll;
+        auto wait_for = [&](unsigned long long seq) -> int {
+            if (poll) {
+                for (uint64_t spins = 0; spins < (1ull << 26); spins++) {
+                    bool all = true;
+                    for (uint32_t ch = 0; ch < C; ch++) all = all && h_flag[ch] == seq;
+                    if (all) {
+                        std::atomic_thread_fence(std::memory_order_acquire);
+                        return FRI_HIP_OK;
+                    }
+                    if ((spins & 0xFFF) == 0xFFF && hipStreamQuery(s) != hipErrorNotReady) break; // the stream ran dry (or failed) without raising the flags
+                }
+                HIP_TRY(c, hipStreamSynchronize(s)); // reports the launch's error if there was one
+                for (uint32_t ch = 0; ch < C; ch++)
+                    if (h_flag[ch] != seq) return fail_hip(c, hipErrorUnknown, "fit hand-over flag not raised");
+                return FRI_HIP_OK;
+            }
+            HIP_TRY(c, hipStreamSynchronize(s));
+            return FRI_HIP_OK;
+        };
+        unsigned long long seq = ++p->fit_seq;
+        if (poll) {
+            if (int rc = fit_launch(p, 0, b, reinterpret_cast<int64_t *>(ds + kHostSumsInt), nullptr, reinterpret_cast<unsigned long long *>(ds + kHostSumsRange), s,
+                                    reinterpret_cast<unsigned long long *>(ds + kHostSumsFlag), seq))
+                return rc;
+        } else {
+            if (int rc = fit_launch(p, 0, b, (int64_t *)p->d_sums_int, nullptr, p->d_oob_all, s)) return rc;
+            HIP_TRY(c, hipMemcpyAsync(sums, p->d_sums_int, (size_t)C * 3 * 28 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(h_range, p->d_oob_all, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        }
+        if (int rc = wait_for(seq)) return rc;
         for (uint32_t ch = 0; ch < C; ch++)
             if (h_range[ch]) return FRI_HIP_ERR_OUT_OF_RANGE; // a Some coefficient outside [-256, 255]: the fit's 32-bit partial sums would overflow
         for (uint32_t ch = 0; ch < C; ch++) {
             fri_hip_fit_value_params(sums[ch], reinterpret_cast<float(*)[6]>(value_params + ch * 18));
             std::memcpy(b.pp[ch].value, value_params + ch * 18, sizeof(b.pp[ch].value));
         }
-        if (int rc = fit_launch(p, 1, b, (int64_t *)p->d_sums_int, p->d_sums_dbl, nullptr, s)) return rc;
-        HIP_TRY(c, hipMemcpyAsync(wtw, p->d_sums_int, (size_t)C * 3 * 21 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(wtr, p->d_sums_dbl, (size_t)C * 18 * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        seq = ++p->fit_seq;
+        if (poll) {
+            if (int rc = fit_launch(p, 1, b, reinterpret_cast<int64_t *>(ds + kHostSumsInt), reinterpret_cast<double *>(ds + kHostSumsDbl), nullptr, s,
+                                    reinterpret_cast<unsigned long long *>(ds + kHostSumsFlag), seq))
+                return rc;
+        } else {
+            if (int rc = fit_launch(p, 1, b, (int64_t *)p->d_sums_int, p->d_sums_dbl, nullptr, s)) return rc;
+            HIP_TRY(c, hipMemcpyAsync(wtw, p->d_sums_int, (size_t)C * 3 * 21 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(wtr, p->d_sums_dbl, (size_t)C * 18 * sizeof(double), hipMemcpyDeviceToHost, s));
+        }
+        if (int rc = wait_for(seq)) return rc;
         const uint64_t rows[3] = {F * 256, F * 128, F * 128}; // num_ctx_last_layer / num_ctx_middle_layer, context_modeling.rs:84-85
         for (uint32_t ch = 0; ch < C; ch++) fri_hip_fit_width_params(wtw[ch], wtr[ch], rows, reinterpret_cast<float(*)[6]>(width_params + ch * 18));
     }

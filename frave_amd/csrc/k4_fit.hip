@@ -35,6 +35,10 @@ struct FitArgs {
     size_t coef_stride;
     const PredictParams *params;
     PredictParams pp3[3]; // plane k < 3 of a launch without a params array
+    // Host hand-over (the encode chain): when set, the sums go to pinned host memory and the plane's last workgroup then stores done_value to
+    // done_flag[plane] with system-scope release - the host polls the flag instead of queueing a copy and waiting for the stream.
+    unsigned long long *done_flag;
+    unsigned long long done_value;
     int32_t ablate;       // timing-only (tuning build, FRI_HIP_K4_ABLATE): 1 = no sums, 2 = tiles after the first are staged without their global loads
 };
 constexpr int kFitAccInt = 3 * 28, kFitAccDbl = kFitAccInt, kFitAccTicket = kFitAccInt + 18, kFitAccRange = kFitAccTicket + 1;
@@ -579,10 +583,12 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     if (tid == 0) s_flag = __hip_atomic_fetch_add(accp + kFitAccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (s_flag == 0) return;
+    // one wave moves everything out: its own vmcnt(0) then covers every store the flag below has to come after
+    if (tid >= 64) return;
     unsigned long long *const out_int = (MODE == 0 ? a0.gram : a0.wtw) + (size_t)plane * 3 * NI;
-    if (tid < 3 * NI) {
-        out_int[tid] = __hip_atomic_load(accp + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(accp + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < 3 * NI; i += 64) {
+        out_int[i] = __hip_atomic_load(accp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(accp + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (MODE == 1 && tid < 18) {
         const unsigned long long u = __hip_atomic_load(accp + kFitAccDbl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -594,12 +600,16 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         if (a0.out_range) a0.out_range[plane] = r;
         __hip_atomic_store(accp + kFitAccTicket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (a0.done_flag) {
+        __builtin_amdgcn_s_waitcnt(0); // (every lane's stores are out; the release below writes back this XCD's L2 and waits once more)
+        if (tid == 0) __hip_atomic_store(a0.done_flag + plane, a0.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 } // namespace
 
 hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
-                                 unsigned long long *out_of_range, hipStream_t stream) {
+                                 unsigned long long *out_of_range, hipStream_t stream, unsigned long long *done_flag, unsigned long long done_value) {
     if (!acc || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
     FitArgs a{};
     a.coefs = b.coefs;
@@ -618,6 +628,9 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
     a.wtr = sums_dbl;
     a.out_range = out_of_range;
     a.ablate = p.k4_ablate;
+    a.done_flag = done_flag;
+    a.done_value = done_value;
+    if (done_flag && p.k4_previous) return hipErrorInvalidValue; // (the first kernel has no host hand-over)
     uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
     if (b.n_planes > 1) { // as in launch_predict_histogram: a plane on an eighth of the machine, eight planes side by side
         const uint32_t share = (p.n_pred_tiles + 7) / 8, eighth = p.hist_blocks / 8 ? p.hist_blocks / 8 : 1;

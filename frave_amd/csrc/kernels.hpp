@@ -40,6 +40,7 @@ struct DevicePlan {
     uint32_t pred_blocks = 0;             // workgroups of the pipelined K2: one 1024-thread workgroup per CU
     bool k2_previous = false;             // tuning: round 1's pipelined K2 (A/B)
     bool k4_previous = false;             // tuning: round 1's fit kernel (A/B)
+    bool fit_no_poll = false;             // tuning: the encode chain fetches the fit sums with copy + stream synchronisation instead of the polled hand-over (A/B)
     uint32_t n_tiles = 0;
     uint32_t F = 0;
     int32_t width = 0, height = 0, channels = 0;
@@ -94,7 +95,7 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const Pr
 // acc: n_planes accumulators of kFitAccWords words, all zero between launches.
 // out_of_range (may be NULL): per plane, the number of waves that staged a Some coefficient outside [-256, 255] - the sums are then not to be trusted.
 hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
-                                 unsigned long long *out_of_range, hipStream_t stream);
+                                 unsigned long long *out_of_range, hipStream_t stream, unsigned long long *done_flag = nullptr, unsigned long long done_value = 0);
 // K3: (reference-faithful) dequantisation + inverse transform + clamp.
 // n_images images of the plan's shape: image k at coefs + k * coef_stride (int32 elements), pixels + k * pixel_stride (bytes)
 hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, const int32_t *coefs, size_t coef_stride, const QMatrix &q, uint8_t *pixels, size_t pixel_stride,

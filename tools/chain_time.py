@@ -1,0 +1,39 @@
+"""Time the device-resident encode chain (fri_hip_encode_image_dev) at 4096x4096xC with and without the fit. GPU only.
+FRI_HIP_TUNING=1 FRI_HIP_FIT_NO_POLL=1: the fit sums come back by copy + stream synchronisation instead of the polled hand-over (A/B)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import frave_amd
+
+C = int(os.environ.get("SWEEP_C", "1"))
+ctx = frave_amd.Context(0)
+plan = frave_amd.Plan(ctx, 4096, 4096, C)
+F = plan.num_cells
+d_px = torch.randint(0, 256, (plan.pixel_bytes,), dtype=torch.uint8, device="cuda")
+d_co = torch.empty(plan.coef_count, dtype=torch.int32, device="cuda")
+d_b = torch.empty(C * F * 512, dtype=torch.uint8, device="cuda")
+d_p = torch.empty(C * F * 512, dtype=torch.int32, device="cuda")
+d_h = torch.empty(C * 10 * 1024, dtype=torch.int32, device="cuda")
+d_o = torch.empty(C, dtype=torch.int64, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+vp = np.tile(np.array([0.25, 0.25, 0.25, 0.125, 0.0625, 0.0625], np.float32), (C, 3, 1))
+wp = np.tile(np.array([1.0, 0.5, 0.25, 0.25, 0.125, 0.125], np.float32), (C, 3, 1))
+plan.time_transform_quant_dev(1, d_px.data_ptr(), plan.pixel_bytes, d_co.data_ptr(), plan.coef_count, 2000, stream=s)  # clocks up
+for fit in (False, True):
+    vpf, wpf = vp.copy(), wp.copy()
+    call = lambda: plan.encode_image_dev(d_px.data_ptr(), d_co.data_ptr(), d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), vpf, wpf, fit=fit, stream=s)
+    for _ in range(5):
+        call()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 50
+    for _ in range(reps):
+        call()
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / reps * 1e6
+    print(f"4096x4096x{C} encode chain, fit={fit}: {us:8.1f} us per image (wall clock, {reps} images back to back)")
