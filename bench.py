@@ -31,7 +31,7 @@ def measured_traffic():
     """HBM bytes per K1 launch from the committed rocprofv3 PMC pass (profiles/), or None. bench.py cannot collect
     hardware counters itself; the number is tied to the kernel named in the file."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_k1_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_k1_traffic.json")) as f:
             return int(json.load(f)["hbm_bytes_per_launch"])
     except Exception:
         return None
