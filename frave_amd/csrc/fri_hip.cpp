@@ -324,6 +324,8 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         if (tp.target_wgs <= 0 && ctx) tp.target_wgs = ctx->cu_count * ranks;
     };
     set_ranks(env_int("FRI_HIP_RANKS") > 0 ? std::min(env_int("FRI_HIP_RANKS"), 4) : 4);
+    bool many_shares = false;
+    auto ctx_wgs = [](const fri_hip_ctx *c, int ranks) { return c ? c->cu_count * ranks : 1024; };
     // Shrink the tiles until they fit the forward kernel's static register / LDS budget (irregular centre spacing
     // makes a few tiles wider than the average; RGB triples the bytes per pixel).
     for (;;) {
@@ -343,6 +345,18 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             const int resident = (int)std::min<size_t>(4, (160 * 1024) / fwd_lds_bytes(probe));
             if (ctx && env_int("FRI_HIP_RANKS") <= 0 && resident >= 1 && resident < tp.ranks) { // e.g. RGB: three workgroups per CU
                 set_ranks(resident);
+                continue;
+            }
+            // Large images: with one share per resident workgroup every workgroup streams through its own 1/1024 of the image for the whole
+            // launch - 1024 read and 1024 write fronts spread over all of it (1.4 GB at 16384^2). Many short shares (~32 cells), handed
+            // out in dispatch order, let the resident set slide over the image instead: 8192^2 60.2 -> 56.5 us, 12000^2 120.7 -> 107.1 us,
+            // 16384^2 297-311 -> 275-279 us (tools/sweep_16k_shares.sh; equal shares: the dispatch-rank weights are for a launch of one round).
+            // Below ~128 cells per workgroup (8192^2: neutral) the one-round launch with weighted shares is kept.
+            const size_t F = p->geo.centers.size(), one_round = (size_t)ctx_wgs(ctx, tp.ranks);
+            if (ctx && !many_shares && env_int("FRI_HIP_TARGET_WGS") <= 0 && tp.cells_per_wg <= 0 && F >= 128 * one_round) {
+                many_shares = true;
+                tp.target_wgs = (int)(((F / 32 + 1023) / 1024) * 1024);
+                for (int i = 0; i < 4; i++) tp.rank_weight[i] = i < tp.ranks ? 1.f : 0.f;
                 continue;
             }
             break;
@@ -394,6 +408,14 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.max_wg_tiles = std::max(g.max_wg_tiles, g.max_wg_tiles_batch);
         d.n_wg_batch = (uint32_t)g.wg_tiles_batch.size() - 1;
         d.max_wg_cells = g.max_wg_cells;
+        // the inverse kernel keeps one share per resident workgroup: with the forward kernel's many short shares it walks groups of them
+        d.inv_group = many_shares && g.wg_tiles.size() > 1 && (g.wg_tiles.size() - 1) % 1024 == 0 ? (int32_t)((g.wg_tiles.size() - 1) / 1024) : 1;
+        d.inv_max_wg_tiles = d.inv_group > 1 ? 0 : d.max_wg_tiles, d.inv_max_wg_cells = d.inv_group > 1 ? 0 : d.max_wg_cells;
+        for (size_t sh = 0; d.inv_group > 1 && sh + d.inv_group < g.wg_tiles.size(); sh += d.inv_group) {
+            const Tile &first = g.tiles[g.wg_tiles[sh]], &last = g.tiles[g.wg_tiles[sh + d.inv_group] - 1];
+            d.inv_max_wg_cells = std::max(d.inv_max_wg_cells, last.cell_begin + last.cell_count - first.cell_begin);
+            d.inv_max_wg_tiles = std::max(d.inv_max_wg_tiles, g.wg_tiles[sh + d.inv_group] - g.wg_tiles[sh]);
+        }
         d.n_wg = (uint32_t)g.wg_tiles.size() - 1;
         d.pred_blocks = (uint32_t)ctx->cu_count;
         if (env_int("FRI_HIP_PRED_BLOCKS") > 0) d.pred_blocks = (uint32_t)env_int("FRI_HIP_PRED_BLOCKS");

@@ -535,6 +535,7 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
     return hipGetLastError();
 }

@@ -1068,6 +1068,7 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const Pr
         if (!bucket || !prediction || b.n_planes != 1) return hipErrorInvalidValue;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(predict_histogram_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, kPred2LdsBytes);
         if (e != hipSuccess) return e;
+        (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
         hipLaunchKernelGGL(predict_histogram_kernel2, dim3(blocks), dim3(kPred2Threads), kPred2LdsBytes, stream, a);
         return hipGetLastError();
     }
@@ -1075,6 +1076,7 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const Pr
     a.pair_pos = p.pair_pos;
     a.heap_of_pos = p.heap_of_pos;
     a.ablate = p.k2_ablate;
+    (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
     hipLaunchKernelGGL(predict_histogram_kernel3, dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess || from_forward_kernel) return e; // the forward kernel's coefficients are differences of 8-bit pixels divided by a quantiser: always representable
@@ -1095,6 +1097,7 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const Pr
     x.acc = acc;
     x.F = p.F;
     const uint32_t xb = p.F < blocks ? p.F : blocks;
+    (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
     hipLaunchKernelGGL(exact_predict_kernel, dim3(xb ? xb : 1, b.n_planes), dim3(kCell), 0, stream, x);
     return hipGetLastError();
 }

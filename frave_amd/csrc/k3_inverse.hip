@@ -28,7 +28,8 @@ struct InvArgs {
     const TileCell *tile_meta; // in tile order
     const int32_t *wg_tiles;   // [n_wg + 1]
     int32_t width, height, channels;
-    uint32_t F, n_wg;
+    uint32_t F, n_wg;          // n_wg: workgroups = groups of `group` consecutive shares
+    uint32_t group;
     int32_t buf_bytes;   // LDS pixel rectangle (16 bit per byte), multiple of 16
     int32_t queue_bytes; // LDS rim queue per wave
     int32_t max_wg_tiles;
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
     TileCell *lds_cells = reinterpret_cast<TileCell *>(lds_tiles + a.max_wg_tiles);
     // Blocks of one XCD take a contiguous range of shares: the rim bytes of neighbouring tiles complete their lines in ONE L2.
     const uint32_t wg = xcd_contiguous_share(blockIdx.x, a.n_wg);
-    const int tb = a.wg_tiles[wg], te = a.wg_tiles[wg + 1];
+    const int tb = a.wg_tiles[wg * a.group], te = a.wg_tiles[wg * a.group + a.group];
     const int C = a.channels;
     const uint32_t base_lo = (uint32_t)reinterpret_cast<uintptr_t>(img_pixels);
     const uint32_t wc = (uint32_t)a.width * (uint32_t)C;
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(co
     InvTileLists *lds_lists = reinterpret_cast<InvTileLists *>(lds_tiles + a.max_wg_tiles);
     TileCell *lds_cells = reinterpret_cast<TileCell *>(lds_lists + a.max_wg_tiles);
     const uint32_t wg = xcd_contiguous_share(blockIdx.x, a.n_wg);
-    const int tb = a.wg_tiles[wg], te = a.wg_tiles[wg + 1];
+    const int tb = a.wg_tiles[wg * a.group], te = a.wg_tiles[wg * a.group + a.group];
     const int C = a.channels;
     const size_t wc = (size_t)a.width * (size_t)C;
     trace_stamp(a.trace, wg, 0, tid);
@@ -437,7 +438,7 @@ static size_t inv_queue_bytes(const DevicePlan &p) {
     const size_t quads = (size_t)p.lds_rows * (size_t)(p.lds_pitch / 16);
     return (((quads + kInvThreads - 1) / kInvThreads) * 64 * 2 + 15) & ~(size_t)15;
 }
-size_t inv_lds_bytes(const DevicePlan &p) { return inv_buf_bytes(p) + kInvWaves * inv_queue_bytes(p) + (size_t)p.max_wg_tiles * sizeof(Tile) + (size_t)p.max_wg_cells * sizeof(TileCell); }
+size_t inv_lds_bytes(const DevicePlan &p) { return inv_buf_bytes(p) + kInvWaves * inv_queue_bytes(p) + (size_t)p.inv_max_wg_tiles * sizeof(Tile) + (size_t)p.inv_max_wg_cells * sizeof(TileCell); }
 hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, const int32_t *coefs, size_t coef_stride, const QMatrix &q, uint8_t *pixels, size_t pixel_stride,
                                     hipStream_t stream) {
     if (!n_images || n_images > 65535u) return hipErrorInvalidValue;
@@ -461,9 +462,10 @@ hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, cons
     a.height = p.height;
     a.channels = p.channels;
     a.F = p.F;
-    a.n_wg = p.n_wg;
+    a.group = (uint32_t)p.inv_group;
+    a.n_wg = p.n_wg / a.group;
     a.buf_bytes = (int32_t)inv_buf_bytes(p);
-    a.max_wg_tiles = p.max_wg_tiles;
+    a.max_wg_tiles = p.inv_max_wg_tiles;
     a.ablate = p.k3_ablate;
     a.trace = p.trace;
     a.q = q;
@@ -471,7 +473,7 @@ hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, cons
     for (int i = 0; i <= 9; i++) a.q_identity &= (q.q[i] == 1);
     a.queue_bytes = (int32_t)inv_queue_bytes(p);
     const int items_per_wave = (p.max_tile_cells * p.channels + kInvWaves - 1) / kInvWaves;
-    if (items_per_wave > kInvMaxItemsPerWave || p.max_wg_tiles > kInvThreads || p.lds_rows > 256 || p.lds_pitch / 16 > 256) return hipErrorInvalidConfiguration;
+    if (items_per_wave > kInvMaxItemsPerWave || p.inv_max_wg_tiles > kInvThreads || p.lds_rows > 256 || p.lds_pitch / 16 > 256) return hipErrorInvalidConfiguration;
     // static write-out lists when every image row starts 16-byte aligned
     const bool lists = p.inv_lists && !p.k3_scan && (reinterpret_cast<uintptr_t>(pixels) & 15) == 0 && (((size_t)p.width * p.channels) & 15) == 0 &&
                        (n_images == 1 || (pixel_stride & 15) == 0);
@@ -481,13 +483,14 @@ hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, cons
         a.dwords = p.inv_dwords;
         a.parts = p.inv_parts;
         a.rect_bytes = p.inv_rect_bytes;
-        const size_t lds2 = (size_t)p.inv_rect_bytes + (size_t)p.max_wg_tiles * (sizeof(Tile) + sizeof(InvTileLists)) + (size_t)p.max_wg_cells * sizeof(TileCell);
+        const size_t lds2 = (size_t)p.inv_rect_bytes + (size_t)p.inv_max_wg_tiles * (sizeof(Tile) + sizeof(InvTileLists)) + (size_t)p.inv_max_wg_cells * sizeof(TileCell);
         void (*k2)(const InvArgs) = items_per_wave <= 1 ? inverse_transform_lists_kernel<1> : items_per_wave == 2 ? inverse_transform_lists_kernel<2> : inverse_transform_lists_kernel<4>;
         if (lds2 > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k2, dim3(p.n_wg, n_images), dim3(kInvThreads), lds2, stream, a);
+        (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
+        hipLaunchKernelGGL(k2, dim3(a.n_wg, n_images), dim3(kInvThreads), lds2, stream, a);
         return hipGetLastError();
     }
     const size_t lds = inv_lds_bytes(p);
@@ -496,7 +499,8 @@ hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, cons
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(p.n_wg, n_images), dim3(kInvThreads), lds, stream, a);
+    (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
+    hipLaunchKernelGGL(kern, dim3(a.n_wg, n_images), dim3(kInvThreads), lds, stream, a);
     return hipGetLastError();
 }
 

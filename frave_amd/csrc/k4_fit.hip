@@ -640,12 +640,14 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
     }
     if (!blocks) blocks = 1;
     if (p.k4_previous) { // FRI_HIP_TUNING=1 FRI_HIP_K4_PREVIOUS=1: round 1's kernel (A/B on one box)
+        (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
         if (mode == 0)
             hipLaunchKernelGGL(fit_accumulate_kernel<0>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
         else
             hipLaunchKernelGGL(fit_accumulate_kernel<1>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
         return hipGetLastError();
     }
+    (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
     if (mode == 0)
         hipLaunchKernelGGL(fit_accumulate_kernel2<0>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
     else

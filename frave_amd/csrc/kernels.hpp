@@ -22,6 +22,8 @@ struct DevicePlan {
     bool covers_image = false;            // every pixel of the image is a leaf of a retained cell
     int32_t max_wg_tiles = 0;
     int32_t max_wg_cells = 0;             // most cells in one workgroup share
+    int32_t inv_group = 1;                // the inverse kernel's workgroups walk this many consecutive shares each (large images: K1 wants many short shares, K3 one per resident workgroup)
+    int32_t inv_max_wg_tiles = 0, inv_max_wg_cells = 0; // the same two maxima per group of inv_group shares
     const Int2 *centers = nullptr;
     const uint8_t *interior = nullptr;
     const uint32_t *valid_mask = nullptr; // [F][16]

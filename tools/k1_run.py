@@ -21,4 +21,4 @@ spin = int(os.environ.get("K1_SPIN_UP", "3000"))  # untimed: a fresh GPU needs t
 if spin:
     plan.time_transform_quant_dev(slots, d_px.data_ptr(), plan.pixel_bytes, d_co.data_ptr(), plan.coef_count, spin, stream=s)
 us = plan.time_transform_quant_dev(slots, d_px.data_ptr(), plan.pixel_bytes, d_co.data_ptr(), plan.coef_count, n, stream=s)
-print(f"K1 {SIZE}x{SIZE}x{C}: {us:.2f} us/launch over {n} launches, {slots} rotating slot(s)")
+print(f"K1 {SIZE}x{SIZE}x{C}: {us:.2f} us/launch over {n} launches, {slots} rotating slot(s), {plan.tiling()['n_wg']} shares")
