@@ -323,6 +323,21 @@ def test_config5_16384_square(ctx):
     assert int(d_b.view(P.num_cells, 512)[~valid].max()) == 0 and int(d_p.view(P.num_cells, 512)[~valid].abs().max()) == 0
 
 
+def test_large_image_short_shares_against_the_oracle(ctx, oracle):
+    """From 128 cells per resident workgroup on (8192 x 8192 is the first square size) the plan cuts the image into many short shares
+    and the inverse kernel walks groups of them: the full coefficient array against the oracle, and the way back."""
+    w = h = 8192
+    P = _plan(ctx, w, h, 1)
+    assert P.tiling()["n_wg"] > 1024 and P.tiling()["n_wg"] % 1024 == 0
+    img = gen_image("noise", w, h, 1, 8)
+    img[:100] = gen_image("smooth", w, 100, 1, 9)
+    co = P.transform_quant(img)
+    W = oracle.Wavelet(img, h, w, 1)
+    assert np.array_equal(co, W.coefficients())
+    W.close()
+    assert np.array_equal(P.inverse_transform(co), img.reshape(-1))
+
+
 @pytest.mark.parametrize("shape", [(12, 4, 1), (20, 8, 3), (100, 64, 1), (52, 40, 3)])
 def test_row_stride_not_multiple_of_16(ctx, oracle, shape):
     """width * channels is not a multiple of 16 but the image size is: the generic (neither FAST nor EDGE) staging variant."""
