@@ -275,6 +275,24 @@ __device__ __forceinline__ void mask_windows(uint32_t leaf_mask, uint32_t (&w)[3
     w[1] &= ff(2, 0) | ff(1, 1) | ff(6, 2) | ff(5, 3);
     w[2] &= ff(3, 0) | ff(7, 2);
 }
+// The same for interleaved RGB: a lane's 8 leaves of one channel sit 3 bytes apart - row 0: bytes 0 and 6 from (x0, y0, ch), rows 1
+// and 2: bytes 0, 3, 6, 9 and 0, 6 from (x0 - 1, y0 + 1 / + 2, ch). Seven 4-byte windows out of ten aligned dwords (six LDS
+// instructions) instead of eight ds_read_u8, which hold the LDS pipe ~12 cycles each (PMC: 200 LDS cycles per pair of items,
+// half of them bank conflicts). w[0], w[1]: row 0 from byte 0 / byte 4; w[2..4]: row 1 from byte 0 / 4 / 8; w[5], w[6]: row 2.
+__device__ __forceinline__ void fetch_windows_rgb(int buf_off, const int (&rb)[3], uint32_t (&w)[7]) {
+    const uint32_t b0 = (uint32_t)(buf_off + rb[0]), b1 = (uint32_t)(buf_off + rb[1] - 3), b2 = (uint32_t)(buf_off + rb[2] - 3);
+    const LdsDwordPtr p0 = (LdsDwordPtr)(uintptr_t)(b0 & ~3u), p1 = (LdsDwordPtr)(uintptr_t)(b1 & ~3u), p2 = (LdsDwordPtr)(uintptr_t)(b2 & ~3u);
+    const uint32_t d00 = p0[0], d01 = p0[1], d02 = p0[2];
+    const uint32_t d10 = p1[0], d11 = p1[1], d12 = p1[2], d13 = p1[3];
+    const uint32_t d20 = p2[0], d21 = p2[1], d22 = p2[2];
+    w[0] = __builtin_amdgcn_alignbyte(d01, d00, b0 & 3u);
+    w[1] = __builtin_amdgcn_alignbyte(d02, d01, b0 & 3u);
+    w[2] = __builtin_amdgcn_alignbyte(d11, d10, b1 & 3u);
+    w[3] = __builtin_amdgcn_alignbyte(d12, d11, b1 & 3u);
+    w[4] = __builtin_amdgcn_alignbyte(d13, d12, b1 & 3u);
+    w[5] = __builtin_amdgcn_alignbyte(d21, d20, b2 & 3u);
+    w[6] = __builtin_amdgcn_alignbyte(d22, d21, b2 & 3u);
+}
 // {byte I of a, byte I of b} zero-extended into the two 16-bit halves.
 template <int I>
 __device__ __forceinline__ u16x2 pair_bytes(uint32_t a, uint32_t b) {
@@ -423,17 +441,26 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
                     leaf[5] = pair_bytes<3>(wA[1], wB[1]);
                     leaf[6] = pair_bytes<2>(wA[1], wB[1]);
                     leaf[7] = pair_bytes<2>(wA[2], wB[2]);
-                } else if ((A.leaf_mask & B.leaf_mask) == 0xFFu) {
+                } else {
+                    // window byte of leaf j: row 0: leaf0 -> w[0] byte 0, leaf4 -> w[1] byte 2; row 1: leaf2 -> w[2] byte 0, leaf1 -> w[2] byte 3,
+                    // leaf6 -> w[3] byte 2, leaf5 -> w[4] byte 1; row 2: leaf3 -> w[5] byte 0, leaf7 -> w[6] byte 2
+                    uint32_t wA[7], wB[7];
+                    fetch_windows_rgb(buf_off, A.rb, wA);
+                    fetch_windows_rgb(buf_off, B.rb, wB);
+                    leaf[0] = pair_bytes<0>(wA[0], wB[0]);
+                    leaf[4] = pair_bytes<2>(wA[1], wB[1]);
+                    leaf[2] = pair_bytes<0>(wA[2], wB[2]);
+                    leaf[1] = pair_bytes<3>(wA[2], wB[2]);
+                    leaf[6] = pair_bytes<2>(wA[3], wB[3]);
+                    leaf[5] = pair_bytes<1>(wA[4], wB[4]);
+                    leaf[3] = pair_bytes<0>(wA[5], wB[5]);
+                    leaf[7] = pair_bytes<2>(wA[6], wB[6]);
+                    if ((A.leaf_mask & B.leaf_mask) != 0xFFu) { // some lane has a leaf outside the image: it enters as 0, the None outputs come from the validity tree
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        leaf[j].x = cur[A.rb[leaf_dy(j)] + leaf_dx(j) * C];
-                        leaf[j].y = cur[B.rb[leaf_dy(j)] + leaf_dx(j) * C];
-                    }
-                } else { // some lane has a leaf outside the image: it enters as 0, the None outputs come from the validity tree
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        leaf[j].x = ((A.leaf_mask >> j) & 1u) ? cur[A.rb[leaf_dy(j)] + leaf_dx(j) * C] : (uint8_t)0;
-                        leaf[j].y = ((B.leaf_mask >> j) & 1u) ? cur[B.rb[leaf_dy(j)] + leaf_dx(j) * C] : (uint8_t)0;
+                        for (int j = 0; j < 8; j++) {
+                            if (!((A.leaf_mask >> j) & 1u)) leaf[j].x = 0;
+                            if (!((B.leaf_mask >> j) & 1u)) leaf[j].y = 0;
+                        }
                     }
                 }
                 fwd_wave_pk(leaf, lane, res[c]);
