@@ -644,11 +644,28 @@ std::string decode_channel(const fri::Geometry &g, const SymbolOrder &order, con
             v[k] = x == kNone ? 0 : x; // .unwrap_or(0)
         }
     };
+    // Symbol of a slot value (:243-256: the last symbol whose cumulative start is <= v): a 4096-entry table per context over the slot's
+    // top bits gives the answer for the first value of the table cell, a short forward walk the rest - instead of a ten-step
+    // binary search with unpredictable branches per symbol.
+    constexpr int kLutBits = 12;
+    std::vector<uint16_t> lut((size_t)kContexts << kLutBits);
+    int lut_shift[kContexts];
+    for (int b = 0; b < kContexts; b++) {
+        const AnsContext &c = s.contexts[b];
+        lut_shift[b] = c.max_freq_bits > (uint32_t)kLutBits ? (int)c.max_freq_bits - kLutBits : 0;
+        int sym = 0;
+        for (uint32_t i = 0; i < (1u << kLutBits); i++) {
+            const uint64_t v0 = (uint64_t)i << lut_shift[b];
+            while (sym + 1 < kAlphabet && c.cdf[sym + 1] <= v0) sym++;
+            lut[((size_t)b << kLutBits) + i] = (uint16_t)sym;
+        }
+    }
     auto decode_one = [&](uint32_t cell, uint32_t heap, int bucket, int32_t prediction) { // decode_symbol, :205-264
         const AnsContext &c = s.contexts[bucket];
         const int state = kContexts - bucket - 1; // :239
         const uint32_t v = dec.get_at(state, c.max_freq_bits);
-        const int sym = (int)(std::upper_bound(c.cdf.begin(), c.cdf.end(), v) - c.cdf.begin()) - 1; // :243-256, see decode_symbols
+        int sym = c.cdf[0] <= v ? (int)lut[((size_t)bucket << kLutBits) + std::min<uint32_t>(v >> lut_shift[bucket], (1u << kLutBits) - 1)] : -1;
+        while (sym >= 0 && sym + 1 < kAlphabet && c.cdf[sym + 1] <= v) sym++;
         if (sym < 0 || c.freqs[sym] == 0) {
             failure = "stream does not match the model";
             return;

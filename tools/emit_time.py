@@ -29,7 +29,11 @@ b = np.stack([p[0] for p in per])
 pr = np.stack([p[1] for p in per])
 hist = np.stack([p[2] for p in per])
 print(f"oracle inputs for {w}x{h}x{c}: {time.perf_counter() - t0:.1f} s, {len(centers)} cells")
-for k in range(5):
+for k in range(2):
     t0 = time.perf_counter()
     frv = emit.encode_image(w, h, centers, co, b, pr, hist, vp, wp)
     print(f"encode_image call {k}: {time.perf_counter() - t0:.3f} s, {len(frv)} bytes")
+for k in range(2):
+    t0 = time.perf_counter()
+    out = emit.decode_image(frv)
+    print(f"decode_image call {k}: {time.perf_counter() - t0:.3f} s")
