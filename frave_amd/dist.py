@@ -22,13 +22,13 @@ def timed_region(fn, dist=None, device_sync=None, device=None):
     """Runs fn() bracketed by barrier + device synchronisation on both sides; returns the MAX elapsed seconds over ranks."""
     import torch
 
-    def fence():
+    def fence():  # this rank's device work is finished, then every rank's is (a barrier on the host; without it one synchronise is all there is to do)
         if device_sync:
             device_sync()
         if dist is not None:
             dist.barrier()
-        if device_sync:
-            device_sync()
+            if device_sync:
+                device_sync()  # the barrier of the nccl backend is itself device work
 
     fence()
     t0 = time.perf_counter()
