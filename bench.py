@@ -195,7 +195,9 @@ def main():
         # K steps = K single-image launches over the rotating slots, issued by the library's native loop (what a C++ / Rust host
         # does through the same ABI; a Python call per step adds ~1 us of host time between launches). The same call brackets
         # the K launches with HIP events on the launch stream: the dominant kernel's mean launch period over the timed region.
+        t_call = time.perf_counter()
         timed["kernel_us"] = plan.time_transform_quant_dev(args.slots, px0, pstride, co0, cstride, args.steps, stream=stream)
+        timed["call_us"] = (time.perf_counter() - t_call) * 1e6
 
     # barrier + device synchronisation on both sides, MAX over ranks (the protocol tests/test_multi_gloo.py exercises on gloo)
     elapsed = timed_region(timed_steps, dist=dist, device_sync=torch.cuda.synchronize, device="cuda")
@@ -232,6 +234,14 @@ def main():
             "kernel": "fwd_transform_quant_kernel<1,false,true,4,true>",
             "kernel_us": round(kernel_us, 3),
             "algorithmic_bytes_per_launch": alg_bytes,
+        },
+        # where the wall clock of the timed region goes (rank 0): the K launches by HIP events, what the native call adds before the first
+        # and after the last of them, and the closing synchronise - a fixed 40-90 us that K = 20 feels and K = 400 does not
+        "timed_region": {
+            "wall_us": round(elapsed * 1e6, 1),
+            "kernels_us": round(kernel_us * args.steps, 1),
+            "call_us": round(timed["call_us"], 1),
+            "after_call_us": round(elapsed * 1e6 - timed["call_us"], 1),
         },
     }
 
