@@ -178,3 +178,59 @@ def test_config3_batched_chain_over_1080p_frames(ctx, oracle):
     torch.cuda.synchronize()
     assert torch.equal(d_back, d_px)
     P.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_batched_entry_points_on_random_small_shapes(ctx, oracle, seed):
+    """The batch launches (planes / images on the second grid dimension, a plane on an eighth of the machine) against the
+    single-plane entry points and the oracle, on shapes from one tile to a few dozen, with padded strides and 1..9 planes."""
+    import torch
+
+    import frave_amd as fa
+
+    rng = np.random.default_rng(seed)
+    s = torch.cuda.current_stream().cuda_stream
+    for case in range(6):
+        w, h = (int(rng.integers(1, 50)), int(rng.integers(1, 700))) if case == 0 else (int(rng.integers(40, 900)), int(rng.integers(40, 600)))
+        n = int(rng.integers(1, 10))
+        P = fa.Plan(ctx, w, h, 1)
+        F, plane = P.num_cells, P.num_cells * 512
+        pad = 512 * int(rng.integers(0, 3))  # strides larger than a plane
+        imgs = [gen_image(["noise", "smooth", "const"][int(rng.integers(0, 3))], w, h, 1, int(rng.integers(0, 1 << 20))) for _ in range(n)]
+        d_px = torch.from_numpy(np.stack([im.reshape(-1) for im in imgs])).cuda()
+        d_co = torch.full((n, plane + pad), 12345, dtype=torch.int32, device="cuda")
+        P.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=s, n_images=n, pixel_stride=P.pixel_bytes, coef_stride=plane + pad)
+        params = np.stack([np.stack(random_params(int(rng.integers(0, 1000)))) for _ in range(n)]).astype(np.float32)  # [n][2][3][6]
+        d_params = torch.from_numpy(params).cuda()
+        d_b = torch.zeros((n, plane + pad), dtype=torch.uint8, device="cuda")
+        d_p = torch.zeros((n, plane + pad), dtype=torch.int32, device="cuda")
+        d_h = torch.empty((n, 10, 1024), dtype=torch.int32, device="cuda")
+        d_o = torch.empty(n, dtype=torch.int64, device="cuda")
+        P.predict_histogram_batch_dev(n, d_co.data_ptr(), plane + pad, d_params.data_ptr(), d_b.data_ptr(), d_p.data_ptr(), plane + pad, d_h.data_ptr(), d_o.data_ptr(), stream=s)
+        d_g = torch.empty((n, 3, 28), dtype=torch.int64, device="cuda")
+        P.fit_value_sums_batch_dev(n, d_co.data_ptr(), plane + pad, d_g.data_ptr(), stream=s)
+        d_w = torch.empty((n, 3, 21), dtype=torch.int64, device="cuda")
+        d_r = torch.empty((n, 3, 6), dtype=torch.float64, device="cuda")
+        P.fit_width_sums_batch_dev(n, d_co.data_ptr(), plane + pad, d_params.data_ptr(), d_w.data_ptr(), d_r.data_ptr(), stream=s)
+        d_back = torch.zeros((n, P.pixel_bytes + 16), dtype=torch.uint8, device="cuda")
+        P.inverse_transform_batch_dev(n, d_co.data_ptr(), plane + pad, d_back.data_ptr(), P.pixel_bytes + 16, stream=s)
+        torch.cuda.synchronize()
+        assert bool((d_co[:, plane:] == 12345).all()) and bool((d_back[:, P.pixel_bytes :] == 0).all())  # nothing written between the planes
+        d_g1 = torch.empty((3, 28), dtype=torch.int64, device="cuda")
+        d_w1 = torch.empty((3, 21), dtype=torch.int64, device="cuda")
+        d_r1 = torch.empty((3, 6), dtype=torch.float64, device="cuda")
+        for k in range(n):
+            W = oracle.Wavelet(imgs[k], h, w, 1)
+            assert np.array_equal(d_co[k, :plane].cpu().numpy().reshape(1, F, 512), W.coefficients()), (w, h, n, k)
+            W.quantize(ONES)
+            wb, wpred, whist, woob = W.predict(0, params[k, 0], params[k, 1])
+            want_back = W.to_raster()  # (images thinner than a cell are not covered by the reference's lattice: compare with ITS way back)
+            W.close()
+            assert np.array_equal(d_b[k, :plane].cpu().numpy().reshape(F, 512), wb) and np.array_equal(d_p[k, :plane].cpu().numpy().reshape(F, 512), wpred), (w, h, n, k)
+            assert np.array_equal(d_h[k].cpu().numpy().astype(np.uint32), whist) and int(d_o[k]) == woob, (w, h, n, k)
+            P.fit_value_sums_dev(d_co[k].data_ptr(), 0, d_g1.data_ptr(), stream=s)
+            P.fit_width_sums_dev(d_co[k].data_ptr(), 0, params[k, 0], d_w1.data_ptr(), d_r1.data_ptr(), stream=s)
+            assert torch.equal(d_g1, d_g[k]) and torch.equal(d_w1, d_w[k]), (w, h, n, k)
+            assert torch.allclose(d_r1, d_r[k], rtol=1e-9, atol=1e-6), (w, h, n, k)
+            assert np.array_equal(d_back[k, : P.pixel_bytes].cpu().numpy(), want_back.reshape(-1)), (w, h, n, k)
+        P.close()
