@@ -1,11 +1,11 @@
 """Host emit (symbol order, ANS models, rANS, container) timed on the CPU alone: the inputs come from the CPU oracle instead of the device
 kernels (same arrays), so this runs without a GPU. First call of a geometry builds and caches the symbol order; the following ones are
-what every further image of that size costs.   python tools/emit_time.py [width height channels]"""
+what every further image of that size costs.   python tests/tools/emit_time.py [width height channels]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 from frave_amd import emit
