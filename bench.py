@@ -87,7 +87,9 @@ def cpu_baseline(seconds_budget=12.0):
     # has touched the GPU (main() calls this first). An oracle instance of a 4096^2 plane holds ~2.5 GB, hence the cap.
     import multiprocessing as mp
 
-    workers = max(1, min(usable, 16))  # a one-GPU box's CPU share is 16 cores, whatever the host shows
+    # A one-GPU box of the pool is a 1/8 share of an 8-GPU host: its CPU share is 16 cores whatever the host shows (256), and more worker
+    # processes than that would run on the other tenants' cores. Memory would allow more (2.5 GB per instance).
+    workers = max(1, min(usable, 16))
     rounds = max(1, min(3, int(seconds_budget / 2 / max(per_image * 1.5, 1e-3))))
 
     def work(k):
@@ -114,8 +116,92 @@ def cpu_baseline(seconds_budget=12.0):
         "host_cores_usable": usable,
         "cpu_model": model,
         "sample": f"oracle/fri_oracle.c (C restatement of libfri, transform+quant of {W}x{H}x{CHANNELS} noise planes): {workers} processes x {rounds} image(s) "
-                  f"in {tn:.1f} s (one single-threaded instance per core, like running libfri per image); 1 thread: {n1} image(s) in {t1:.1f} s",
+                  f"in {tn:.1f} s (one single-threaded instance per core, like running libfri per image; capped at 16 = this one-GPU box's share of the "
+                  f"{host_cores}-core host); 1 thread: {n1} image(s) in {t1:.1f} s",
     }
+
+
+def extras(plan, ctx, torch, np, px0, co0, pstride, cstride, slots, alg_bytes, stream, full=False):
+    """Event-timed figures for the kernels beside K1 and for the chain (see the call site). {us, frac}: microseconds per launch (or per chain /
+    per image) and algorithmic bytes / us / 8 TB/s."""
+    import frave_amd
+
+    F = plan.num_cells
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps=20):
+        fn()
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / reps * 1e3
+
+    def entry(us, nbytes):
+        return {"us": round(us, 2), "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+
+    plane = F * 512
+    k2_bytes = plane * (4 + 1 + 4) + 10 * 1024 * 4  # coefficient read + bucket + prediction write + histogram
+    k4_bytes = plane * 4
+    vp = np.tile(np.array([0.25, 0.25, 0.25, 0.125, 0.0625, 0.0625], np.float32), (3, 1))
+    wp = np.tile(np.array([1.0, 0.5, 0.25, 0.25, 0.125, 0.125], np.float32), (3, 1))
+    d_b = torch.empty(plane, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(plane, dtype=torch.int32, device="cuda")
+    d_h = torch.empty(10 * 1024, dtype=torch.int32, device="cuda")
+    d_o = torch.empty(1, dtype=torch.int64, device="cuda")
+    d_back = torch.empty(plan.pixel_bytes, dtype=torch.uint8, device="cuda")
+    d_g = torch.empty(3 * 28, dtype=torch.int64, device="cuda")
+    d_w = torch.empty(18, dtype=torch.float64, device="cuda")
+    d_par = torch.zeros(36, dtype=torch.float32, device="cuda")
+    res = {"note": "HIP events around 20 back-to-back launches each, one 4096x4096 plane unless said otherwise; frac = algorithmic bytes (SURVEY.md 8d) / us / 8 TB/s"}
+    # K2 alone: the coefficients are K1's, so the plan may skip the exact-int32 guard launch (fri_hip_plan_assume_forward_coefficients)
+    plan.assume_forward_coefficients(True)
+    res["k2_predict_histogram"] = entry(timed(lambda: plan.predict_histogram_dev(co0, 0, vp, wp, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=stream)), k2_bytes)
+    plan.assume_forward_coefficients(False)
+    assert int(d_h.sum()) + int(d_o) == plan.num_some
+    res["k3_inverse"] = entry(timed(lambda: plan.inverse_transform_dev(co0, d_back.data_ptr(), stream=stream)), alg_bytes)
+    res["k4_fit_value_sums"] = entry(timed(lambda: plan.fit_value_sums_dev(co0, 0, d_g.data_ptr(), stream=stream)), k4_bytes)
+    res["k4_fit_width_sums"] = entry(timed(lambda: plan.fit_width_sums_dev(co0, 0, vp, d_g.data_ptr(), d_w.data_ptr(), stream=stream)), k4_bytes)
+    # the device part of FRIEncoder::encode for one image, everything in HBM, nothing but enqueues (fri_hip_encode_image_batch_dev): with the
+    # parameters given (K1 -> K2) and with the fit (K1 -> value sums -> solves -> width sums -> solves -> K2, the solves on the device)
+    d_par.copy_(torch.from_numpy(np.stack([vp, wp]).reshape(-1)))
+    given = timed(lambda: plan.encode_image_batch_dev(1, px0, pstride, d_par.data_ptr(), co0, cstride, d_b.data_ptr(), d_p.data_ptr(), plane, d_h.data_ptr(), d_o.data_ptr(),
+                                                      fit=False, stream=stream))
+    res["chain_k1_k2_given_params"] = entry(given, alg_bytes + k2_bytes)
+    fit = timed(lambda: plan.encode_image_batch_dev(1, px0, pstride, d_par.data_ptr(), co0, cstride, d_b.data_ptr(), d_p.data_ptr(), plane, d_h.data_ptr(), d_o.data_ptr(),
+                                                    fit=True, stream=stream))
+    res["chain_with_fit"] = entry(fit, alg_bytes + k2_bytes + 2 * k4_bytes)
+    # K1 on RGB, the colour space libfri really encodes (wavelet_transform.rs:191, 415-416)
+    plan3 = frave_amd.Plan(ctx, W, H, 3)
+    d_px3 = torch.randint(0, 256, (2, plan3.pixel_bytes), dtype=torch.uint8, device="cuda")
+    d_co3 = torch.empty((2, plan3.coef_count), dtype=torch.int32, device="cuda")
+    it = [0]
+
+    def k1_rgb():
+        k = it[0] & 1
+        it[0] += 1
+        plan3.transform_quant_dev(d_px3[k].data_ptr(), d_co3[k].data_ptr(), stream=stream)
+
+    res["k1_rgb"] = entry(timed(k1_rgb, reps=30), plan3.pixel_bytes + plan3.coef_count * 4)
+    del d_px3, d_co3
+    plan3.close()
+    # K1 with many images per launch (the batch entry point; BASELINE config 4 runs like this). Two figures that must not be confused: a launch
+    # over the bench's own 8 slots re-reads the same 134 MB of pixels every repetition - they stay in the 256 MiB Infinity Cache, so its rate is
+    # cache-assisted - and a launch over 32 DISTINCT images (2.7 GB: every byte comes from and goes to HBM), which is the HBM-bound batch figure.
+    us8 = timed(lambda: plan.transform_quant_dev(px0, co0, stream=stream, n_images=slots, pixel_stride=pstride, coef_stride=cstride)) / slots
+    n32 = 32
+    d_px32 = torch.randint(0, 256, (n32, plan.pixel_bytes), dtype=torch.uint8, device="cuda")
+    d_co32 = torch.empty((n32, plan.coef_count), dtype=torch.int32, device="cuda")
+    us32 = timed(lambda: plan.transform_quant_dev(d_px32.data_ptr(), d_co32.data_ptr(), stream=stream, n_images=n32, pixel_stride=plan.pixel_bytes, coef_stride=plan.coef_count),
+                 reps=6) / n32
+    del d_px32, d_co32
+    res["k1_batch_launch"] = {"per_image_32_distinct_images": entry(us32, alg_bytes), "per_image_8_resident_slots": entry(us8, alg_bytes),
+                              "note": "32 distinct images per launch = HBM-bound; the 8-slot figure re-reads pixels that stay in the Infinity Cache and is NOT an HBM fraction"}
+    if full:
+        res["encode_pcie_bytes_per_image"] = {"host_to_device": plan.pixel_bytes, "device_to_host": plane * (4 + 1 + 4) + 10 * 1024 * 4 + 8}
+    return res
 
 
 def main():
@@ -125,7 +211,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)  # on top of the untimed spin-up, see SPIN_UP_LAUNCHES
     ap.add_argument("--slots", type=int, default=8, help="distinct image/coefficient buffer pairs the steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also time an 8-image batch launch of K1, K2 (predict+histogram) and K3 (inverse)")
+    ap.add_argument("--no-extras", action="store_true", help="leave the event-timed figures of K2 / K3 / K4 / K1-RGB / the chain out of the line")
+    ap.add_argument("--extras", action="store_true", help="(kept for older command lines: the extras are in the default line now; adds the PCIe byte counts)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,83 +326,18 @@ def main():
         # and after the last of them, and the closing synchronise - a fixed 40-90 us that K = 20 feels and K = 400 does not
         "timed_region": {
             "wall_us": round(elapsed * 1e6, 1),
+            "Mpixels_per_s_by_events": round(world * W * H / kernel_us, 1),  # the same steps by their HIP events (rank 0's kernel period): `value` is the wall-clock figure
             "kernels_us": round(kernel_us * args.steps, 1),
             "call_us": round(timed["call_us"], 1),
             "after_call_us": round(elapsed * 1e6 - timed["call_us"], 1),
         },
     }
 
-    # The same kernel with all slots in ONE launch (the batch entry point; BASELINE config 4 runs like this): the ramp and the
-    # tail of consecutive images overlap. Reported next to the single-image figures, never as `value`; only with --extras, so that
-    # the default command launches nothing but single-image kernels (its rocprofv3 kernel stats are then those of `roofline`).
-    if args.extras and rank == 0:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
-        plan.transform_quant_dev(px0, co0, stream=stream, n_images=args.slots, pixel_stride=pstride, coef_stride=cstride)
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(reps):
-            plan.transform_quant_dev(px0, co0, stream=stream, n_images=args.slots, pixel_stride=pstride, coef_stride=cstride)
-        ev1.record()
-        torch.cuda.synchronize()
-        us_img = ev0.elapsed_time(ev1) / reps / args.slots * 1e3
-        out["batch_launch"] = {
-            "images_per_launch": args.slots,
-            "us_per_image": round(us_img, 3),
-            "achieved_GBps": round(alg_bytes / us_img / 1e3, 1),
-            "frac_of_peak": round(alg_bytes / us_img / 1e3 / HBM_PEAK_GBS, 4),
-        }
-
-    if args.extras and rank == 0:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        vp = np.tile(np.array([0.25, 0.25, 0.25, 0.125, 0.0625, 0.0625], np.float32), (3, 1))
-        wp = np.tile(np.array([1.0, 0.5, 0.25, 0.25, 0.125, 0.125], np.float32), (3, 1))
-        d_b = torch.empty(F * 512, dtype=torch.uint8, device="cuda")
-        d_p = torch.empty(F * 512, dtype=torch.int32, device="cuda")
-        d_h = torch.empty(10 * 1024, dtype=torch.int32, device="cuda")
-        d_o = torch.empty(1, dtype=torch.int64, device="cuda")
-        d_back = torch.empty(plan.pixel_bytes, dtype=torch.uint8, device="cuda")
-        reps = 20
-
-        def timed(fn):
-            fn()
-            torch.cuda.synchronize()
-            ev0.record()
-            for _ in range(reps):
-                fn()
-            ev1.record()
-            torch.cuda.synchronize()
-            return ev0.elapsed_time(ev1) / reps * 1e3
-
-        k2_us = timed(lambda: plan.predict_histogram_dev(co0, 0, vp, wp, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=stream))
-        k3_us = timed(lambda: plan.inverse_transform_dev(co0, d_back.data_ptr(), stream=stream))
-        assert torch.equal(d_back, d_px[0]), "K3(K1(x)) != x"
-        d_g = torch.empty(3 * 28, dtype=torch.int64, device="cuda")
-        d_w = torch.empty(18, dtype=torch.float64, device="cuda")
-        k4v_us = timed(lambda: plan.fit_value_sums_dev(co0, 0, d_g.data_ptr(), stream=stream))
-        k4w_us = timed(lambda: plan.fit_width_sums_dev(co0, 0, vp, d_g.data_ptr(), d_w.data_ptr(), stream=stream))
-        # the whole device part of FRIEncoder::encode for one image, coefficients staying in HBM (fri_hip_encode_image_dev): with the
-        # parameters given (K1 -> K2) and with the fit (K1 -> fit sums -> solve -> fit sums -> solve -> K2; two host round trips inside)
-        vp3, wp3 = vp.reshape(1, 3, 6).copy(), wp.reshape(1, 3, 6).copy()
-        enc_given = timed(lambda: plan.encode_image_dev(px0, co0, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), vp3, wp3, fit=False, stream=stream))
-        vpf, wpf = np.zeros((1, 3, 6), np.float32), np.zeros((1, 3, 6), np.float32)
-        enc_fit = timed(lambda: plan.encode_image_dev(px0, co0, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), vpf, wpf, fit=True, stream=stream))
-        k2_bytes = F * 512 * (4 + 1 + 4) + 10 * 1024 * 4  # coefficient read + bucket + prediction write + histogram
-        out["extras"] = {
-            "k2_predict_histogram_us": round(k2_us, 2),
-            "k2_Mpixels_per_s": round(W * H / k2_us, 1),
-            "k2_algorithmic_GBps": round(k2_bytes / k2_us / 1e3, 1),
-            "k2_note": "through fri_hip_predict_histogram_dev, i.e. the fast kernel + the exact int32 kernel that returns at once for the forward kernel's output",
-            "k3_inverse_us": round(k3_us, 2),
-            "k3_Mpixels_per_s": round(W * H / k3_us, 1),
-            "k3_algorithmic_GBps": round(alg_bytes / k3_us / 1e3, 1),
-            "k4_fit_value_sums_us": round(k4v_us, 2),
-            "k4_fit_width_sums_us": round(k4w_us, 2),
-            "encode_device_us": {"parameters_given": round(enc_given, 2), "with_fit": round(enc_fit, 2)},
-            "encode_pcie_bytes_per_image": {"host_to_device": plan.pixel_bytes, "device_to_host": F * 512 * (4 + 1 + 4) + 10 * 1024 * 4 + 8,
-                                            "note": "fri_hip_encode_image: the pixels go up once, coefficients / bucket / prediction / histogram come down once; nothing is uploaded twice"},
-            "note": "per channel plane; K2 = 6-neighbour gather + bucket/prediction + histogram, K3 = dequant + inverse transform, K4 = normal-equation sums of the predictor fit",
-        }
+    # The rest of the path north_star names (K2 = predict + histogram) and of the encode chain, in the same line: every figure is the mean
+    # period of back-to-back launches between two HIP events on the launch stream, with its fraction of the 8 TB/s roofline for the
+    # algorithmic bytes of SURVEY.md section 8d. ~40 ms of GPU time behind the timed region (rank 0 only); never part of `value`.
+    if rank == 0 and not args.no_extras:
+        out["extras"] = extras(plan, ctx, torch, np, px0, co0, pstride, cstride, args.slots, alg_bytes, stream, full=args.extras)
 
     if rank == 0:
         if cpu is not None:

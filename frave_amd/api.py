@@ -25,6 +25,8 @@ SYMBOLS = [
     "fri_hip_multi_plan", "fri_hip_multi_transform_quant", "fri_hip_predict_histogram_batch_dev", "fri_hip_fit_value_sums_batch_dev",
     "fri_hip_fit_width_sums_batch_dev", "fri_hip_solve6", "fri_hip_fit_value_params", "fri_hip_fit_width_params", "fri_hip_encode_image",
     "fri_hip_encode_image_dev", "fri_hip_inverse_transform_batch_dev", "fri_hip_predict_image", "fri_hip_predict_image_dev",
+    "fri_hip_fit_params_batch_dev", "fri_hip_encode_image_batch_dev", "fri_hip_fit_value_params_batch_dev", "fri_hip_fit_width_params_batch_dev",
+    "fri_hip_plan_assume_forward_coefficients", "fri_hip_encode_image_batch", "fri_hip_multi_encode_image",
 ]
 
 
@@ -68,6 +70,18 @@ def load_library():
         except Exception:
             pass
     L = C.CDLL(_SO)
+    if os.environ.get("FRI_HIP_LIBRARY"):
+        # an alternative build selected for an A/B measurement (tools/ab_lib.py) may predate the newest entry points: give those a stub that raises
+        # when called, so that the older build still loads. The in-tree library gets no such leniency (tests/test_abi_symbols.py).
+        def _missing(name):
+            def stub(*a):
+                raise AttributeError(f"{_SO} does not export {name}")
+            return stub
+        for name in SYMBOLS:
+            try:
+                getattr(L, name)
+            except AttributeError:
+                setattr(L, name, _missing(name))
     vp, u32, i32, sz = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t
     L.fri_hip_strerror.restype = C.c_char_p
     L.fri_hip_strerror.argtypes = [i32]
@@ -124,6 +138,13 @@ def load_library():
     L.fri_hip_inverse_transform_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, vp]
     L.fri_hip_predict_image.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.fri_hip_predict_image_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.fri_hip_fit_params_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp, vp]
+    L.fri_hip_plan_assume_forward_coefficients.argtypes = [vp, i32]
+    L.fri_hip_encode_image_batch.argtypes = [vp, u32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.fri_hip_multi_encode_image.argtypes = [vp, u32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.fri_hip_fit_value_params_batch_dev.argtypes = [vp, u32, vp, vp, vp]
+    L.fri_hip_fit_width_params_batch_dev.argtypes = [vp, u32, vp, vp, vp, vp]
+    L.fri_hip_encode_image_batch_dev.argtypes = [vp, u32, vp, sz, vp, i32, vp, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -191,6 +212,25 @@ def fit_width_params(wtw_tri, wtr, rows):
     return out
 
 
+def _encode_batch(fn, handle, where, ctx, images, channels, num_cells, qmatrix, fit, params, want_bucket, want_prediction):
+    """Shared marshalling of fri_hip_encode_image_batch / fri_hip_multi_encode_image: lists of per-image arrays."""
+    imgs = [np.ascontiguousarray(i, np.uint8).reshape(-1) for i in images]
+    n, c, f = len(imgs), channels, num_cells
+    if params is None:
+        par = [np.zeros((c, 2, 3, 6), np.float32) for _ in imgs]
+    else:
+        par = [np.ascontiguousarray(p, np.float32).reshape(c, 2, 3, 6).copy() for p in params]
+    coefs = [np.empty((c, f, 512), np.int32) for _ in imgs]
+    bucket = [np.empty((c, f, 512), np.uint8) for _ in imgs] if want_bucket else None
+    pred = [np.empty((c, f, 512), np.int32) for _ in imgs] if want_prediction else None
+    hist = [np.empty((c, 10, 1024), np.uint32) for _ in imgs]
+    oob = [np.zeros(c, np.uint64) for _ in imgs]
+    arr = lambda xs: (C.c_void_p * n)(*[x.ctypes.data for x in xs]) if xs is not None else None
+    q = _q(qmatrix)
+    _check(fn(handle, n, arr(imgs), _p(q), 1 if fit else 0, arr(par), arr(coefs), arr(bucket), arr(pred), arr(hist), arr(oob)), where, ctx)
+    return coefs, par, bucket, pred, hist, oob
+
+
 class Multi:
     """fri_hip_multi: one process driving several GPUs, one ctx + plan per device, image i on devices[i mod len(devices)]."""
 
@@ -214,6 +254,11 @@ class Multi:
         q = _q(qmatrix)
         _check(load_library().fri_hip_multi_transform_quant(self._h, n, pin, _p(q), pout), "fri_hip_multi_transform_quant")
         return outs
+
+    def encode_image(self, images, qmatrix=None, fit=True, params=None, want_bucket=True, want_prediction=True):
+        """fri_hip_multi_encode_image: per image (coefs, params [C][2][3][6], bucket, prediction, hist, oob), image i on device i mod N."""
+        return _encode_batch(load_library().fri_hip_multi_encode_image, self._h, "fri_hip_multi_encode_image", None, images, self.channels, self.num_cells, qmatrix, fit, params,
+                             want_bucket, want_prediction)
 
     def close(self):
         if self._h:
@@ -281,6 +326,10 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+    def assume_forward_coefficients(self, on=True):
+        """fri_hip_plan_assume_forward_coefficients: the predict entry points then skip the exact-kernel guard launch."""
+        _check(load_library().fri_hip_plan_assume_forward_coefficients(self._h, 1 if on else 0), "fri_hip_plan_assume_forward_coefficients")
 
     # ---- getters -------------------------------------------------------------------------------
     def centers(self):
@@ -350,6 +399,11 @@ class Plan:
         q = _q(qmatrix)
         _check(load_library().fri_hip_transform_quant_batch(self._h, n, pin, _p(q), pout), "fri_hip_transform_quant_batch", self.ctx)
         return outs
+
+    def encode_image_batch(self, images, qmatrix=None, fit=True, params=None, want_bucket=True, want_prediction=True):
+        """fri_hip_encode_image_batch: the per-image encode loop for host buffers on this plan's device (lists per image, as Multi.encode_image)."""
+        return _encode_batch(load_library().fri_hip_encode_image_batch, self._h, "fri_hip_encode_image_batch", self.ctx, images, self.channels, self.num_cells, qmatrix, fit, params,
+                             want_bucket, want_prediction)
 
     def predict_histogram(self, coefs, channel, value_params, width_params, want_bucket=True, want_prediction=True):
         """(bucket, prediction, hist, n_out_of_alphabet); an output that is not wanted is passed as NULL and returned as None."""
@@ -458,6 +512,25 @@ class Plan:
     def fit_width_sums_batch_dev(self, n_planes, d_coefs, coef_stride, d_params, d_wtw, d_wtr, stream=0):
         _check(load_library().fri_hip_fit_width_sums_batch_dev(self._h, n_planes, d_coefs, coef_stride, d_params, d_wtw, d_wtr, stream),
                "fri_hip_fit_width_sums_batch_dev", self.ctx)
+
+    def fit_value_params_batch_dev(self, n_planes, d_gram, d_params, stream=0):
+        _check(load_library().fri_hip_fit_value_params_batch_dev(self._h, n_planes, d_gram, d_params, stream), "fri_hip_fit_value_params_batch_dev", self.ctx)
+
+    def fit_width_params_batch_dev(self, n_planes, d_wtw, d_wtr, d_params, stream=0):
+        _check(load_library().fri_hip_fit_width_params_batch_dev(self._h, n_planes, d_wtw, d_wtr, d_params, stream), "fri_hip_fit_width_params_batch_dev", self.ctx)
+
+    def fit_params_batch_dev(self, n_planes, d_coefs, coef_stride, d_params, d_fit_out_of_range=None, stream=0):
+        """fri_hip_fit_params_batch_dev: the whole fit (sums + 6 x 6 solves) of n_planes planes on the device, parameters into d_params."""
+        _check(load_library().fri_hip_fit_params_batch_dev(self._h, n_planes, d_coefs, coef_stride, d_params, d_fit_out_of_range, stream),
+               "fri_hip_fit_params_batch_dev", self.ctx)
+
+    def encode_image_batch_dev(self, n_images, d_pixels, pixel_stride, d_params, d_coefs, coef_stride, d_bucket, d_prediction, out_stride, d_hist, d_oob,
+                               fit=True, d_fit_out_of_range=None, qmatrix=None, stream=0):
+        """fri_hip_encode_image_batch_dev: K1 -> (fit) -> K2 for n_images images, all in device memory, nothing but enqueues."""
+        q = _q(qmatrix)
+        _check(load_library().fri_hip_encode_image_batch_dev(self._h, n_images, d_pixels, pixel_stride, _p(q), 1 if fit else 0, d_params, d_coefs, coef_stride,
+                                                             d_bucket, d_prediction, out_stride, d_hist, d_oob, d_fit_out_of_range, stream),
+               "fri_hip_encode_image_batch_dev", self.ctx)
 
     def inverse_transform_batch_dev(self, n_images, d_coefs, coef_stride, d_pixels, pixel_stride, qmatrix=None, stream=0):
         q = _q(qmatrix)

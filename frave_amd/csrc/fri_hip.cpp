@@ -17,6 +17,7 @@
 
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "solve6.hpp"
 
 using namespace fri;
 
@@ -38,6 +39,12 @@ struct Slot {
     uint8_t *d_pixels = nullptr;
     int32_t *d_coefs = nullptr;
     int pending = -1; // image index whose result sits in h_coefs once the stream drains
+    // the rest of an image's encode outputs (fri_hip_encode_image_batch), allocated on first use
+    uint8_t *h_bucket = nullptr, *d_bucket = nullptr;
+    int32_t *h_prediction = nullptr, *d_prediction = nullptr;
+    uint32_t *h_hist = nullptr, *d_hist = nullptr;             // [C][10][1024]
+    unsigned long long *h_oob = nullptr, *d_oob = nullptr;     // [C] out of alphabet, then [C] the fit's out-of-range counts
+    float *h_params = nullptr, *d_params = nullptr;            // [C][2][3][6]
 };
 
 } // namespace
@@ -67,19 +74,26 @@ struct fri_hip_plan {
         hipEvent_t handed_over = nullptr;
         uint32_t *pred_acc = nullptr;           // [planes][kPredAccWords], grown on demand, all zero between launches
         unsigned long long *fit_acc = nullptr;  // [planes][kFitAccWords]
+        // scratch of the device-side fit (fit_chain): the sums of a launch's planes on their way to the solve kernels, their out-of-range
+        // counts, and parameter sets for callers that keep theirs on the host. Per stream like the accumulators: chains of several streams
+        // (fri_hip_multi_encode_image's slots) run side by side on one plan.
+        unsigned long long *sums_int = nullptr; // [planes][3][28]
+        double *sums_dbl = nullptr;             // [planes][3][6]
+        unsigned long long *range = nullptr;    // [planes]
+        float *params = nullptr;                // [planes][2][3][6]
         uint32_t planes = 0;
     } acc_slots[kPredAccRing];
     std::vector<void *> retired_acc; // accumulators outgrown by a larger batch: freed with the plan (a launch may still be draining them)
-    // fri_hip_encode_image: all channels' outputs + fit sums on the device, pinned mirrors of the small ones
+    // fri_hip_encode_image (host form): all channels' outputs on the device
     uint8_t *d_bucket_all = nullptr;
     int32_t *d_prediction_all = nullptr;
     uint32_t *d_hist_all = nullptr;           // [C][10][1024]
     unsigned long long *d_oob_all = nullptr;  // [C]
-    unsigned long long *d_sums_int = nullptr; // [C][3][28]
-    double *d_sums_dbl = nullptr;             // [C][3][6]
-    void *d_h_sums = nullptr;                 // the device's address of h_sums: the fit kernels of the encode chain write their sums straight into it
-    uint64_t fit_seq = 0;                     // value of the next hand-over flag (h_sums' last words)
-    void *h_sums = nullptr;                   // pinned: the fit sums on their way to the host's 6 x 6 solves (a pageable target makes each of the two round trips several times longer)
+    // host-facing fit (fri_hip_encode_image_dev / fri_hip_predict_image_dev with fit != 0): the fitted parameters and the range counts come
+    // back through pinned memory behind an event, while the scan kernel that follows them is already queued
+    void *h_fit = nullptr;     // pinned: [3] PredictParams + [3] u64
+    hipEvent_t ev_fit = nullptr;
+    bool assume_forward = false; // fri_hip_plan_assume_forward_coefficients
     uint32_t acc_next = 0;
     bool acc_dirty = false; // a launch on this plan failed: the accumulators are re-zeroed before the next use
     hipEvent_t ev_begin = nullptr, ev_end = nullptr; // timing helper's events, created with the plan (creating an event is not work to be timed)
@@ -160,6 +174,10 @@ int ensure_staging(fri_hip_plan *p) {
 // Accumulators for a K2 / K4 launch over n_planes planes on `stream` (see fri_hip_plan::acc_slots). Returns the slot index, or a negative error code.
 int acquire_acc(fri_hip_plan *p, hipStream_t stream, uint32_t n_planes = 1) {
     fri_hip_ctx *c = p->ctx;
+    // The accumulators are allocated (and, on the rare paths, cleared / waited for) right here, on the launch path of the `_dev` entry
+    // points, which take whatever device the calling thread has current: bind the plan's device first, or a plan of fri_hip_multi's
+    // device d > 0 would get its accumulators on another GPU.
+    HIP_TRY(c, hipSetDevice(c->device));
     if (p->acc_dirty) { // rare: a previous launch failed part-way; nothing may be in flight on the accumulators when they are cleared
         HIP_TRY(c, hipDeviceSynchronize());
         for (auto &a : p->acc_slots) {
@@ -182,28 +200,44 @@ int acquire_acc(fri_hip_plan *p, hipStream_t stream, uint32_t n_planes = 1) {
         idx = (int)p->acc_next;
         p->acc_next = (p->acc_next + 1) % kPredAccRing;
         if (!v.handed_over) HIP_TRY(c, hipEventCreateWithFlags(&v.handed_over, hipEventDisableTiming));
-        HIP_TRY(c, hipEventRecord(v.handed_over, v.stream)); // everything the previous owner has queued so far ...
-        HIP_TRY(c, hipStreamWaitEvent(stream, v.handed_over, 0)); // ... finishes before the new owner's kernel starts
+        // everything the previous owner has queued so far finishes before the new owner's kernel starts. The previous owner is known by
+        // its handle only: the caller may have destroyed that stream since (the record then fails, or lands on a recycled handle). Either
+        // way the slot must come out usable: without a valid event, wait for the whole device once - whatever was queued on a stream
+        // that no longer exists has drained by then.
+        hipError_t e = hipEventRecord(v.handed_over, v.stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, v.handed_over, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(c, hipDeviceSynchronize());
+        }
         v.stream = stream;
     }
     auto &a = p->acc_slots[idx];
     if (a.planes < n_planes) { // grow: the old buffers may still be in use by queued launches, so they are retired, not freed
         const uint32_t planes = n_planes < 4 ? 4 : n_planes;
-        void *pa = nullptr, *fa = nullptr;
+        void *pa = nullptr, *fa = nullptr, *si = nullptr, *sd = nullptr, *rg = nullptr, *pr = nullptr;
         const size_t pb = (size_t)planes * kPredAccWords * sizeof(uint32_t), fb = (size_t)planes * kFitAccWords * sizeof(unsigned long long);
         hipError_t e = hipMalloc(&pa, pb);
         if (e == hipSuccess) e = hipMalloc(&fa, fb);
+        if (e == hipSuccess) e = hipMalloc(&si, (size_t)planes * 3 * 28 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc(&sd, (size_t)planes * 18 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(&rg, (size_t)planes * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc(&pr, (size_t)planes * sizeof(PredictParams));
         if (e == hipSuccess) e = hipMemset(pa, 0, pb);
         if (e == hipSuccess) e = hipMemset(fa, 0, fb);
         if (e != hipSuccess) {
-            if (pa) (void)hipFree(pa);
-            if (fa) (void)hipFree(fa);
+            for (void *d : {pa, fa, si, sd, rg, pr})
+                if (d) (void)hipFree(d);
             return fail_hip(c, e, "accumulator allocation");
         }
-        if (a.pred_acc) p->retired_acc.push_back(a.pred_acc);
-        if (a.fit_acc) p->retired_acc.push_back(a.fit_acc);
+        for (void *d : {(void *)a.pred_acc, (void *)a.fit_acc, (void *)a.sums_int, (void *)a.sums_dbl, (void *)a.range, (void *)a.params})
+            if (d) p->retired_acc.push_back(d);
         a.pred_acc = static_cast<uint32_t *>(pa);
         a.fit_acc = static_cast<unsigned long long *>(fa);
+        a.sums_int = static_cast<unsigned long long *>(si);
+        a.sums_dbl = static_cast<double *>(sd);
+        a.range = static_cast<unsigned long long *>(rg);
+        a.params = static_cast<float *>(pr);
         a.planes = planes;
     }
     return idx;
@@ -214,8 +248,10 @@ void free_slots(fri_hip_plan *p) {
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.h_pixels) (void)hipHostFree(s.h_pixels);
         if (s.h_coefs) (void)hipHostFree(s.h_coefs);
-        if (s.d_pixels) (void)hipFree(s.d_pixels);
-        if (s.d_coefs) (void)hipFree(s.d_coefs);
+        for (void *d : {(void *)s.d_pixels, (void *)s.d_coefs, (void *)s.d_bucket, (void *)s.d_prediction, (void *)s.d_hist, (void *)s.d_oob, (void *)s.d_params})
+            if (d) (void)hipFree(d);
+        for (void *h : {(void *)s.h_bucket, (void *)s.h_prediction, (void *)s.h_hist, (void *)s.h_oob, (void *)s.h_params})
+            if (h) (void)hipHostFree(h);
         s = Slot{};
     }
     p->slots_ready = false;
@@ -240,6 +276,32 @@ int ensure_slots(fri_hip_plan *p) {
         return rc;
     }
     p->slots_ready = true;
+    return FRI_HIP_OK;
+}
+
+// the encode outputs of the batch slots (bucket / prediction only when somebody wants them: 5 bytes per coefficient of pinned memory)
+int ensure_encode_slots(fri_hip_plan *p, bool want_bucket, bool want_prediction) {
+    if (int rc = ensure_slots(p)) return rc;
+    fri_hip_ctx *c = p->ctx;
+    const size_t C = p->geo.channels, n = fri_hip_plan_coef_count(p);
+    for (Slot &s : p->slots) {
+        if (want_bucket && !s.d_bucket) {
+            HIP_TRY(c, hipMalloc((void **)&s.d_bucket, n));
+            HIP_TRY(c, hipHostMalloc((void **)&s.h_bucket, n, hipHostMallocDefault));
+        }
+        if (want_prediction && !s.d_prediction) {
+            HIP_TRY(c, hipMalloc((void **)&s.d_prediction, n * sizeof(int32_t)));
+            HIP_TRY(c, hipHostMalloc((void **)&s.h_prediction, n * sizeof(int32_t), hipHostMallocDefault));
+        }
+        if (!s.d_hist) {
+            HIP_TRY(c, hipMalloc((void **)&s.d_hist, C * 10 * 1024 * sizeof(uint32_t)));
+            HIP_TRY(c, hipHostMalloc((void **)&s.h_hist, C * 10 * 1024 * sizeof(uint32_t), hipHostMallocDefault));
+            HIP_TRY(c, hipMalloc((void **)&s.d_oob, 2 * C * sizeof(unsigned long long)));
+            HIP_TRY(c, hipHostMalloc((void **)&s.h_oob, 2 * C * sizeof(unsigned long long), hipHostMallocDefault));
+            HIP_TRY(c, hipMalloc((void **)&s.d_params, C * sizeof(PredictParams)));
+            HIP_TRY(c, hipHostMalloc((void **)&s.h_params, C * sizeof(PredictParams), hipHostMallocDefault));
+        }
+    }
     return FRI_HIP_OK;
 }
 
@@ -387,10 +449,17 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         std::vector<uint32_t> gather_off((size_t)kCell * 4);
         std::vector<uint16_t> pair_pos(256), heap_of_pos(kCell);
         build_gather_tables(tab.data(), gather_off.data(), pair_pos.data(), heap_of_pos.data());
+        std::vector<uint32_t> halo_list(1024);
+        build_halo_list(tab.data(), pair_pos.data(), halo_list.data());
+        if (halo_list[0] == 0xFFFFFFFFu) { // more halo values than threads: the neighbour table is not the one the kernel was laid out for
+            fri_hip_plan_destroy(p);
+            return FRI_HIP_ERR_INVALID_ARGUMENT;
+        }
         if ((rc = upload(p, g.tiles, d.tiles)) || (rc = upload(p, g.tile_cells, d.tile_cells)) || (rc = upload(p, g.tile_meta, d.tile_meta)) || (rc = upload(p, g.wg_tiles, d.wg_tiles)) || (rc = upload(p, g.wg_tiles_batch, d.wg_tiles_batch)) || (rc = upload(p, g.centers, d.centers)) ||
             (rc = upload(p, g.interior, d.interior)) || (rc = upload(p, g.valid_mask, d.valid_mask)) ||
             (rc = upload(p, g.nbr_cells, d.nbr_cells)) || (rc = upload(p, g.pred_slots, d.pred_slots)) || (rc = upload(p, tab, d.nbr_table)) || (rc = upload(p, pred_off, d.pred_off)) ||
-            (rc = upload(p, gather_off, d.gather_off)) || (rc = upload(p, pair_pos, d.pair_pos)) || (rc = upload(p, heap_of_pos, d.heap_of_pos))) {
+            (rc = upload(p, gather_off, d.gather_off)) || (rc = upload(p, pair_pos, d.pair_pos)) || (rc = upload(p, heap_of_pos, d.heap_of_pos)) ||
+            (rc = upload(p, halo_list, d.halo_list))) {
             fri_hip_plan_destroy(p);
             return rc;
         }
@@ -430,7 +499,6 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         }
         d.k2_previous = env_int("FRI_HIP_K2_PREVIOUS") > 0;
         d.k4_previous = env_int("FRI_HIP_K4_PREVIOUS") > 0;
-        d.fit_no_poll = env_int("FRI_HIP_FIT_NO_POLL") > 0;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
         d.k2_ablate = env_int("FRI_HIP_K2_ABLATE");
@@ -477,13 +545,14 @@ int fri_hip_plan_destroy(fri_hip_plan *p) {
         free_slots(p);
         for (auto &a : p->acc_slots) {
             if (a.handed_over) (void)hipEventDestroy(a.handed_over);
-            if (a.pred_acc) (void)hipFree(a.pred_acc);
-            if (a.fit_acc) (void)hipFree(a.fit_acc);
+            for (void *d : {(void *)a.pred_acc, (void *)a.fit_acc, (void *)a.sums_int, (void *)a.sums_dbl, (void *)a.range, (void *)a.params})
+                if (d) (void)hipFree(d);
         }
         for (void *d : p->retired_acc) (void)hipFree(d);
-        for (void *d : {(void *)p->d_bucket_all, (void *)p->d_prediction_all, (void *)p->d_hist_all, (void *)p->d_oob_all, (void *)p->d_sums_int, (void *)p->d_sums_dbl})
+        for (void *d : {(void *)p->d_bucket_all, (void *)p->d_prediction_all, (void *)p->d_hist_all, (void *)p->d_oob_all})
             if (d) (void)hipFree(d);
-        if (p->h_sums) (void)hipHostFree(p->h_sums);
+        if (p->h_fit) (void)hipHostFree(p->h_fit);
+        if (p->ev_fit) (void)hipEventDestroy(p->ev_fit);
         if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
         if (p->ev_end) (void)hipEventDestroy(p->ev_end);
     }
@@ -497,6 +566,12 @@ uint32_t fri_hip_plan_num_interior_cells(const fri_hip_plan *p) { return p ? p->
 size_t fri_hip_plan_coef_count(const fri_hip_plan *p) { return p ? (size_t)p->geo.channels * p->geo.centers.size() * kCell : 0; }
 size_t fri_hip_plan_pixel_bytes(const fri_hip_plan *p) { return p ? (size_t)p->geo.width * p->geo.height * p->geo.channels : 0; }
 uint64_t fri_hip_plan_num_some(const fri_hip_plan *p) { return p ? p->geo.n_some : 0; }
+
+int fri_hip_plan_assume_forward_coefficients(fri_hip_plan *p, int on) {
+    if (!p) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    p->assume_forward = on != 0;
+    return FRI_HIP_OK;
+}
 
 int fri_hip_plan_centers(const fri_hip_plan *p, int32_t *centers) {
     if (!p || !centers) return FRI_HIP_ERR_INVALID_ARGUMENT;
@@ -679,22 +754,21 @@ int fri_hip_multi_transform_quant(fri_hip_multi *m, uint32_t n_images, const uin
 }
 
 /* ---- prediction + histogram ----------------------------------------------------------------- */
-static int predict_launch(fri_hip_plan *p, const PredBatch &b, uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist, uint64_t *d_oob, bool from_forward_kernel,
+static int predict_launch(fri_hip_plan *p, const PredBatch &b, uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist, uint64_t *d_oob, int trust,
                           hipStream_t stream) {
     const int slot = acquire_acc(p, stream, b.n_planes);
     if (slot < 0) return slot;
-    if (hipError_t e = launch_predict_histogram(p->dev, p->acc_slots[slot].pred_acc, b, d_bucket, d_prediction, d_hist, (unsigned long long *)d_oob, from_forward_kernel, stream)) {
+    if (hipError_t e = launch_predict_histogram(p->dev, p->acc_slots[slot].pred_acc, b, d_bucket, d_prediction, d_hist, (unsigned long long *)d_oob, trust, stream)) {
         p->acc_dirty = true;
         return fail_hip(p->ctx, e, "launch_predict_histogram");
     }
     return FRI_HIP_OK;
 }
 // d_range (may be NULL): per plane, how many waves staged a Some coefficient outside [-256, 255] (include/fri_hip.h: the fit's precondition)
-static int fit_launch(fri_hip_plan *p, int mode, const PredBatch &b, int64_t *d_int, double *d_dbl, unsigned long long *d_range, hipStream_t stream,
-                      unsigned long long *d_done_flag = nullptr, unsigned long long done_value = 0) {
+static int fit_launch(fri_hip_plan *p, int mode, const PredBatch &b, int64_t *d_int, double *d_dbl, unsigned long long *d_range, hipStream_t stream) {
     const int slot = acquire_acc(p, stream, b.n_planes);
     if (slot < 0) return slot;
-    if (hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream, d_done_flag, done_value)) {
+    if (hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream)) {
         p->acc_dirty = true;
         return fail_hip(p->ctx, e, "launch_fit_accumulate");
     }
@@ -713,7 +787,7 @@ int fri_hip_predict_histogram_batch_dev(fri_hip_plan *p, uint32_t n_planes, cons
     b.coef_stride = coef_stride;
     b.out_stride = out_stride;
     b.params = reinterpret_cast<const PredictParams *>(d_params);
-    return predict_launch(p, b, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, false, (hipStream_t)stream);
+    return predict_launch(p, b, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, p->assume_forward ? kPredPromised : kPredAnyInt32, (hipStream_t)stream);
 }
 
 int fri_hip_predict_histogram_dev(fri_hip_plan *p, const int32_t *d_coefs, uint32_t channel, const float value_params[3][6],
@@ -725,7 +799,7 @@ int fri_hip_predict_histogram_dev(fri_hip_plan *p, const int32_t *d_coefs, uint3
     std::memcpy(b.pp[0].value, value_params, sizeof(b.pp[0].value));
     std::memcpy(b.pp[0].width, width_params, sizeof(b.pp[0].width));
     b.coefs = d_coefs + (size_t)channel * p->geo.centers.size() * kCell;
-    return predict_launch(p, b, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, false, (hipStream_t)stream);
+    return predict_launch(p, b, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, p->assume_forward ? kPredPromised : kPredAnyInt32, (hipStream_t)stream);
 }
 
 int fri_hip_predict_histogram(fri_hip_plan *p, const int32_t *coefs, uint32_t channel, const float value_params[3][6],
@@ -835,125 +909,20 @@ int fri_hip_fit_width_sums(fri_hip_plan *p, const int32_t *coefs, uint32_t chann
     return FRI_HIP_OK;
 }
 
-/* ---- the 6 x 6 solves behind the fit -------------------------------------------------------------- */
+/* ---- the 6 x 6 solves behind the fit (solve6.hpp: one source for these host functions and for the device's solve kernel) ------ */
 void fri_hip_solve6(const double m[6][6], const double y[6], double x[6]) {
-    // A system that is positive definite with room to spare (every Cholesky pivot above 1e-8 of the largest diagonal entry - any image with
-    // texture in the layer group) has one solution and no direction for a cut-off to drop: Cholesky, ~150 flops instead of the
-    // eigen-decomposition's ~15 000 (six of these solves per channel sit between the encode chain's kernels).
-    {
-        double l[6][6], dmax = 0.0;
-        for (int i = 0; i < 6; i++) dmax = std::fmax(dmax, m[i][i]);
-        bool ok = dmax > 0.0 && std::isfinite(dmax);
-        for (int j = 0; j < 6 && ok; j++) {
-            double d = m[j][j];
-            for (int k = 0; k < j; k++) d -= l[j][k] * l[j][k];
-            if (!(d > 1e-8 * dmax)) {
-                ok = false;
-                break;
-            }
-            l[j][j] = std::sqrt(d);
-            for (int i = j + 1; i < 6; i++) {
-                double t = m[i][j];
-                for (int k = 0; k < j; k++) t -= l[i][k] * l[j][k];
-                l[i][j] = t / l[j][j];
-            }
-        }
-        if (ok) {
-            double z[6];
-            for (int i = 0; i < 6; i++) { // L z = y
-                double t = y[i];
-                for (int k = 0; k < i; k++) t -= l[i][k] * z[k];
-                z[i] = t / l[i][i];
-            }
-            for (int i = 5; i >= 0; i--) { // L^T x = z
-                double t = z[i];
-                for (int k = i + 1; k < 6; k++) t -= l[k][i] * x[k];
-                x[i] = t / l[i][i];
-            }
-            return;
-        }
-    }
-    // Otherwise (rank-deficient or nearly so: flat regions, a feature that is zero everywhere) the minimum-norm solution, as lstsq's SVD gives it.
-    // cyclic Jacobi: a = V diag(lam) V^T; x = sum over the eigen-directions above the cut-off of v (v . y) / lam
-    double a[6][6], v[6][6];
-    for (int i = 0; i < 6; i++)
-        for (int j = 0; j < 6; j++) {
-            a[i][j] = m[i][j];
-            v[i][j] = i == j ? 1.0 : 0.0;
-        }
-    for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0.0;
-        for (int i = 0; i < 6; i++)
-            for (int j = i + 1; j < 6; j++) off += a[i][j] * a[i][j];
-        if (off < 1e-300) break;
-        for (int pp = 0; pp < 6; pp++)
-            for (int q = pp + 1; q < 6; q++) {
-                if (std::fabs(a[pp][q]) < 1e-300) continue;
-                const double theta = (a[q][q] - a[pp][pp]) / (2.0 * a[pp][q]);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
-                for (int k = 0; k < 6; k++) {
-                    const double akp = a[k][pp], akq = a[k][q];
-                    a[k][pp] = c * akp - sn * akq;
-                    a[k][q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < 6; k++) {
-                    const double apk = a[pp][k], aqk = a[q][k];
-                    a[pp][k] = c * apk - sn * aqk;
-                    a[q][k] = sn * apk + c * aqk;
-                }
-                for (int k = 0; k < 6; k++) {
-                    const double vkp = v[k][pp], vkq = v[k][q];
-                    v[k][pp] = c * vkp - sn * vkq;
-                    v[k][q] = sn * vkp + c * vkq;
-                }
-            }
-    }
-    double lmax = 0.0;
-    for (int i = 0; i < 6; i++) lmax = std::fmax(lmax, a[i][i]);
-    for (int k = 0; k < 6; k++) x[k] = 0.0;
-    for (int i = 0; i < 6; i++) {
-        if (!(a[i][i] > 1e-12 * lmax)) continue; // rank-deficient direction: the minimum-norm solution leaves it at 0
-        double proj = 0.0;
-        for (int k = 0; k < 6; k++) proj += v[k][i] * y[k];
-        for (int k = 0; k < 6; k++) x[k] += v[k][i] * proj / a[i][i];
-    }
-}
-
-static int tri(int i, int j, int n) { // index into the upper triangle (row major)
-    if (i > j) std::swap(i, j);
-    return i * n - i * (i - 1) / 2 + (j - i);
+    solve6(*reinterpret_cast<const double(*)[6][6]>(m), *reinterpret_cast<const double(*)[6]>(y), *reinterpret_cast<double(*)[6]>(x));
 }
 
 void fri_hip_fit_value_params(const int64_t gram[3][28], float value_params[3][6]) {
-    for (int g = 0; g < 3; g++) { // optimize_value_prediction, context_modeling.rs:175-202
-        double m[6][6], y[6], x[6];
-        for (int i = 0; i < 6; i++) {
-            y[i] = (double)gram[g][tri(i, 6, 7)];
-            for (int j = 0; j < 6; j++) m[i][j] = (double)gram[g][tri(i, j, 7)];
-        }
-        fri_hip_solve6(m, y, x);
-        for (int k = 0; k < 6; k++) value_params[g][k] = (float)x[k];
-    }
+    for (int g = 0; g < 3; g++) fit_value_group(reinterpret_cast<const long long *>(gram[g]), value_params[g]); // optimize_value_prediction, context_modeling.rs:175-202
 }
 
 void fri_hip_fit_width_params(const int64_t wtw[3][21], const double wtr[3][6], const uint64_t rows[3], float width_params[3][6]) {
-    for (int g = 0; g < 3; g++) { // optimize_width_prediction, context_modeling.rs:144-173
-        double m[6][6], y[6], x[6];
-        for (int i = 0; i < 6; i++) {
-            y[i] = wtr[g][i];
-            for (int j = 0; j < 6; j++) m[i][j] = (double)wtw[g][tri(i, j, 6)];
-        }
-        m[0][0] += (double)rows[g] - (double)wtw[g][0]; // the reference's all-zero rows: constant feature 1, residual 0
-        fri_hip_solve6(m, y, x);
-        for (int k = 0; k < 6; k++) width_params[g][k] = (float)x[k];
-    }
+    for (int g = 0; g < 3; g++) fit_width_group(reinterpret_cast<const long long *>(wtw[g]), wtr[g], rows[g], width_params[g]); // optimize_width_prediction, :144-173
 }
 
 /* ---- the device part of FRIEncoder::encode in one call ------------------------------------------------ */
-// h_sums (pinned, device-visible): [3][3][28] int64 sums | [3][3][6] f64 sums | [3] out-of-range counts | [3] hand-over flags
-constexpr size_t kHostSumsInt = 0, kHostSumsDbl = 3 * 3 * 28 * sizeof(int64_t), kHostSumsRange = kHostSumsDbl + 3 * 18 * sizeof(double),
-                 kHostSumsFlag = kHostSumsRange + 3 * sizeof(unsigned long long), kHostSumsBytes = kHostSumsFlag + 3 * sizeof(unsigned long long);
 static int ensure_encode_staging(fri_hip_plan *p) {
     fri_hip_ctx *c = p->ctx;
     const size_t C = p->geo.channels, plane = p->geo.centers.size() * kCell;
@@ -961,97 +930,76 @@ static int ensure_encode_staging(fri_hip_plan *p) {
     if (!p->d_prediction_all) HIP_TRY(c, hipMalloc((void **)&p->d_prediction_all, C * plane * sizeof(int32_t)));
     if (!p->d_hist_all) HIP_TRY(c, hipMalloc((void **)&p->d_hist_all, C * 10 * 1024 * sizeof(uint32_t)));
     if (!p->d_oob_all) HIP_TRY(c, hipMalloc((void **)&p->d_oob_all, C * sizeof(unsigned long long)));
-    if (!p->d_sums_int) HIP_TRY(c, hipMalloc((void **)&p->d_sums_int, C * 3 * 28 * sizeof(unsigned long long)));
-    if (!p->d_sums_dbl) HIP_TRY(c, hipMalloc((void **)&p->d_sums_dbl, C * 18 * sizeof(double)));
-    if (!p->h_sums) {
-        HIP_TRY(c, hipHostMalloc(&p->h_sums, kHostSumsBytes, hipHostMallocMapped));
-        std::memset(p->h_sums, 0, kHostSumsBytes);
-        HIP_TRY(c, hipHostGetDevicePointer(&p->d_h_sums, p->h_sums, 0));
-    }
     return FRI_HIP_OK;
 }
 
-// prediction::encode for all channels of one image whose coefficients are in device memory (prediction.rs:224-323 minus the host's
-// ANS model): optional fit (sums on the device, solves on the host: two stream synchronisations), then K2 for every channel in one launch.
+// ContextModeler::optimize_parameters for the planes of `b` (prediction.rs:232-235, context_modeling.rs:204-213), entirely on the device and
+// without a word to the host: value sums -> 6 x 6 solves -> width sums (with the value parameters just written) -> solves. The parameters land
+// in the device array b.params (PredictParams per plane), where the scan kernel reads them. d_range (may be NULL) receives, per plane, the
+// number of waves that staged a Some coefficient outside [-256, 255] (the sums are then not to be trusted).
+static int fit_chain(fri_hip_plan *p, const PredBatch &b, unsigned long long *d_range, hipStream_t s) {
+    if (!b.params) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    const int slot = acquire_acc(p, s, b.n_planes); // the stream's accumulators and fit scratch (the launches below find the same slot)
+    if (slot < 0) return slot;
+    auto &k = p->acc_slots[slot];
+    float *params = const_cast<float *>(reinterpret_cast<const float *>(b.params));
+    const uint64_t F = p->geo.centers.size();
+    const unsigned long long rows[3] = {F * 256, F * 128, F * 128}; // num_ctx_last_layer / num_ctx_middle_layer, context_modeling.rs:84-85
+    if (int rc = fit_launch(p, 0, b, (int64_t *)k.sums_int, nullptr, d_range ? d_range : k.range, s)) return rc;
+    HIP_TRY(p->ctx, launch_fit_solve(0, b.n_planes, k.sums_int, nullptr, nullptr, params, s));
+    if (int rc = fit_launch(p, 1, b, (int64_t *)k.sums_int, k.sums_dbl, nullptr, s)) return rc;
+    HIP_TRY(p->ctx, launch_fit_solve(1, b.n_planes, k.sums_int, k.sums_dbl, rows, params, s));
+    return FRI_HIP_OK;
+}
+
+// prediction::encode for all channels of one image whose coefficients are in device memory (prediction.rs:224-323 minus the host's ANS
+// model), parameters on the HOST side of the ABI: given (fit == 0: they travel as kernel arguments) or fitted and returned (fit != 0: the
+// device-side fit above, then the parameters and the range counts come back through pinned memory behind an event the host waits for
+// while the scan kernel, already queued behind them, runs).
 static int predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, float *value_params, float *width_params, uint8_t *d_bucket, int32_t *d_prediction,
-                             uint32_t *d_hist, uint64_t *d_oob, bool from_forward_kernel, hipStream_t s) {
+                             uint32_t *d_hist, uint64_t *d_oob, int trust, hipStream_t s) {
     fri_hip_ctx *c = p->ctx;
-    if (int rc = ensure_encode_staging(p)) return rc;
     const uint32_t C = p->geo.channels;
-    const size_t F = p->geo.centers.size(), plane = F * kCell;
+    const size_t plane = p->geo.centers.size() * kCell;
     PredBatch b;
     b.n_planes = C;
     b.coefs = d_coefs;
     b.coef_stride = plane;
     b.out_stride = plane;
-    if (fit) { // ContextModeler::optimize_parameters per channel (prediction.rs:232-235, context_modeling.rs:204-213)
-        char *const hs = static_cast<char *>(p->h_sums), *const ds = static_cast<char *>(p->d_h_sums);
-        int64_t(*sums)[3][28] = reinterpret_cast<int64_t(*)[3][28]>(hs + kHostSumsInt);
-        int64_t(*wtw)[3][21] = reinterpret_cast<int64_t(*)[3][21]>(hs + kHostSumsInt);
-        double(*wtr)[3][6] = reinterpret_cast<double(*)[3][6]>(hs + kHostSumsDbl);
-        unsigned long long *h_range = reinterpret_cast<unsigned long long *>(hs + kHostSumsRange);
-        volatile unsigned long long *h_flag = reinterpret_cast<volatile unsigned long long *>(hs + kHostSumsFlag);
-        // Two round trips to the host's 6 x 6 solves. The fit kernel's last workgroup writes the sums straight into pinned host memory
-        // and raises a flag behind them (system-scope release); the host polls the flag - no copy command, no stream synchronisation
-        // (those cost ~60 us per round trip, more than the kernel in front of them). The tuning build's first fit kernel has no such
-        // hand-over: copy + synchronise there.
-        const bool poll = !p->dev.k4_previous && !p->dev.fit_no_poll;
-        auto wait_for = [&](unsigned long long seq) -> int {
-            if (poll) {
-                for (uint64_t spins = 0; spins < (1ull << 26); spins++) {
-                    bool all = true;
-                    for (uint32_t ch = 0; ch < C; ch++) all = all && h_flag[ch] == seq;
-                    if (all) {
-                        std::atomic_thread_fence(std::memory_order_acquire);
-                        return FRI_HIP_OK;
-                    }
-                    if ((spins & 0xFFF) == 0xFFF && hipStreamQuery(s) != hipErrorNotReady) break; // the stream ran dry (or failed) without raising the flags
-                }
-                HIP_TRY(c, hipStreamSynchronize(s)); // reports the launch's error if there was one
-                for (uint32_t ch = 0; ch < C; ch++)
-                    if (h_flag[ch] != seq) return fail_hip(c, hipErrorUnknown, "fit hand-over flag not raised");
-                return FRI_HIP_OK;
-            }
-            HIP_TRY(c, hipStreamSynchronize(s));
-            return FRI_HIP_OK;
-        };
-        unsigned long long seq = ++p->fit_seq;
-        if (poll) {
-            if (int rc = fit_launch(p, 0, b, reinterpret_cast<int64_t *>(ds + kHostSumsInt), nullptr, reinterpret_cast<unsigned long long *>(ds + kHostSumsRange), s,
-                                    reinterpret_cast<unsigned long long *>(ds + kHostSumsFlag), seq))
-                return rc;
-        } else {
-            if (int rc = fit_launch(p, 0, b, (int64_t *)p->d_sums_int, nullptr, p->d_oob_all, s)) return rc;
-            HIP_TRY(c, hipMemcpyAsync(sums, p->d_sums_int, (size_t)C * 3 * 28 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipMemcpyAsync(h_range, p->d_oob_all, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        }
-        if (int rc = wait_for(seq)) return rc;
-        for (uint32_t ch = 0; ch < C; ch++)
-            if (h_range[ch]) return FRI_HIP_ERR_OUT_OF_RANGE; // a Some coefficient outside [-256, 255]: the fit's 32-bit partial sums would overflow
+    if (!fit) {
         for (uint32_t ch = 0; ch < C; ch++) {
-            fri_hip_fit_value_params(sums[ch], reinterpret_cast<float(*)[6]>(value_params + ch * 18));
             std::memcpy(b.pp[ch].value, value_params + ch * 18, sizeof(b.pp[ch].value));
+            std::memcpy(b.pp[ch].width, width_params + ch * 18, sizeof(b.pp[ch].width));
         }
-        seq = ++p->fit_seq;
-        if (poll) {
-            if (int rc = fit_launch(p, 1, b, reinterpret_cast<int64_t *>(ds + kHostSumsInt), reinterpret_cast<double *>(ds + kHostSumsDbl), nullptr, s,
-                                    reinterpret_cast<unsigned long long *>(ds + kHostSumsFlag), seq))
-                return rc;
-        } else {
-            if (int rc = fit_launch(p, 1, b, (int64_t *)p->d_sums_int, p->d_sums_dbl, nullptr, s)) return rc;
-            HIP_TRY(c, hipMemcpyAsync(wtw, p->d_sums_int, (size_t)C * 3 * 21 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipMemcpyAsync(wtr, p->d_sums_dbl, (size_t)C * 18 * sizeof(double), hipMemcpyDeviceToHost, s));
-        }
-        if (int rc = wait_for(seq)) return rc;
-        const uint64_t rows[3] = {F * 256, F * 128, F * 128}; // num_ctx_last_layer / num_ctx_middle_layer, context_modeling.rs:84-85
-        for (uint32_t ch = 0; ch < C; ch++) fri_hip_fit_width_params(wtw[ch], wtr[ch], rows, reinterpret_cast<float(*)[6]>(width_params + ch * 18));
+        return predict_launch(p, b, d_bucket, d_prediction, d_hist, d_oob, trust, s); // the scan loop of prediction::encode (prediction.rs:237-298), every channel
     }
+    const int slot = acquire_acc(p, s, C);
+    if (slot < 0) return slot;
+    auto &k = p->acc_slots[slot];
+    constexpr size_t kFitBytes = 3 * sizeof(PredictParams) + 3 * sizeof(unsigned long long);
+    if (!p->h_fit) {
+        HIP_TRY(c, hipHostMalloc(&p->h_fit, kFitBytes, hipHostMallocDefault));
+        std::memset(p->h_fit, 0, kFitBytes);
+    }
+    if (!p->ev_fit) HIP_TRY(c, hipEventCreateWithFlags(&p->ev_fit, hipEventDisableTiming));
+    b.params = reinterpret_cast<const PredictParams *>(k.params);
+    if (int rc = fit_chain(p, b, k.range, s)) return rc;
+    char *const h = static_cast<char *>(p->h_fit);
+    HIP_TRY(c, hipMemcpyAsync(h, k.params, (size_t)C * sizeof(PredictParams), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(h + 3 * sizeof(PredictParams), k.range, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(p->ev_fit, s));
+    // the scan is queued before the host looks at the fit: it runs while the parameters travel
+    const int rc_scan = predict_launch(p, b, d_bucket, d_prediction, d_hist, d_oob, trust, s);
+    HIP_TRY(c, hipEventSynchronize(p->ev_fit));
+    const unsigned long long *h_range = reinterpret_cast<const unsigned long long *>(h + 3 * sizeof(PredictParams));
+    const PredictParams *h_params = reinterpret_cast<const PredictParams *>(h);
     for (uint32_t ch = 0; ch < C; ch++) {
-        std::memcpy(b.pp[ch].value, value_params + ch * 18, sizeof(b.pp[ch].value));
-        std::memcpy(b.pp[ch].width, width_params + ch * 18, sizeof(b.pp[ch].width));
+        std::memcpy(value_params + ch * 18, h_params[ch].value, sizeof(h_params[ch].value));
+        std::memcpy(width_params + ch * 18, h_params[ch].width, sizeof(h_params[ch].width));
     }
-    // the scan loop of prediction::encode (prediction.rs:237-298) for every channel
-    return predict_launch(p, b, d_bucket, d_prediction, d_hist, d_oob, from_forward_kernel, s);
+    for (uint32_t ch = 0; ch < C; ch++)
+        if (h_range[ch]) return FRI_HIP_ERR_OUT_OF_RANGE; // a Some coefficient outside [-256, 255]: the fit's 32-bit partial sums would overflow
+    return rc_scan;
 }
 
 int fri_hip_encode_image_dev(fri_hip_plan *p, const uint8_t *d_pixels, const int32_t qmatrix[32], int fit, float *value_params, float *width_params, int32_t *d_coefs,
@@ -1063,8 +1011,66 @@ int fri_hip_encode_image_dev(fri_hip_plan *p, const uint8_t *d_pixels, const int
     HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
     // wavelet_transform::encode + quantization::encode (encoder.rs:24-31): one kernel, all channels; the coefficients then stay where they are
     HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, 1, d_pixels, 0, d_coefs, 0, q, (hipStream_t)stream));
-    bool small = true; // |coefficient| <= 255 for quantisers of magnitude >= 1: the exact kernel behind K2 cannot be needed
-    return predict_image_dev(p, d_coefs, fit, value_params, width_params, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, small, (hipStream_t)stream);
+    // |coefficient| <= 255 for quantisers of magnitude >= 1, and the kernel above wrote every one of them: the scan need not look
+    return predict_image_dev(p, d_coefs, fit, value_params, width_params, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, kPredForwardOutput, (hipStream_t)stream);
+}
+
+// n_images images in one asynchronous chain, parameters in DEVICE memory (no host round trip, no synchronisation):
+// K1 (all images, all channels) -> [value sums -> solves -> width sums -> solves] -> K2 (all planes).
+int fri_hip_encode_image_batch_dev(fri_hip_plan *p, uint32_t n_images, const uint8_t *d_pixels, size_t pixel_stride, const int32_t qmatrix[32], int fit, float *d_params,
+                                   int32_t *d_coefs, size_t coef_stride, uint8_t *d_bucket, int32_t *d_prediction, size_t out_stride, uint32_t *d_hist,
+                                   uint64_t *d_n_out_of_alphabet, uint64_t *d_fit_out_of_range, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    const uint32_t C = p->geo.channels;
+    const size_t plane = p->geo.centers.size() * kCell, image = (size_t)C * plane;
+    if (!d_pixels || !d_params || !d_coefs || !d_hist || !d_n_out_of_alphabet || !n_images || (uint64_t)n_images * C > 65535u) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    if (n_images > 1 && (pixel_stride < fri_hip_plan_pixel_bytes(p) || coef_stride < image || ((d_bucket || d_prediction) && out_stride < image))) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    // the planes of the batch must be evenly spaced for the one-launch-per-stage form: C == 1 (any stride) or images back to back
+    if (C > 1 && n_images > 1 && (coef_stride != image || ((d_bucket || d_prediction) && out_stride != image))) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    QMatrix q;
+    if (int rc = check_q(qmatrix, q)) return rc;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, q, s));
+    PredBatch b;
+    b.n_planes = n_images * C;
+    b.coefs = d_coefs;
+    b.coef_stride = C > 1 ? plane : coef_stride;
+    b.out_stride = C > 1 ? plane : out_stride;
+    b.params = reinterpret_cast<const PredictParams *>(d_params);
+    if (fit)
+        if (int rc = fit_chain(p, b, (unsigned long long *)d_fit_out_of_range, s)) return rc;
+    return predict_launch(p, b, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, kPredForwardOutput, s);
+}
+
+int fri_hip_fit_value_params_batch_dev(fri_hip_plan *p, uint32_t n_planes, const int64_t *d_gram, float *d_params, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_gram || !d_params || !n_planes || n_planes > 65535u) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    HIP_TRY(p->ctx, launch_fit_solve(0, n_planes, reinterpret_cast<const unsigned long long *>(d_gram), nullptr, nullptr, d_params, (hipStream_t)stream));
+    return FRI_HIP_OK;
+}
+
+int fri_hip_fit_width_params_batch_dev(fri_hip_plan *p, uint32_t n_planes, const int64_t *d_wtw, const double *d_wtr, float *d_params, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_wtw || !d_wtr || !d_params || !n_planes || n_planes > 65535u) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    const uint64_t F = p->geo.centers.size();
+    const unsigned long long rows[3] = {F * 256, F * 128, F * 128}; // num_ctx_last_layer / num_ctx_middle_layer, context_modeling.rs:84-85
+    HIP_TRY(p->ctx, launch_fit_solve(1, n_planes, reinterpret_cast<const unsigned long long *>(d_wtw), d_wtr, rows, d_params, (hipStream_t)stream));
+    return FRI_HIP_OK;
+}
+
+int fri_hip_fit_params_batch_dev(fri_hip_plan *p, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, float *d_params, uint64_t *d_fit_out_of_range, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_coefs || !d_params || !n_planes || n_planes > 65535u || (n_planes > 1 && coef_stride < p->geo.centers.size() * kCell)) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    PredBatch b;
+    b.n_planes = n_planes;
+    b.coefs = d_coefs;
+    b.coef_stride = coef_stride;
+    b.params = reinterpret_cast<const PredictParams *>(d_params);
+    return fit_chain(p, b, (unsigned long long *)d_fit_out_of_range, (hipStream_t)stream);
 }
 
 int fri_hip_predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, float *value_params, float *width_params, uint8_t *d_bucket, int32_t *d_prediction,
@@ -1072,7 +1078,7 @@ int fri_hip_predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, 
     if (int rc = need_device(p)) return rc;
     if (!d_coefs || !value_params || !width_params || !d_hist || !d_n_out_of_alphabet) return FRI_HIP_ERR_INVALID_ARGUMENT;
     HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
-    return predict_image_dev(p, d_coefs, fit, value_params, width_params, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, false, (hipStream_t)stream);
+    return predict_image_dev(p, d_coefs, fit, value_params, width_params, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, kPredAnyInt32, (hipStream_t)stream);
 }
 
 int fri_hip_predict_image(fri_hip_plan *p, const int32_t *coefs, int fit, float *value_params, float *width_params, uint8_t *bucket, int32_t *prediction, uint32_t *hist,
@@ -1086,7 +1092,7 @@ int fri_hip_predict_image(fri_hip_plan *p, const int32_t *coefs, int fit, float 
     const size_t C = p->geo.channels, plane = p->geo.centers.size() * kCell;
     HIP_TRY(c, hipMemcpy(p->d_coefs, coefs, C * plane * sizeof(int32_t), hipMemcpyHostToDevice)); // once, for the fit and the scan of every channel
     if (int rc = predict_image_dev(p, p->d_coefs, fit, value_params, width_params, bucket ? p->d_bucket_all : nullptr, prediction ? p->d_prediction_all : nullptr, p->d_hist_all,
-                                   (uint64_t *)p->d_oob_all, false, nullptr))
+                                   (uint64_t *)p->d_oob_all, kPredAnyInt32, nullptr))
         return rc;
     if (bucket) HIP_TRY(c, hipMemcpy(bucket, p->d_bucket_all, C * plane, hipMemcpyDeviceToHost));
     if (prediction) HIP_TRY(c, hipMemcpy(prediction, p->d_prediction_all, C * plane * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1114,6 +1120,96 @@ int fri_hip_encode_image(fri_hip_plan *p, const uint8_t *pixels, const int32_t q
     if (prediction) HIP_TRY(c, hipMemcpy(prediction, p->d_prediction_all, C * plane * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(hist, p->d_hist_all, C * 10 * 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(n_out_of_alphabet, p->d_oob_all, C * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (size_t ch = 0; ch < C; ch++) // the scan met a coefficient its LDS image cannot hold although the forward kernel wrote them (unreachable for |q| >= 1; see the header)
+        if (n_out_of_alphabet[ch] == ~0ull) return FRI_HIP_ERR_OUT_OF_RANGE;
+    return FRI_HIP_OK;
+}
+
+// The reference's per-image loop (crates/fri-cli/src/commands/bench.rs:15-120 around FRIEncoder::encode, encoder.rs:87-109) for host buffers on ONE
+// device: each image runs the whole asynchronous chain (fri_hip_encode_image_batch_dev with one image) on one of three streams, so that image
+// i + 1's upload and image i - 1's download overlap image i's kernels.
+int fri_hip_encode_image_batch(fri_hip_plan *p, uint32_t n_images, const uint8_t *const *pixels, const int32_t qmatrix[32], int fit, float *const *params,
+                               int32_t *const *coefs, uint8_t *const *bucket, int32_t *const *prediction, uint32_t *const *hist, uint64_t *const *n_out_of_alphabet) {
+    if (int rc = need_device(p)) return rc;
+    if (!pixels || !params || !coefs || !hist || !n_out_of_alphabet) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    QMatrix q;
+    if (int rc = check_q(qmatrix, q)) return rc;
+    fri_hip_ctx *c = p->ctx;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = ensure_encode_slots(p, bucket != nullptr, prediction != nullptr)) return rc;
+    const size_t C = p->geo.channels, pb = fri_hip_plan_pixel_bytes(p), n = fri_hip_plan_coef_count(p);
+    int first_error = FRI_HIP_OK;
+    auto drain = [&](Slot &s) -> int {
+        if (s.pending < 0) return FRI_HIP_OK;
+        const int i = s.pending;
+        s.pending = -1;
+        HIP_TRY(c, hipStreamSynchronize(s.stream));
+        std::memcpy(coefs[i], s.h_coefs, n * sizeof(int32_t));
+        if (bucket && bucket[i]) std::memcpy(bucket[i], s.h_bucket, n);
+        if (prediction && prediction[i]) std::memcpy(prediction[i], s.h_prediction, n * sizeof(int32_t));
+        std::memcpy(hist[i], s.h_hist, C * 10 * 1024 * sizeof(uint32_t));
+        std::memcpy(n_out_of_alphabet[i], s.h_oob, C * sizeof(uint64_t));
+        if (fit) std::memcpy(params[i], s.h_params, C * sizeof(PredictParams));
+        for (size_t ch = 0; ch < C; ch++)
+            if ((fit && s.h_oob[C + ch]) || s.h_oob[ch] == ~0ull) first_error = first_error ? first_error : FRI_HIP_ERR_OUT_OF_RANGE;
+        return FRI_HIP_OK;
+    };
+    for (Slot &s : p->slots) s.pending = -1;
+    for (uint32_t i = 0; i < n_images; i++) {
+        if (!pixels[i] || !params[i] || !coefs[i] || !hist[i] || !n_out_of_alphabet[i]) return FRI_HIP_ERR_INVALID_ARGUMENT;
+        Slot &s = p->slots[i % kBatchSlots];
+        if (int rc = drain(s)) return rc; // the other slots' copies and kernels keep running meanwhile
+        std::memcpy(s.h_pixels, pixels[i], pb);
+        HIP_TRY(c, hipMemcpyAsync(s.d_pixels, s.h_pixels, pb, hipMemcpyHostToDevice, s.stream));
+        if (!fit) {
+            std::memcpy(s.h_params, params[i], C * sizeof(PredictParams));
+            HIP_TRY(c, hipMemcpyAsync(s.d_params, s.h_params, C * sizeof(PredictParams), hipMemcpyHostToDevice, s.stream));
+        }
+        if (int rc = fri_hip_encode_image_batch_dev(p, 1, s.d_pixels, 0, qmatrix, fit, s.d_params, s.d_coefs, 0, bucket && bucket[i] ? s.d_bucket : nullptr,
+                                                    prediction && prediction[i] ? s.d_prediction : nullptr, 0, s.d_hist, (uint64_t *)s.d_oob, (uint64_t *)(s.d_oob + C), s.stream))
+            return rc;
+        HIP_TRY(c, hipMemcpyAsync(s.h_coefs, s.d_coefs, n * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+        if (bucket && bucket[i]) HIP_TRY(c, hipMemcpyAsync(s.h_bucket, s.d_bucket, n, hipMemcpyDeviceToHost, s.stream));
+        if (prediction && prediction[i]) HIP_TRY(c, hipMemcpyAsync(s.h_prediction, s.d_prediction, n * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(c, hipMemcpyAsync(s.h_hist, s.d_hist, C * 10 * 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(c, hipMemcpyAsync(s.h_oob, s.d_oob, 2 * C * sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream));
+        if (fit) HIP_TRY(c, hipMemcpyAsync(s.h_params, s.d_params, C * sizeof(PredictParams), hipMemcpyDeviceToHost, s.stream));
+        s.pending = (int)i;
+    }
+    for (Slot &s : p->slots)
+        if (int rc = drain(s)) return rc;
+    return first_error;
+}
+
+// ... and over the GPUs of a node: image i on devices[i mod n_devices], one host thread per device running the loop above over its shard.
+int fri_hip_multi_encode_image(fri_hip_multi *m, uint32_t n_images, const uint8_t *const *pixels, const int32_t qmatrix[32], int fit, float *const *params,
+                               int32_t *const *coefs, uint8_t *const *bucket, int32_t *const *prediction, uint32_t *const *hist, uint64_t *const *n_out_of_alphabet) {
+    if (!m || !pixels || !params || !coefs || !hist || !n_out_of_alphabet || !qmatrix) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    const uint32_t n_devices = (uint32_t)m->plans.size();
+    std::vector<int> rcs(n_devices, FRI_HIP_OK);
+    auto work = [&](uint32_t d) {
+        const uint32_t n = fri_hip_shard_size(n_images, d, n_devices);
+        if (!n) return;
+        std::vector<const uint8_t *> in(n);
+        std::vector<float *> par(n);
+        std::vector<int32_t *> co(n), pr(n);
+        std::vector<uint8_t *> bu(n);
+        std::vector<uint32_t *> hi(n);
+        std::vector<uint64_t *> oo(n);
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t i = fri_hip_shard_image(k, d, n_devices);
+            in[k] = pixels[i], par[k] = params[i], co[k] = coefs[i], hi[k] = hist[i], oo[k] = n_out_of_alphabet[i];
+            bu[k] = bucket ? bucket[i] : nullptr, pr[k] = prediction ? prediction[i] : nullptr;
+        }
+        rcs[d] = fri_hip_encode_image_batch(m->plans[d], n, in.data(), qmatrix, fit, par.data(), co.data(), bucket ? bu.data() : nullptr, prediction ? pr.data() : nullptr, hi.data(),
+                                            oo.data());
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t d = 1; d < n_devices; d++) threads.emplace_back(work, d);
+    work(0); // the calling thread drives the first device
+    for (auto &t : threads) t.join();
+    for (int rc : rcs)
+        if (rc != FRI_HIP_OK) return rc;
     return FRI_HIP_OK;
 }
 

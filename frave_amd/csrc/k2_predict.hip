@@ -2,6 +2,9 @@
 // channel plane (context_modeling.rs:25-77; stages/prediction.rs:86-207, 237-298).
 #include "gather_common.hpp"
 
+#include <algorithm>
+#include <vector>
+
 namespace fri {
 namespace {
 
@@ -46,6 +49,7 @@ struct PredArgs {
                                // (build_pred_offsets), bytes from the own slot in the permuted 1 KiB layout for kernel3 (build_gather_tables)
     const uint16_t *pair_pos;  // [256] dword position of halfword pair q inside a 1 KiB slot (gather_layout.inc)
     const uint16_t *heap_of_pos; // [512] its inverse per halfword: heap index stored at halfword position i
+    const uint32_t *halo_list; // [kP3Threads] the halo values a tile needs, one per thread (build_halo_list)
     uint32_t *inexact;         // (set per plane by the kernel: acc + kAccInexact) raised when a staged value does not fit the LDS image; the exact kernel then redoes the plane
     // planes of a batch (grid.y): plane k reads coefs + k * coef_stride, writes bucket / prediction + k * out_stride, hist + k * 10 * 1024, n_oob + k,
     // hands over through acc + k * kPredAccWords and takes its parameters from params[k] (NULL: pp)
@@ -63,6 +67,8 @@ struct PredArgs {
     unsigned long long *trace; // diagnostic timeline, null in production
     uint32_t *acc;             // plan scratch, all zero between launches: [kHistBins] counts, then kAccOob (u64), kAccTicket
     uint32_t n_tiles;
+    int32_t trusted;      // the caller vouches for |coefficient| <= 256 (this library's forward kernel wrote them) and enqueues no exact kernel: a plane that
+                          // raises `inexact` all the same reports n_oob = ~0 (an error the host maps to FRI_HIP_ERR_OUT_OF_RANGE) and lowers the flag itself
     PredictParams pp;     // this plane's parameters (filled per plane inside the kernel)
     PredictParams pp3[3]; // plane k < 3 of a launch without a params array
 };
@@ -113,7 +119,8 @@ __device__ __forceinline__ void pred_hand_over(const PredArgs &a, const uint32_t
     }
     if (tid == 0) {
         const unsigned long long oob = __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(a.acc + kAccOob), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *a.n_oob = inexact ? 0ull : oob;
+        *a.n_oob = inexact ? (a.trusted ? ~0ull : 0ull) : oob;
+        if (inexact && a.trusted) __hip_atomic_store(a.inexact, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // no exact kernel follows to lower it
         __hip_atomic_store(a.acc + kAccTicket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -384,7 +391,6 @@ struct P3Lds { // static LDS: every address below is a compile-time constant tha
     int32_t ring[3][kPredSlots];                        // slot lists of tiles i, i + 1, i + 2
     uint16_t bkt[32];                                   // bucket_of(w) << 12
     uint32_t masks[2][kPredSlots][16];                  // Some/None masks of the staged cells
-    uint32_t lf_rel[2][4];                              // the LF pass's offsets (p3_lf_pass), per heap node 0 / 1
 };
 static_assert(sizeof(P3Lds) <= 160 * 1024 && kP3ImageBytes + kP3SlotBytes < 65536, "LDS budget / image + cell offset must fit a DS instruction's 16-bit offset field");
 struct P3Group { // the parameters of one layer group (prediction.rs:165-179)
@@ -468,7 +474,7 @@ __device__ __forceinline__ int p3_node_of(int lane, int n) {
 // both, the distance rides in the offset field) out of LDS image IMG. One straight-line body for every kind of cell: interior,
 // boundary (some4 = which of the lane's nodes are Some) and absent (some4 = 0, the results go to the wave's junk lines) - the gather
 // registers then never pass through a control-flow merge, where the compiler would copy all twelve. Heap nodes 0 and 1 (lane 0 of
-// role 0) belong to the LF predictor, which p3_lf_pass evaluates for the whole tile: here they are computed like any node and masked.
+// role 0) belong to the LF predictor, which the prologue evaluates for all of the workgroup's tiles (p3_lf_finish): here they are computed like any node and masked.
 // Role 1 leaves as one dwordx4 + one dword store, role 0 as two dwordx2 + two short stores.
 template <int IMG, int ROLE, int CELL>
 __device__ __forceinline__ void p3_half(const uint32_t (&addr)[4][6], float (&ga)[6], float (&gb)[6], const int (&own)[4], const PredictParams &pp, bool interior, uint32_t some4,
@@ -539,39 +545,61 @@ __device__ __forceinline__ void p3_half(const uint32_t (&addr)[4][6], float (&ga
     }
 }
 
-// get_lf_context_bucket (prediction.rs:86-149) for heap nodes 0 (DC) and 1 (root) of all 16 block cells of a tile at once: lane = 2 *
-// block cell + node, run by one wave per tile. The three neighbours are the same heap node of the cells to the left, up-left and
-// up-right (lf_addr: their LDS addresses relative to the own slot); values come out of the image as integers (exact: the image holds
-// magnitudes <= 256 only).
-template <int IMG>
-__device__ __forceinline__ void p3_lf_pass(const PredArgs &a, P3Lds &lds, const int32_t *cur_slots, int lane) {
-    if (lane >= 2 * kPredBlock * kPredBlock) return;
-    // (nothing loop invariant may be hoisted out of here into registers all sixteen waves would pay for: the lane index the address
-    // arithmetic starts from is made opaque)
-    asm volatile("" : "+v"(lane));
-    const int c = lane >> 1, n = lane & 1;
-    const u32x4 lf = *reinterpret_cast<const u32x4 *>(lds.lf_rel[n]); // kept in LDS: loop invariants of ONE wave must not cost all of them registers
-    const uint32_t lf_rel[4] = {lf.x, lf.y, lf.z, lf.w};
+// get_lf_context_bucket (prediction.rs:86-149) for heap nodes 0 (DC) and 1 (root), OUTSIDE the tile loop. The two nodes of a cell see the
+// same heap node of three neighbouring CELLS (left, up-left, up-right: entries 0..2 of their rows of the static neighbour table), 66 K
+// nodes of a 4096^2 plane's 17 M - but as a pass of one wave inside every tile iteration (round 2) they sat on the critical path of the
+// tile's barrier: ~95 vector instructions and three LDS round trips on one of sixteen waves, ~0.3 us of every 4.3 us tile. Here one thread
+// takes one (tile of the workgroup's walk, block cell, node): slot entries first (hop A: the cell and its three neighbours come out of the
+// tile's slot list), then four int32 coefficients straight from global memory (hop B; exact for any int32, no LDS image involved), and both
+// hops ride on round trips the prologue makes anyway (slot lists of the first tiles; the first tile's staging loads).
+struct P3LfItem {
+    int raw;          // slot entry of the own cell (-1: no item / no cell)
+    int nb[3];        // slot entries of the three neighbour cells (-1: absent, or the position is never a node: the reference reads 0)
+    int node;         // heap index 0 / 1
+};
+__device__ __forceinline__ void p3_lf_hop_a(const PredArgs &a, uint32_t tile, bool active, int tid, P3LfItem &it) {
+    const int c = (tid & 31) >> 1;
+    it.node = tid & 1;
     const int slot = (1 + c / kPredBlock) * kPredSide + 1 + (c % kPredBlock);
-    const int raw = cur_slots[slot];
-    const int cell = pred_slot_cell(raw);
-    const uint8_t *img = lds.cells[IMG];
-    auto value_at = [&](uint32_t rel) -> int { // rel: byte offset from the own slot, 0x7FFF = never a node
-        const uint32_t off = rel == 0x7FFFu ? (uint32_t)kP3ZeroOff : (uint32_t)(slot * kP3SlotBytes + (int)(short)rel);
-        const uint32_t h = *reinterpret_cast<const uint16_t *>(img + off);
-        return f32_as_i32(__builtin_bit_cast(float, h << 16));
-    };
-    const int v0 = value_at(lf_rel[0]), v1 = value_at(lf_rel[1]), v2 = value_at(lf_rel[2]), value = value_at(lf_rel[3]);
+    const int32_t *row = a.pred_slots + (size_t)(active ? tile : 0) * kPredSlots;
+    it.raw = row[slot];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t e = a.nbr_table[it.node * 6 + k];
+        const int s7 = (e >> 9) & 7; // index into {self, +V9[0..5]}: lattice deltas as in pred_offsets_from_row
+        const int da = (int)((0x0F14u >> (2 * s7)) & 3u), db = (int)((0x14F0u >> (2 * s7)) & 3u);
+        const int delta = ((da & 1) - (da & 2)) * kPredSide + ((db & 1) - (db & 2));
+        const int r = row[slot + delta];
+        it.nb[k] = (e & 0x8000u) ? -1 : r;
+    }
+    if (!active) it.raw = -1;
+}
+struct P3LfValues {
+    int v[3], value;
+    uint32_t mask0;
+};
+__device__ __forceinline__ void p3_lf_hop_b(const PredArgs &a, const int32_t *plane, const P3LfItem &it, P3LfValues &x) {
+    const uint32_t n = (uint32_t)it.node;
+#pragma unroll
+    for (int k = 0; k < 3; k++) x.v[k] = (plane + (size_t)max(pred_slot_cell(it.nb[k]), 0) * kCell)[n]; // unconditional loads: an absent neighbour reads cell 0 and is zeroed below
+    const int cell = max(pred_slot_cell(it.raw), 0);
+    x.value = (plane + (size_t)cell * kCell)[n];
+    x.mask0 = a.valid_mask[(size_t)cell * 16];
+}
+__device__ __forceinline__ void p3_lf_finish(const PredArgs &a, uint32_t *s_hist, const P3LfItem &it, const P3LfValues &x) {
+    const int cell = pred_slot_cell(it.raw);
+    if (cell < 0) return;
+    int v[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) v[k] = it.nb[k] < 0 || x.v[k] == kNone ? 0 : x.v[k]; // no cell there / Option::None: unwrap_or(0)
     uint32_t b12;
     int prediction;
-    p3_lf(v0, v1, v2, b12, prediction);
-    const bool some = cell >= 0 && (pred_slot_interior(raw) || ((lds.masks[IMG][slot][0] >> n) & 1u));
-    const uint32_t sym = pack_signed(sub_w(value, prediction));
-    if (some) atomicAdd(&lds.hist[sym < 1024u ? (b12 >> 2) + sym : (uint32_t)kHistBins], 1u);
-    if (cell >= 0) {
-        if (a.prediction) a.prediction[(size_t)cell * kCell + n] = some ? prediction : 0;
-        if (a.bucket) a.bucket[(size_t)cell * kCell + n] = (uint8_t)(some ? b12 >> 12 : 0u);
-    }
+    p3_lf(v[0], v[1], v[2], b12, prediction);
+    const bool some = pred_slot_interior(it.raw) || ((x.mask0 >> it.node) & 1u);
+    const uint32_t sym = pack_signed(sub_w(x.value, prediction));
+    if (some) atomicAdd(&s_hist[sym < 1024u ? (b12 >> 2) + sym : (uint32_t)kHistBins], 1u);
+    if (a.prediction) a.prediction[(size_t)cell * kCell + it.node] = some ? prediction : 0;
+    if (a.bucket) a.bucket[(size_t)cell * kCell + it.node] = (uint8_t)(some ? b12 >> 12 : 0u);
 }
 
 // The same outputs the way the reference computes them for ANY int32 input (prediction.rs:86-207, context_modeling.rs:25-77): one
@@ -686,35 +714,28 @@ __global__ void __launch_bounds__(kCell) exact_predict_kernel(const ExactArgs a0
     }
 }
 
-struct P3Staged { // one whole (halo) cell on its way from global memory to an LDS image
-    i32x4 lo, hi;  // heap nodes 4 lane .. 4 lane + 3 and 256 + 4 lane .. 256 + 4 lane + 3
-    uint32_t mask; // lanes 0..15: the cell's Some/None words
-};
-__device__ __forceinline__ void p3_issue_cell(const PredArgs &a, const int32_t *plane, int raw, int lane, P3Staged &st) {
-    const int cell = max(pred_slot_cell(raw), 0); // a slot without a cell loads cell 0 and is zeroed at the commit: no load is conditional
-    const i32x4 *src = reinterpret_cast<const i32x4 *>(plane + (size_t)cell * kCell); // wave-uniform base + 32-bit lane offset
-    st.lo = src[(uint32_t)lane];
-    st.hi = src[64u + (uint32_t)lane];
-    st.mask = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u];
-}
 __device__ __forceinline__ int p3_some_or_zero(int v) { return v == kNone ? 0 : v; }
-// int32 -> upper half of the f32 pattern, two per dword; returns the larger magnitude (as f32)
+// int32 -> upper half of the f32 pattern, two per dword; with CHECK returns the larger magnitude (as f32), else 0
+template <bool CHECK>
 __device__ __forceinline__ float p3_pack2(int x, int y, uint32_t &d) {
     const float f0 = (float)x, f1 = (float)y;
     d = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, f1), __builtin_bit_cast(uint32_t, f0), 0x07060302u);
-    return __builtin_fmaxf(__builtin_fabsf(f0), __builtin_fabsf(f1));
+    return CHECK ? __builtin_fmaxf(__builtin_fabsf(f0), __builtin_fabsf(f1)) : 0.f;
 }
 // Four consecutive heap nodes (two pairs) of a cell into its slot at byte positions pos0, pos1. `raw` is the slot-list entry.
-// Returns the largest magnitude written.
+// Returns the largest magnitude written (CHECK). The fix-up of a boundary cell's None entries / of a slot without a cell happens IN PLACE
+// (wave-uniform and rare): a by-value copy made the compiler keep two versions of the lane's own values around the branch - eight register
+// moves per tile on the common path; the own values with None -> 0 serve the residuals just as well (a None node's outputs are masked).
+template <bool CHECK>
 __device__ __forceinline__ float p3_commit4(int raw, i32x4 v, uint8_t *dst, uint32_t pos0, uint32_t pos1) {
-    if (!pred_slot_interior(raw)) { // wave-uniform and rare: a slot without a retained cell reads as 0, a boundary cell's None entries too (unwrap_or(0))
+    if (!pred_slot_interior(raw)) { // a slot without a retained cell reads as 0, a boundary cell's None entries too (unwrap_or(0))
         if (raw < 0)
             v = i32x4{0, 0, 0, 0};
         else
             v = i32x4{p3_some_or_zero(v.x), p3_some_or_zero(v.y), p3_some_or_zero(v.z), p3_some_or_zero(v.w)};
     }
     uint32_t d0, d1;
-    const float m = __builtin_fmaxf(p3_pack2(v.x, v.y, d0), p3_pack2(v.z, v.w, d1));
+    const float m = __builtin_fmaxf(p3_pack2<CHECK>(v.x, v.y, d0), p3_pack2<CHECK>(v.z, v.w, d1));
     *reinterpret_cast<uint32_t *>(dst + pos0) = d0;
     *reinterpret_cast<uint32_t *>(dst + pos1) = d1;
     return m;
@@ -725,29 +746,22 @@ __device__ __forceinline__ float p3_commit4(int raw, i32x4 v, uint8_t *dst, uint
 __device__ __forceinline__ void p3_check(float m, int lane, uint32_t *inexact) {
     if (__builtin_expect(__any(m > 256.0f), 0) && lane == 0) __hip_atomic_store(inexact, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// a quarter of a halo cell: heap nodes 128 quarter + 2 lane, + 1 = one pair per lane
-struct P3Quarter {
-    i32x2 v;
-    uint32_t mask;
+// One halo value per thread and tile (build_halo_list): the slot-list entry of its halo cell comes out of the LDS ring, the value straight from
+// the plane (wave-uniform base + 32-bit offset), and it lands as one halfword - the upper half of its f32 pattern - in the next image.
+struct P3Halo {
+    int raw, v;
 };
-__device__ __forceinline__ void p3_issue_quarter(const PredArgs &a, const int32_t *plane, int raw, int quarter, int lane, P3Quarter &st) {
-    const int cell = max(pred_slot_cell(raw), 0);
-    st.v = reinterpret_cast<const i32x2 *>(plane + (size_t)cell * kCell + 128 * quarter)[(uint32_t)lane];
-    st.mask = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u];
+__device__ __forceinline__ void p3_issue_halo(const int32_t *plane, const int32_t *slots, uint32_t ring_off, uint32_t heap_off, P3Halo &h) {
+    h.raw = *reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(slots) + ring_off);
+    const uint32_t cell = (uint32_t)max(h.raw, 0) & (uint32_t)(kPredSlotInterior - 1); // a slot without a cell reads cell 0 and is zeroed at the commit
+    h.v = *reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(plane) + ((cell << 11) + heap_off));
 }
-__device__ __forceinline__ float p3_commit_quarter(int raw, int slot, int quarter, int lane, uint32_t qpos, P3Quarter st, uint8_t *image, uint32_t *masks) {
-    if (quarter == 0 && lane < 16) masks[slot * 16 + lane] = st.mask;
-    int x = st.v.x, y = st.v.y;
-    if (!pred_slot_interior(raw)) {
-        if (raw < 0)
-            x = y = 0;
-        else
-            x = p3_some_or_zero(x), y = p3_some_or_zero(y);
-    }
-    uint32_t d;
-    const float m = p3_pack2(x, y, d);
-    *reinterpret_cast<uint32_t *>(image + slot * kP3SlotBytes + qpos) = d;
-    return m;
+template <bool CHECK>
+__device__ __forceinline__ float p3_commit_halo(const P3Halo &h, uint8_t *image, uint32_t lds_off) {
+    const int v = (h.raw < 0 || h.v == kNone) ? 0 : h.v; // no cell there / Option::None: unwrap_or(0)
+    const float f = (float)v;
+    *reinterpret_cast<uint16_t *>(image + lds_off) = (uint16_t)(__builtin_bit_cast(uint32_t, f) >> 16);
+    return CHECK ? __builtin_fabsf(f) : 0.f;
 }
 
 // Wave w of a workgroup works on the block cells 2 (w >> 1) and 2 (w >> 1) + 1 of a tile - neighbours in a block row, so their LDS slots
@@ -755,9 +769,10 @@ __device__ __forceinline__ float p3_commit_quarter(int raw, int slot, int quarte
 // addresses serves both cells.
 struct P3Lane {          // loop invariants of a lane
     uint32_t addr[4][6]; // LDS addresses (image 0, first cell) of the six neighbours of its four nodes
-    uint32_t wpos[4];    // byte positions inside a slot of pairs 2 lane, 2 lane + 1, 128 + 2 lane, 128 + 2 lane + 1 (what a lane stages of a halo cell)
-    uint32_t opos[2];    // of the two pairs it stages of its own cells: role 1 = wpos[2], wpos[3]; role 0 = pairs lane and 64 + lane
-    uint32_t qpos;       // of its pair of the quarter cell
+    uint32_t opos[2];    // byte positions inside a slot of the two pairs it stages of its own cells: role 1 = pairs 128 + 2 lane, + 1; role 0 = pairs lane and 64 + lane
+    uint32_t halo_ring;  // the thread's halo value (build_halo_list): byte offset of its cell's entry in a slot list,
+    uint32_t halo_heap;  // byte offset of the value inside the cell's 2 KiB,
+    uint32_t halo_lds;   // byte offset of its halfword inside an LDS image
 };
 
 // what a wave stages of one of its own block cells: its four nodes (role 1: one dwordx4, role 0: two dwordx2). Wave-uniform base
@@ -771,20 +786,18 @@ __device__ __forceinline__ i32x4 p3_load_own(const int32_t *cell_base, uint32_t 
 
 // OWN_CUR / OWN_NXT: the lane's own values (exact int32, for the residuals) of this tile's two cells and, loaded here, of the next
 // tile's; the two register sets swap roles from tile to tile (IMG), so nothing is copied.
-template <int IMG, int ROLE>
+template <int IMG, int ROLE, bool CHECK>
 __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane, P3Lds &lds, int it, bool more, uint32_t next2_tile, int tid, int lane, int wave, int slot_a,
                                         const P3Lane &L, float (&ga)[6], float (&gb)[6], const i32x4 (&own_cur)[2], i32x4 (&own_nxt)[2]) {
     uint32_t *s_hist = lds.hist;
     const uint16_t *s_bkt = lds.bkt;
     const int32_t *cur_slots = lds.ring[it % 3], *nxt_slots = lds.ring[(it + 1) % 3];
     // in flight across the arithmetic below: the slot list of tile i + 2 and what this wave stages of tile i + 1 - its half of its two
-    // block cells, one halo cell, a quarter of one of the last four halo cells
+    // block cells and one halo value per lane
     const int32_t slot_pre = a.pred_slots[(size_t)next2_tile * kPredSlots + tid % kPredSlots];
-    const int halo_slot = p3_halo_slot(wave), quarter_slot = p3_halo_slot(kP3Waves + (wave >> 2)), quarter = wave & 3;
     uint32_t st_own_mask[2];
-    P3Staged st_halo;
-    P3Quarter st_q;
-    int raw_own[2] = {-1, -1}, raw_halo = -1, raw_q = -1;
+    P3Halo st_halo;
+    int raw_own[2] = {-1, -1};
     if (ablate_flags(a.ablate) & 2) more = false;
     if (more) {
 #pragma unroll
@@ -794,13 +807,8 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
             own_nxt[c] = p3_load_own<ROLE>(plane + (size_t)cell * kCell, (uint32_t)lane);
             if (ROLE == 1) st_own_mask[c] = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u]; // the level-8 waves have registers to spare
         }
-        raw_halo = __builtin_amdgcn_readfirstlane(nxt_slots[halo_slot]);
-        raw_q = __builtin_amdgcn_readfirstlane(nxt_slots[quarter_slot]);
-        p3_issue_cell(a, plane, raw_halo, lane, st_halo);
-        p3_issue_quarter(a, plane, raw_q, quarter, lane, st_q);
+        p3_issue_halo(plane, nxt_slots, L.halo_ring, L.halo_heap, st_halo);
     }
-
-    if (ROLE == 1 && wave == 1 && !(ablate_flags(a.ablate) & 1)) p3_lf_pass<IMG>(a, lds, cur_slots, lane);
 
     // two block cells per wave; every cell issues the same number of stores (without a retained cell at the block slot they go to the
     // wave's junk lines), so the commit below waits for the staging loads with a counted vmcnt and not for the stores just issued
@@ -819,7 +827,7 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
                 some4 = (m[8 + (lane >> 3)] >> (4 * (lane & 7))) & 15u;
             } else {
                 some4 = ((m[lane >> 4] >> (2 * (lane & 15))) & 3u) | (((m[4 + (lane >> 4)] >> (2 * (lane & 15))) & 3u) << 2);
-                if (lane == 0) some4 &= ~3u; // heap nodes 0 and 1: p3_lf_pass
+                if (lane == 0) some4 &= ~3u; // heap nodes 0 and 1: p3_lf_finish
             }
         }
         const int own4[4] = {own_cur[c].x, own_cur[c].y, own_cur[c].z, own_cur[c].w};
@@ -843,27 +851,30 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
     if (more) {
         // The staged registers are consumed from here on, not earlier: left alone, the compiler hoists uses of the next tile's own
         // values to the top of the iteration and waits for the loads there - in front of the arithmetic they are meant to hide behind.
-        asm volatile("" : "+v"(own_nxt[0]), "+v"(own_nxt[1]), "+v"(st_halo.lo), "+v"(st_halo.hi), "+v"(st_q.v));
-        uint8_t *nxt = lds.cells[IMG ^ 1];
-        uint32_t *nxt_masks = &lds.masks[IMG ^ 1][0][0];
+        asm volatile("" : "+v"(own_nxt[0]), "+v"(own_nxt[1]), "+v"(st_halo.v));
+        // The image the staging writes into is a compile-time constant per unrolled phase, so the nine write addresses of a lane (image + slot +
+        // lane position) are loop invariants to the compiler: it hoists them out of the tile loop into registers the loop does not have - and
+        // reloads the spilled ones from scratch memory behind an s_waitcnt vmcnt(0), i.e. behind the tile's stores. The image offset is made
+        // opaque (a scalar: no instruction), so the additions stay where they are.
+        uint32_t nxt_img = IMG ^ 1;
+        asm volatile("" : "+s"(nxt_img));
+        uint8_t *nxt = lds.cells[0] + nxt_img * kP3ImageBytes;
+        uint32_t *nxt_masks = &lds.masks[0][0][0] + nxt_img * (kPredSlots * 16);
         float m = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            m = __builtin_fmaxf(m, p3_commit4(raw_own[c], own_nxt[c], nxt + (slot_a + c) * kP3SlotBytes, L.opos[0], L.opos[1]));
+            m = __builtin_fmaxf(m, p3_commit4<CHECK>(raw_own[c], own_nxt[c], nxt + (slot_a + c) * kP3SlotBytes, L.opos[0], L.opos[1]));
             if (ROLE == 1 && lane < 16) nxt_masks[(slot_a + c) * 16 + lane] = st_own_mask[c];
         }
-        if (lane < 16) nxt_masks[halo_slot * 16 + lane] = st_halo.mask;
-        m = __builtin_fmaxf(m, p3_commit4(raw_halo, st_halo.lo, nxt + halo_slot * kP3SlotBytes, L.wpos[0], L.wpos[1]));
-        m = __builtin_fmaxf(m, p3_commit4(raw_halo, st_halo.hi, nxt + halo_slot * kP3SlotBytes, L.wpos[2], L.wpos[3]));
-        m = __builtin_fmaxf(m, p3_commit_quarter(raw_q, quarter_slot, quarter, lane, L.qpos, st_q, nxt, nxt_masks));
-        p3_check(m, lane, a.inexact);
+        m = __builtin_fmaxf(m, p3_commit_halo<CHECK>(st_halo, nxt, L.halo_lds));
+        if (CHECK) p3_check(m, lane, a.inexact);
     }
     if (tid < kPredSlots) lds.ring[(it + 2) % 3][tid] = slot_pre;
     lds_barrier();
     trace_stamp(a.trace, blockIdx.x, 2 + it, tid);
 }
 
-template <int ROLE>
+template <int ROLE, bool CHECK>
 __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, int lane, int wave) {
     uint8_t *s_cells = lds.cells[0];
     int32_t *s_ring = &lds.ring[0][0];
@@ -885,25 +896,32 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
             L.addr[j][k] = r == 0x7FFF ? cells_lds + kP3ZeroOff : cells_lds + (uint32_t)(slot_a * kP3SlotBytes + r);
         }
     }
-#pragma unroll
-    for (int w = 0; w < 4; w++) L.wpos[w] = 4u * a.pair_pos[2 * lane + (w & 1) + 128 * (w >> 1)];
-    L.opos[0] = ROLE ? L.wpos[2] : 4u * a.pair_pos[lane];
-    L.opos[1] = ROLE ? L.wpos[3] : 4u * a.pair_pos[64 + lane];
-    L.qpos = 4u * a.pair_pos[64 * (wave & 3) + lane];
+    L.opos[0] = 4u * a.pair_pos[ROLE ? 128 + 2 * lane : lane];
+    L.opos[1] = 4u * a.pair_pos[ROLE ? 129 + 2 * lane : 64 + lane];
+    {
+        const uint32_t e = a.halo_list[tid];
+        L.halo_ring = 4u * (e & 63u), L.halo_heap = 4u * ((e >> 8) & 511u), L.halo_lds = (e & 63u) * (uint32_t)kP3SlotBytes + (e >> 20);
+    }
     float ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     i32x4 own_a[2] = {i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}}, own_b[2] = {i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
 
     const PredTileWalk walk(a.n_tiles);
     if (walk.first >= walk.end) return; // (a workgroup without a tile still takes part in the hand-over)
     const uint32_t last = walk.first + ((walk.end - 1 - walk.first) / walk.step) * walk.step; // this workgroup's last tile
+    // Heap nodes 0 and 1 of every block cell of this workgroup's tiles (p3_lf_*), by the level-8 waves only (role 0 holds two parameter groups
+    // in scalar registers and has none to spare: with this code in its prologue its tile loop spilled 68 scalars instead of 4): thread t of the
+    // eight role-1 waves takes tile t >> 5 of the walk, 16 tiles per pass.
+    constexpr uint32_t kLfTilesPerPass = kP3Threads / 2 / 32;
+    const uint32_t my_tiles = (walk.end - walk.first + walk.step - 1u) / walk.step;
+    const int lf_tid = (wave >> 1) * 64 + lane;
+    P3LfItem lf_item;
+    if (ROLE == 1) p3_lf_hop_a(a, walk.first + (uint32_t)(lf_tid >> 5) * walk.step, (uint32_t)(lf_tid >> 5) < my_tiles, lf_tid, lf_item);
     if (tid < kPredSlots) {
         s_ring[tid] = a.pred_slots[(size_t)walk.first * kPredSlots + tid];
         s_ring[kPredSlots + tid] = a.pred_slots[(size_t)min(walk.first + walk.step, last) * kPredSlots + tid];
     }
     __syncthreads();
     { // tile 0 straight into image 0: everything a wave stages is requested before the first value is converted
-        const int halo_slot = p3_halo_slot(wave), quarter_slot = p3_halo_slot(kP3Waves + (wave >> 2)), quarter = wave & 3;
-        const int raw_halo = __builtin_amdgcn_readfirstlane(s_ring[halo_slot]), raw_q = __builtin_amdgcn_readfirstlane(s_ring[quarter_slot]);
         uint32_t st_own_mask[2] = {0, 0};
         int raw_own[2];
 #pragma unroll
@@ -913,31 +931,39 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
             own_a[c] = p3_load_own<ROLE>(plane + (size_t)cell * kCell, (uint32_t)lane);
             if (ROLE == 1) st_own_mask[c] = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u];
         }
-        P3Staged st_halo;
-        P3Quarter st_q;
-        p3_issue_cell(a, plane, raw_halo, lane, st_halo);
-        p3_issue_quarter(a, plane, raw_q, quarter, lane, st_q);
+        P3Halo st_halo;
+        p3_issue_halo(plane, s_ring, L.halo_ring, L.halo_heap, st_halo);
+        P3LfValues lf_values;
+        if (ROLE == 1) p3_lf_hop_b(a, plane, lf_item, lf_values); // behind the staging loads: one round trip for both
         float m = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            m = __builtin_fmaxf(m, p3_commit4(raw_own[c], own_a[c], s_cells + (slot_a + c) * kP3SlotBytes, L.opos[0], L.opos[1]));
+            m = __builtin_fmaxf(m, p3_commit4<CHECK>(raw_own[c], own_a[c], s_cells + (slot_a + c) * kP3SlotBytes, L.opos[0], L.opos[1]));
             if (ROLE == 1 && lane < 16) s_masks[(slot_a + c) * 16 + lane] = st_own_mask[c];
         }
-        if (lane < 16) s_masks[halo_slot * 16 + lane] = st_halo.mask;
-        m = __builtin_fmaxf(m, p3_commit4(raw_halo, st_halo.lo, s_cells + halo_slot * kP3SlotBytes, L.wpos[0], L.wpos[1]));
-        m = __builtin_fmaxf(m, p3_commit4(raw_halo, st_halo.hi, s_cells + halo_slot * kP3SlotBytes, L.wpos[2], L.wpos[3]));
-        m = __builtin_fmaxf(m, p3_commit_quarter(raw_q, quarter_slot, quarter, lane, L.qpos, st_q, s_cells, s_masks));
-        p3_check(m, lane, a.inexact);
+        m = __builtin_fmaxf(m, p3_commit_halo<CHECK>(st_halo, s_cells, L.halo_lds));
+        if (CHECK) p3_check(m, lane, a.inexact);
+        if (ROLE == 1 && !(ablate_flags(a.ablate) & 1)) p3_lf_finish(a, lds.hist, lf_item, lf_values);
+    }
+    if (ROLE == 1) {
+        for (uint32_t base = kLfTilesPerPass; base < my_tiles; base += kLfTilesPerPass) { // more than 16 tiles per workgroup (large images): further passes, two round trips each
+            const uint32_t k = base + (uint32_t)(lf_tid >> 5);
+            P3LfItem it;
+            P3LfValues x;
+            p3_lf_hop_a(a, walk.first + k * walk.step, k < my_tiles, lf_tid, it);
+            p3_lf_hop_b(a, plane, it, x);
+            if (!(ablate_flags(a.ablate) & 1)) p3_lf_finish(a, lds.hist, it, x);
+        }
     }
     __syncthreads();
     trace_stamp(a.trace, blockIdx.x, 1, tid);
 
     int it = 0;
     for (uint32_t tile = walk.first; tile < walk.end;) { // unrolled by two: the LDS image a tile lives in is a compile-time constant
-        p3_tile<0, ROLE>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_a, own_b);
+        p3_tile<0, ROLE, CHECK>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_a, own_b);
         tile += walk.step, it++;
         if (tile >= walk.end) break;
-        p3_tile<1, ROLE>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_b, own_a);
+        p3_tile<1, ROLE, CHECK>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_b, own_a);
         tile += walk.step, it++;
     }
 }
@@ -965,6 +991,10 @@ __device__ __forceinline__ PredArgs pred_plane_view(const PredArgs &a0, uint32_t
     return a;
 }
 
+// CHECK = false: the coefficients were written by this library's forward kernel in the same chain (fri_hip_encode_image*): every magnitude is
+// <= 255 by construction and the staging does not look (18 max operations per lane and tile). CHECK = true: any int32 array; a value the LDS image
+// cannot hold raises the plane's `inexact` flag (see PredArgs::trusted for what happens then).
+template <bool CHECK>
 __global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const PredArgs a0) {
     const PredArgs a = pred_plane_view(a0, blockIdx.y);
     __shared__ __attribute__((aligned(16))) P3Lds lds;
@@ -977,17 +1007,12 @@ __global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const Pr
     trace_stamp(a.trace, blockIdx.x, 0, tid);
     for (int i = tid; i < kHistBins + 4; i += kP3Threads) s_hist[i] = 0;
     if (tid < 32) s_bkt[tid] = (uint16_t)(bucket_of((uint32_t)tid) << 12);
-    if (tid < 2) { // the LF pass: byte offsets, from a cell's slot, of heap node tid's neighbours left, up-left, up-right and of the node itself
-        const u32x4 o = reinterpret_cast<const u32x4 *>(a.pred_off)[tid];
-        lds.lf_rel[tid][0] = o.x & 0xFFFFu, lds.lf_rel[tid][1] = o.x >> 16, lds.lf_rel[tid][2] = o.y & 0xFFFFu;
-        lds.lf_rel[tid][3] = 4u * a.pair_pos[0] + 2u * (uint32_t)tid;
-    }
     for (int i = tid; i < 2 * (kP3ImageBytes - kP3ZeroOff) / 4; i += kP3Threads) // the zero words behind the cells of both images
         reinterpret_cast<uint32_t *>(s_cells + (i / ((kP3ImageBytes - kP3ZeroOff) / 4)) * kP3ImageBytes + kP3ZeroOff)[i % ((kP3ImageBytes - kP3ZeroOff) / 4)] = 0;
     if (wave & 1)
-        p3_run<1>(a, lds, tid, lane, wave);
+        p3_run<1, CHECK>(a, lds, tid, lane, wave);
     else
-        p3_run<0>(a, lds, tid, lane, wave);
+        p3_run<0, CHECK>(a, lds, tid, lane, wave);
     __syncthreads();
     trace_stamp(a.trace, blockIdx.x, 13, tid);
     pred_hand_over(a, s_hist, reinterpret_cast<uint32_t *>(s_ring), tid, kP3Threads);
@@ -1031,8 +1056,41 @@ void build_gather_tables(const uint16_t *nbr_table, uint32_t *gather_off /* [512
     }
 }
 
+// Which values of the 20 halo cells of a tile are ever read. A gather that leaves the own cell goes to one of the six lattice neighbours, and
+// the static neighbour table says where: per direction only 21..46 of the neighbour's 512 nodes (its rim towards this cell) are ever a
+// neighbour position. For a 4 x 4 block that makes 902 (halo slot, heap node) pairs in 18 of the 20 halo slots - round 2 staged all
+// 20 x 512 = 10 240 values per tile, 40 of a tile's 72 KB of loads and ~55 of its ~85 staging instructions per lane. One entry per thread of the
+// 1024-thread workgroup: out[t] = slot | heap << 8 | (byte position inside the slot) << 20, sorted by (slot, heap) so that neighbouring lanes read
+// neighbouring addresses. out[0] = 0xFFFFFFFF: the list does not fit (never with the reference's LITERALS).
+void build_halo_list(const uint16_t *nbr_table, const uint16_t *pair_pos, uint32_t *out /* [kP3Threads] */) {
+    std::vector<uint32_t> keys;
+    for (int r = 1; r <= kPredBlock; r++)
+        for (int c = 1; c <= kPredBlock; c++)
+            for (int p = 2; p < kCell; p++) // heap nodes 0 and 1 are the LF predictor's, which reads global memory (p3_lf_*)
+                for (int k = 0; k < 6; k++) {
+                    const uint32_t e = nbr_table[p * 6 + k];
+                    const int slot7 = (e >> 9) & 7;
+                    if ((e & 0x8000u) || slot7 == 0) continue;
+                    const int da = (int)((0x0F14u >> (2 * slot7)) & 3u), db = (int)((0x14F0u >> (2 * slot7)) & 3u); // as in build_gather_tables
+                    const int rr = r + ((da & 1) - (da & 2)), cc = c + ((db & 1) - (db & 2));
+                    if (rr >= 1 && rr <= kPredBlock && cc >= 1 && cc <= kPredBlock) continue; // another block cell: staged whole by its own waves
+                    keys.push_back((uint32_t)(rr * kPredSide + cc) << 16 | (e & 511u));
+                }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    out[0] = 0xFFFFFFFFu;
+    if (keys.size() > (size_t)kP3Threads) return; // (cannot happen with the reference's LITERALS: 902 entries; the plan checks the table it uploads)
+    // threads without an entry stage heap node 0 of slot 0 - a corner of the 6 x 6 window, which no gather ever reads - each into a halfword of its own
+    for (size_t t = keys.size(); t < (size_t)kP3Threads; t++) out[t] = (uint32_t)(2 * (t - keys.size())) << 20;
+    for (size_t i = 0; i < keys.size(); i++) {
+        const uint32_t slot = keys[i] >> 16, heap = keys[i] & 511u;
+        const uint32_t pos = 2u * (2u * pair_pos[heap >> 1] + (heap & 1u));
+        out[i] = slot | heap << 8 | pos << 20;
+    }
+}
+
 hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const PredBatch &b, uint8_t *bucket, int32_t *prediction, uint32_t *hist, unsigned long long *n_oob,
-                                    bool from_forward_kernel, hipStream_t stream) {
+                                    int trust, hipStream_t stream) {
     if (!acc || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     PredArgs a{};
@@ -1052,6 +1110,7 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const Pr
     a.hist = hist;
     a.n_oob = n_oob;
     a.n_tiles = p.n_pred_tiles;
+    a.trusted = trust != kPredAnyInt32 ? 1 : 0;
     // One plane: a workgroup per CU. Many planes: a plane keeps an eighth of the machine busy (at least ~8 tiles per workgroup, so that
     // the start-up and the hand-over are paid once per 8 tiles) and eight planes run side by side.
     uint32_t blocks = p.n_pred_tiles < p.pred_blocks ? p.n_pred_tiles : p.pred_blocks;
@@ -1075,11 +1134,15 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const Pr
     a.pred_off = p.gather_off;
     a.pair_pos = p.pair_pos;
     a.heap_of_pos = p.heap_of_pos;
+    a.halo_list = p.halo_list;
     a.ablate = p.k2_ablate;
     (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
-    hipLaunchKernelGGL(predict_histogram_kernel3, dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
+    if (trust == kPredForwardOutput)
+        hipLaunchKernelGGL(predict_histogram_kernel3<false>, dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
+    else
+        hipLaunchKernelGGL(predict_histogram_kernel3<true>, dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
     e = hipGetLastError();
-    if (e != hipSuccess || from_forward_kernel) return e; // the forward kernel's coefficients are differences of 8-bit pixels divided by a quantiser: always representable
+    if (e != hipSuccess || trust != kPredAnyInt32) return e; // the forward kernel's coefficients are differences of 8-bit pixels divided by a quantiser: always representable
     ExactArgs x{};
     x.coefs = b.coefs;
     x.coef_stride = b.coef_stride;

@@ -1,5 +1,6 @@
 // k4_fit.hip -- the normal-equation sums behind the context-model fit (next row 8f-3).
 #include "gather_common.hpp"
+#include "solve6.hpp"
 
 namespace fri {
 namespace {
@@ -35,10 +36,6 @@ struct FitArgs {
     size_t coef_stride;
     const PredictParams *params;
     PredictParams pp3[3]; // plane k < 3 of a launch without a params array
-    // Host hand-over (the encode chain): when set, the sums go to pinned host memory and the plane's last workgroup then stores done_value to
-    // done_flag[plane] with system-scope release - the host polls the flag instead of queueing a copy and waiting for the stream.
-    unsigned long long *done_flag;
-    unsigned long long done_value;
     int32_t ablate;       // timing-only (tuning build, FRI_HIP_K4_ABLATE): 1 = no sums, 2 = tiles after the first are staged without their global loads
 };
 constexpr int kFitAccInt = 3 * 28, kFitAccDbl = kFitAccInt, kFitAccTicket = kFitAccInt + 18, kFitAccRange = kFitAccTicket + 1;
@@ -600,16 +597,58 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         if (a0.out_range) a0.out_range[plane] = r;
         __hip_atomic_store(accp + kFitAccTicket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (a0.done_flag) {
-        __builtin_amdgcn_s_waitcnt(0); // (every lane's stores are out; the release below writes back this XCD's L2 and waits once more)
-        if (tid == 0) __hip_atomic_store(a0.done_flag + plane, a0.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The 6 x 6 solves of the fit on the device (ContextModeler::optimize_value_prediction / optimize_width_prediction,
+// context_modeling.rs:144-202, behind prediction.rs:232-235): one thread per (plane, layer group) turns the sums a fit_accumulate launch
+// left in device memory into that group's six parameters, written into the device parameter array the next kernel of the chain reads
+// (the width pass of the fit, then K2) - so the chain K1 -> sums -> solve -> sums -> solve -> K2 is enqueued without the host in between.
+// The arithmetic is solve6.hpp's, shared with the host entry points. A kernel of its own rather than the tail of fit_accumulate_kernel2:
+// the eigen-decomposition route wants ~150 f64 registers (scratch), which must not become the sums kernel's register budget, and a
+// dependent kernel boundary (~1.5 us) costs what the solve would cost serially at the end of the sums kernel.
+struct SolveArgs {
+    const unsigned long long *sums_int; // [n_planes][3][28] (MODE 0) / [n_planes][3][21] (MODE 1)
+    const double *sums_dbl;             // [n_planes][3][6] (MODE 1)
+    float *params;                      // PredictParams[n_planes]: MODE 0 writes .value, MODE 1 .width
+    uint32_t n_planes;
+    unsigned long long rows[3];         // MODE 1: heights of the reference's matrices (F * {256, 128, 128})
+};
+template <int MODE>
+__global__ void __launch_bounds__(64) fit_solve_kernel(const SolveArgs a) {
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    if (t >= a.n_planes * 3u) return;
+    const uint32_t plane = t / 3u, g = t % 3u;
+    float *out = a.params + (size_t)plane * (sizeof(PredictParams) / sizeof(float)) + (MODE ? 18 : 0) + g * 6;
+    if (MODE == 0) {
+        fit_value_group(reinterpret_cast<const long long *>(a.sums_int) + ((size_t)plane * 3 + g) * 28, out);
+    } else {
+        const unsigned long long rows = g == 0 ? a.rows[0] : g == 1 ? a.rows[1] : a.rows[2]; // (selects: no dynamic index into the argument struct)
+        fit_width_group(reinterpret_cast<const long long *>(a.sums_int) + ((size_t)plane * 3 + g) * 21, a.sums_dbl + ((size_t)plane * 3 + g) * 6, rows, out);
     }
 }
 
 } // namespace
 
+hipError_t launch_fit_solve(int mode, uint32_t n_planes, const unsigned long long *sums_int, const double *sums_dbl, const unsigned long long rows[3], float *params,
+                            hipStream_t stream) {
+    if (!n_planes || !sums_int || !params || (mode == 1 && !sums_dbl)) return hipErrorInvalidValue;
+    SolveArgs a{};
+    a.sums_int = sums_int;
+    a.sums_dbl = sums_dbl;
+    a.params = params;
+    a.n_planes = n_planes;
+    for (int g = 0; g < 3; g++) a.rows[g] = rows ? rows[g] : 0;
+    const uint32_t blocks = (n_planes * 3u + 63u) / 64u;
+    (void)hipGetLastError();
+    if (mode == 0)
+        hipLaunchKernelGGL(fit_solve_kernel<0>, dim3(blocks), dim3(64), 0, stream, a);
+    else
+        hipLaunchKernelGGL(fit_solve_kernel<1>, dim3(blocks), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
-                                 unsigned long long *out_of_range, hipStream_t stream, unsigned long long *done_flag, unsigned long long done_value) {
+                                 unsigned long long *out_of_range, hipStream_t stream) {
     if (!acc || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
     FitArgs a{};
     a.coefs = b.coefs;
@@ -628,9 +667,6 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
     a.wtr = sums_dbl;
     a.out_range = out_of_range;
     a.ablate = p.k4_ablate;
-    a.done_flag = done_flag;
-    a.done_value = done_value;
-    if (done_flag && p.k4_previous) return hipErrorInvalidValue; // (the first kernel has no host hand-over)
     uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
     if (b.n_planes > 1) { // as in launch_predict_histogram: a plane on an eighth of the machine, eight planes side by side
         const uint32_t share = (p.n_pred_tiles + 7) / 8, eighth = p.hist_blocks / 8 ? p.hist_blocks / 8 : 1;

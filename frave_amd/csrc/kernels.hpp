@@ -33,6 +33,7 @@ struct DevicePlan {
     const uint32_t *gather_off = nullptr; // [512][4] the same in bytes for the permuted 1 KiB cell layout (build_gather_tables)
     const uint16_t *pair_pos = nullptr;   // [256] gather_layout.inc
     const uint16_t *heap_of_pos = nullptr; // [512]
+    const uint32_t *halo_list = nullptr;   // [1024] K2's sparse halo staging list (build_halo_list)
     const int32_t *pred_slots = nullptr;  // [n_pred_tiles][kPredSlots]
     uint32_t n_pred_tiles = 0;
     uint32_t *hist_partial = nullptr;     // [hist_blocks][10*1024] scratch for the histogram reduction
@@ -42,7 +43,6 @@ struct DevicePlan {
     uint32_t pred_blocks = 0;             // workgroups of the pipelined K2: one 1024-thread workgroup per CU
     bool k2_previous = false;             // tuning: round 1's pipelined K2 (A/B)
     bool k4_previous = false;             // tuning: round 1's fit kernel (A/B)
-    bool fit_no_poll = false;             // tuning: the encode chain fetches the fit sums with copy + stream synchronisation instead of the polled hand-over (A/B)
     uint32_t n_tiles = 0;
     uint32_t F = 0;
     int32_t width = 0, height = 0, channels = 0;
@@ -89,15 +89,22 @@ struct PredBatch {
     PredictParams pp[3] = {}; // used when params is NULL: plane k takes pp[min(k, 2)] (one image's channels travel as kernel arguments)
 };
 // K2. acc: n_planes accumulators of kPredAccWords words, all zero between launches. hist [n_planes][10][1024], n_oob [n_planes].
-// from_forward_kernel: the coefficients are this library's forward kernel's output (magnitudes <= 255): the exact int32 kernel that
-// backs the fast one up for arbitrary arrays is not enqueued.
+// trust: what is known about the coefficients. kPredAnyInt32: nothing - the fast kernel checks what it stages and the exact int32 kernel behind it
+// redoes a plane whose values its LDS image cannot hold. kPredPromised: the caller promises the forward kernel's output (magnitudes <= 255,
+// fri_hip_plan_assume_forward_coefficients): still checked, no exact kernel, a broken promise comes back as n_oob = ~0. kPredForwardOutput: this
+// library's forward kernel wrote them earlier in the same call: not checked.
+constexpr int kPredAnyInt32 = 0, kPredPromised = 1, kPredForwardOutput = 2;
 hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const PredBatch &b, uint8_t *bucket, int32_t *prediction, uint32_t *hist, unsigned long long *n_oob,
-                                    bool from_forward_kernel, hipStream_t stream);
+                                    int trust, hipStream_t stream);
 // Fit accumulators: mode 0 = value fit (sums_int[n_planes][3][28]), mode 1 = width fit (sums_int[n_planes][3][21], sums_dbl[n_planes][3][6]).
 // acc: n_planes accumulators of kFitAccWords words, all zero between launches.
 // out_of_range (may be NULL): per plane, the number of waves that staged a Some coefficient outside [-256, 255] - the sums are then not to be trusted.
 hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
-                                 unsigned long long *out_of_range, hipStream_t stream, unsigned long long *done_flag = nullptr, unsigned long long done_value = 0);
+                                 unsigned long long *out_of_range, hipStream_t stream);
+// The fit's 6 x 6 solves on the device: sums of a launch_fit_accumulate (mode 0: sums_int[n_planes][3][28]; mode 1: sums_int[n_planes][3][21],
+// sums_dbl[n_planes][3][6], rows[3] = heights of the reference's matrices) -> params[n_planes] (PredictParams: mode 0 writes .value, mode 1 .width).
+hipError_t launch_fit_solve(int mode, uint32_t n_planes, const unsigned long long *sums_int, const double *sums_dbl, const unsigned long long rows[3], float *params,
+                            hipStream_t stream);
 // K3: (reference-faithful) dequantisation + inverse transform + clamp.
 // n_images images of the plan's shape: image k at coefs + k * coef_stride (int32 elements), pixels + k * pixel_stride (bytes)
 hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, const int32_t *coefs, size_t coef_stride, const QMatrix &q, uint8_t *pixels, size_t pixel_stride,
@@ -106,6 +113,8 @@ hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, cons
 // K2's per-node neighbour offsets (LDS halfword offsets relative to the own slot, two per word) from the static neighbour table
 void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out /* [512][4] */);
 void build_gather_tables(const uint16_t *nbr_table, uint32_t *gather_off /* [512][4] */, uint16_t *pair_pos /* [256] */, uint16_t *heap_of_pos /* [512] */);
+// K2's sparse halo staging: the (halo slot, heap node) pairs a 4 x 4 block ever gathers, one per thread of its 1024-thread workgroup (0xFFFFFFFF = none)
+void build_halo_list(const uint16_t *nbr_table, const uint16_t *pair_pos, uint32_t *out /* [1024] */);
 size_t fwd_lds_bytes(const DevicePlan &p);
 size_t inv_lds_bytes(const DevicePlan &p);
 // True iff the lane/leaf footprint hard-wired in the kernels equals the table derived from LITERALS.

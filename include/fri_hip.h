@@ -158,6 +158,12 @@ int fri_hip_multi_transform_quant(fri_hip_multi *m, uint32_t n_images, const uin
 int fri_hip_predict_histogram(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, const float value_params[3][6],
                               const float width_params[3][6], uint8_t *bucket, int32_t *prediction, uint32_t *hist,
                               uint64_t *n_out_of_alphabet);
+/* The caller's promise that the coefficient arrays it hands to fri_hip_predict_histogram_dev / _batch_dev on this plan are outputs of
+ * fri_hip_transform_quant* (every magnitude <= 256) - the situation of the replacement stage bodies, where prediction::encode always receives
+ * what wavelet_transform::encode + quantization::encode produced: with on != 0 the exact int32 kernel behind the fast one is not enqueued
+ * (one launch less, ~5 us). A broken promise is detected, not obeyed: the plane reports *n_out_of_alphabet == UINT64_MAX and an all-zero
+ * histogram. Default: off (any int32 array accepted). */
+int fri_hip_plan_assume_forward_coefficients(fri_hip_plan *plan, int on);
 /* Device form: d_hist u32[10*1024] and d_n_out_of_alphabet u64[1] are overwritten. */
 int fri_hip_predict_histogram_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint32_t channel, const float value_params[3][6],
                                   const float width_params[3][6], uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist,
@@ -190,8 +196,10 @@ int fri_hip_fit_value_sums(fri_hip_plan *plan, const int32_t *coefs, uint32_t ch
 int fri_hip_fit_value_sums_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint32_t channel, int64_t *d_gram, void *stream);
 /* Width fit (optimize_width_prediction, :144-173) for given value parameters x: residual r = |f32(value) - A x| in f32
  * (left to right like nalgebra's gemv), features w = [1, |v0-v3|, |v1-v2|, |v4-v5|, |v1-v5|, |v2-v4|].
- * wtw[g][21] = upper triangle of sum w w^T over the Some rows (exact), wtr[g][6] = sum w r (f64; summation order is not
- * fixed, so the last bits may vary between runs). rows[g] = height of the reference's matrix (F*256, F*128, F*128): its
+ * wtw[g][21] = upper triangle of sum w w^T over the Some rows (exact), wtr[g][6] = sum w r: the products of the (at most 16) nodes a lane
+ * holds of one tile are summed in f32, everything beyond that in f64 - relative error <= 2^-20 of sum |w r|, far inside the reference's own
+ * fit, whose matrices and SVD are f32 throughout (context_modeling.rs:144-173); the summation order across workgroups is not fixed, so the
+ * last bits may vary between runs. rows[g] = height of the reference's matrix (F*256, F*128, F*128): its
  * all-zero rows still carry the constant feature 1 with residual 0, so add rows[g] - wtw[g][0] to entry (0,0). */
 int fri_hip_fit_width_sums(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, const float value_params[3][6], int64_t wtw[3][21],
                            double wtr[3][6], uint64_t rows[3]);
@@ -203,13 +211,30 @@ int fri_hip_fit_width_sums_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint3
 int fri_hip_fit_value_sums_batch_dev(fri_hip_plan *plan, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, int64_t *d_gram, void *stream);
 int fri_hip_fit_width_sums_batch_dev(fri_hip_plan *plan, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, const float *d_params, int64_t *d_wtw, double *d_wtr,
                                      void *stream);
-/* The 6 x 6 solves behind the fit (host, pure functions): x = pinv(M) y for a symmetric positive semi-definite M (cyclic Jacobi,
- * eigenvalues <= 1e-12 of the largest are dropped: the minimum-norm solution lstsq's SVD returns, up to rounding); from the sums to
- * the parameters of optimize_value_prediction (context_modeling.rs:175-202) and optimize_width_prediction (:144-173; rows[g] =
- * F * {256, 128, 128}, the reference's matrix heights). */
+/* The 6 x 6 solves behind the fit (host, pure functions): x = pinv(M) y for a symmetric positive semi-definite M - an LDL^T factorisation
+ * when every pivot stays above 1e-8 of the largest diagonal entry (any image with texture in the layer group), otherwise a cyclic Jacobi
+ * eigen-decomposition in which eigenvalues <= 1e-12 of the largest are dropped: the minimum-norm solution lstsq's SVD returns, up to
+ * rounding; from the sums to the parameters of optimize_value_prediction (context_modeling.rs:175-202) and optimize_width_prediction
+ * (:144-173; rows[g] = F * {256, 128, 128}, the reference's matrix heights). The device-side solves of fri_hip_fit_params_batch_dev and of
+ * the encode chain run the same source (csrc/solve6.hpp) and return the same bits for the same sums. */
 void fri_hip_solve6(const double m[6][6], const double y[6], double x[6]);
 void fri_hip_fit_value_params(const int64_t gram[3][28], float value_params[3][6]);
 void fri_hip_fit_width_params(const int64_t wtw[3][21], const double wtr[3][6], const uint64_t rows[3], float width_params[3][6]);
+
+/* The same solves on the device, for sums that are in device memory (the *_sums_batch_dev layouts): one thread per (plane, layer group) writes
+ * the value set (d_params[k][0][3][6]) resp. the width set (d_params[k][1][3][6], rows = F * {256, 128, 128} of this plan) of the DEVICE array
+ * float[n_planes][2][3][6]. Enqueued on `stream`, no synchronisation. */
+int fri_hip_fit_value_params_batch_dev(fri_hip_plan *plan, uint32_t n_planes, const int64_t *d_gram, float *d_params, void *stream);
+int fri_hip_fit_width_params_batch_dev(fri_hip_plan *plan, uint32_t n_planes, const int64_t *d_wtw, const double *d_wtr, float *d_params, void *stream);
+
+/* ContextModeler::optimize_parameters (context_modeling.rs:204-213, called at prediction.rs:232-235) for n_planes planes, entirely on the device
+ * and asynchronously: value sums -> 6 x 6 solves -> width sums (with the value parameters just found) -> 6 x 6 solves, four kernels and two tiny
+ * solve kernels on `stream`, no host round trip, no synchronisation. d_params = DEVICE float[n_planes][2][3][6] (value set, then width set, per
+ * plane - the array fri_hip_predict_histogram_batch_dev reads) is overwritten. d_fit_out_of_range (DEVICE u64[n_planes], may be NULL): per plane
+ * the number of waves that met a Some coefficient outside [-256, 255] (non-zero: that plane's parameters are not to be trusted; the forward
+ * transform never produces one). */
+int fri_hip_fit_params_batch_dev(fri_hip_plan *plan, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, float *d_params, uint64_t *d_fit_out_of_range,
+                                 void *stream);
 
 /* ---- the device part of FRIEncoder::encode in one call ---------------------------------------------- */
 /* Replaces the stage chain of FRIEncoder::encode (encoder.rs:19-48) up to EncoderStage::EntropyEncoding for one image, all channels:
@@ -218,12 +243,40 @@ void fri_hip_fit_width_params(const int64_t wtw[3][21], const double wtr[3][6], 
  * (:237-298) - with the coefficients staying in device memory between the stages, as the reference threads ONE WaveletImage through them.
  * fit != 0: the parameters are fitted and returned in value_params / width_params (float[channels][3][6] each); fit == 0: they are inputs.
  * Outputs: coefs [C][F][512], bucket / prediction [C][F][512] (may be NULL), hist [C][10][1024], n_out_of_alphabet [C].
- * The host form uploads the pixels once and downloads each output once. The device form enqueues on `stream` and, when fit != 0,
- * synchronises that stream twice (the sums come back to the host for the solves); without fit it returns without synchronising. */
+ * The host form uploads the pixels once and downloads each output once. The device form enqueues the whole chain on `stream` (the fit's
+ * 6 x 6 solves run on the device too) and returns without synchronising when fit == 0; with fit != 0 it returns once the fitted parameters have
+ * arrived in value_params / width_params - the scan kernel is queued behind them and still running. One thread / one stream per plan at a time
+ * for the fit forms (the parameters travel through plan-owned buffers). FRI_HIP_ERR_OUT_OF_RANGE from the host forms: see the fit entry points;
+ * the device form reports a plane whose coefficients the scan kernel could not represent although the forward kernel wrote them (cannot
+ * happen for quantisers of magnitude >= 1) as n_out_of_alphabet == UINT64_MAX. */
 int fri_hip_encode_image(fri_hip_plan *plan, const uint8_t *pixels, const int32_t qmatrix[32], int fit, float *value_params, float *width_params, int32_t *coefs,
                          uint8_t *bucket, int32_t *prediction, uint32_t *hist, uint64_t *n_out_of_alphabet);
 int fri_hip_encode_image_dev(fri_hip_plan *plan, const uint8_t *d_pixels, const int32_t qmatrix[32], int fit, float *value_params, float *width_params, int32_t *d_coefs,
                              uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist, uint64_t *d_n_out_of_alphabet, void *stream);
+
+/* The same for n_images images with everything - parameters included - in DEVICE memory: K1 over all images, then (fit != 0) the device-side fit of
+ * fri_hip_fit_params_batch_dev over all n_images * channels planes, then K2 over all planes; no host round trip and no synchronisation anywhere
+ * (the call only enqueues; after a first call of the same batch size - the plan's scratch grows on demand - the sequence is HIP-graph capturable).
+ * Image k: pixels at d_pixels + k * pixel_stride (bytes), coefficients at d_coefs + k * coef_stride (int32 elements, [C][F][512] inside), bucket /
+ * prediction at + k * out_stride (elements; either may be NULL), d_hist[k][C][10][1024], d_n_out_of_alphabet[k][C], d_params[k][C][2][3][6]
+ * (in when fit == 0, out when fit != 0), d_fit_out_of_range[k][C] (may be NULL). With channels == 3 and n_images > 1 the images must lie back to
+ * back (coef_stride == 3 * F * 512 == out_stride): the planes of the batch are then evenly spaced and every stage is one launch.
+ * Replaces the per-image loop around FRIEncoder::encode (crates/fri-cli/src/commands/bench.rs:15-120; BASELINE config 3). */
+int fri_hip_encode_image_batch_dev(fri_hip_plan *plan, uint32_t n_images, const uint8_t *d_pixels, size_t pixel_stride, const int32_t qmatrix[32], int fit, float *d_params,
+                                   int32_t *d_coefs, size_t coef_stride, uint8_t *d_bucket, int32_t *d_prediction, size_t out_stride, uint32_t *d_hist,
+                                   uint64_t *d_n_out_of_alphabet, uint64_t *d_fit_out_of_range, void *stream);
+
+/* The reference's per-image loop itself (crates/fri-cli/src/commands/bench.rs:15-120: FRIEncoder::encode per image, encoder.rs:87-109) for images in
+ * HOST memory: every image runs the asynchronous chain above on one of three internal streams with pinned staging, so uploads, kernels and
+ * downloads of consecutive images overlap. Per image i: params[i] = float[C][2][3][6] (value set then width set per channel: in when fit == 0,
+ * out when fit != 0), coefs[i] [C][F][512], bucket[i] / prediction[i] [C][F][512] (the arrays or single entries may be NULL), hist[i] [C][10][1024],
+ * n_out_of_alphabet[i] [C]. Returns the first error; FRI_HIP_ERR_OUT_OF_RANGE as in fri_hip_encode_image.
+ * fri_hip_multi_encode_image: the same over the GPUs of a fri_hip_multi, image i on devices[i mod n_devices] (fri_hip_shard_*), one host thread per
+ * device, no data between devices - BASELINE config 4 for the whole encoder rather than its first stage. */
+int fri_hip_encode_image_batch(fri_hip_plan *plan, uint32_t n_images, const uint8_t *const *pixels, const int32_t qmatrix[32], int fit, float *const *params,
+                               int32_t *const *coefs, uint8_t *const *bucket, int32_t *const *prediction, uint32_t *const *hist, uint64_t *const *n_out_of_alphabet);
+int fri_hip_multi_encode_image(fri_hip_multi *m, uint32_t n_images, const uint8_t *const *pixels, const int32_t qmatrix[32], int fit, float *const *params,
+                               int32_t *const *coefs, uint8_t *const *bucket, int32_t *const *prediction, uint32_t *const *hist, uint64_t *const *n_out_of_alphabet);
 
 /* prediction::encode alone (stages/prediction.rs:224-323 minus the host's ANS models) for all channels of an image whose coefficients
  * already exist: one upload of the coefficients (host form), optional fit, the scan of every channel in one launch. Same argument

@@ -177,6 +177,74 @@ def test_config3_batched_chain_over_1080p_frames(ctx, oracle):
     P.inverse_transform_batch_dev(n, d_co.data_ptr(), plane, d_back.data_ptr(), P.pixel_bytes, stream=s)
     torch.cuda.synchronize()
     assert torch.equal(d_back, d_px)
+    # The same batch as ONE asynchronous call (fri_hip_encode_image_batch_dev: K1 -> value sums -> device solves -> width sums -> device solves ->
+    # K2, nothing but enqueues): coefficients and value parameters are the stage-by-stage ones bit for bit (exact integer sums, one solver source),
+    # the width parameters agree to the rounding of their f64 sums, and sampled frames are the oracle's predictor run with the batch's own parameters.
+    d_co2 = torch.empty_like(d_co)
+    d_par2 = torch.zeros((n, 2, 3, 6), dtype=torch.float32, device="cuda")
+    d_b2, d_p2, d_h2, d_o2 = torch.empty_like(d_b), torch.empty_like(d_p), torch.empty_like(d_h), torch.empty_like(d_o)
+    d_rng = torch.ones(n, dtype=torch.int64, device="cuda")
+    P.encode_image_batch_dev(n, d_px.data_ptr(), P.pixel_bytes, d_par2.data_ptr(), d_co2.data_ptr(), plane, d_b2.data_ptr(), d_p2.data_ptr(), plane, d_h2.data_ptr(),
+                             d_o2.data_ptr(), fit=True, d_fit_out_of_range=d_rng.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    par2 = d_par2.cpu().numpy()
+    assert torch.equal(d_co2, d_co) and int(d_rng.abs().sum()) == 0
+    assert np.array_equal(par2[:, 0].view(np.uint32), params[:, 0].view(np.uint32))
+    assert np.allclose(par2[:, 1], params[:, 1], rtol=1e-4, atol=1e-6)
+    assert bool((d_h2.sum(dim=(1, 2)) + d_o2 == P.num_some).all())
+    for k in (3, 200):
+        W = oracle.Wavelet(d_px[k].cpu().numpy(), h, w, c)
+        W.quantize(ONES)
+        wb, wpred, whist, woob = W.predict(0, par2[k, 0], par2[k, 1])
+        assert np.array_equal(d_b2[k].cpu().numpy().reshape(F, 512), wb) and np.array_equal(d_p2[k].cpu().numpy().reshape(F, 512), wpred)
+        assert np.array_equal(d_h2[k].cpu().numpy().astype(np.uint32), whist) and int(d_o2[k]) == woob
+        W.close()
+    # parameters given (fit = 0): the batch call is K1 + the batched scan
+    P.encode_image_batch_dev(n, d_px.data_ptr(), P.pixel_bytes, d_params.data_ptr(), d_co2.data_ptr(), plane, d_b2.data_ptr(), d_p2.data_ptr(), plane, d_h2.data_ptr(),
+                             d_o2.data_ptr(), fit=False, stream=s)
+    torch.cuda.synchronize()
+    assert torch.equal(d_b2, d_b) and torch.equal(d_p2, d_p) and torch.equal(d_h2, d_h) and torch.equal(d_o2, d_o)
+    P.close()
+
+
+def test_encode_image_batch_dev_rgb_images_back_to_back(ctx, oracle):
+    """Three RGB images in one asynchronous chain (nine planes, evenly spaced because the images lie back to back); a layout that is not
+    evenly spaced is refused."""
+    import torch
+
+    import frave_amd as fa
+
+    w, h, c, n = 640, 360, 3, 3
+    P = fa.Plan(ctx, w, h, c)
+    F, plane = P.num_cells, P.num_cells * 512
+    imgs = [mixed_image(w, h, c, 40 + k) for k in range(n)]
+    d_px = torch.from_numpy(np.stack([im.reshape(-1) for im in imgs])).cuda()
+    d_co = torch.empty((n, c, plane), dtype=torch.int32, device="cuda")
+    d_par = torch.zeros((n, c, 2, 3, 6), dtype=torch.float32, device="cuda")
+    d_b = torch.empty((n, c, plane), dtype=torch.uint8, device="cuda")
+    d_p = torch.empty((n, c, plane), dtype=torch.int32, device="cuda")
+    d_h = torch.empty((n, c, 10, 1024), dtype=torch.int32, device="cuda")
+    d_o = torch.empty((n, c), dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    P.encode_image_batch_dev(n, d_px.data_ptr(), P.pixel_bytes, d_par.data_ptr(), d_co.data_ptr(), c * plane, d_b.data_ptr(), d_p.data_ptr(), c * plane, d_h.data_ptr(),
+                             d_o.data_ptr(), fit=True, stream=s)
+    torch.cuda.synchronize()
+    par = d_par.cpu().numpy()
+    for k in range(n):
+        co1, vp1, wp1, b1, p1, hist1, oob1 = P.encode_image(imgs[k], fit=True)  # the one-image call
+        assert np.array_equal(d_co[k].cpu().numpy().reshape(c, F, 512), co1)
+        assert np.array_equal(par[k, :, 0].view(np.uint32), vp1.view(np.uint32)) and np.allclose(par[k, :, 1], wp1, rtol=1e-4, atol=1e-6)
+        W = oracle.Wavelet(imgs[k], h, w, c)
+        W.quantize(ONES)
+        for ch in range(c):
+            wb, wpred, whist, woob = W.predict(ch, par[k, ch, 0], par[k, ch, 1])
+            assert np.array_equal(d_b[k, ch].cpu().numpy().reshape(F, 512), wb) and np.array_equal(d_p[k, ch].cpu().numpy().reshape(F, 512), wpred)
+            assert np.array_equal(d_h[k, ch].cpu().numpy().astype(np.uint32), whist) and int(d_o[k, ch]) == woob
+        W.close()
+    with pytest.raises(fa.FriHipError) as e:
+        P.encode_image_batch_dev(n, d_px.data_ptr(), P.pixel_bytes, d_par.data_ptr(), d_co.data_ptr(), c * plane + 512, d_b.data_ptr(), d_p.data_ptr(), c * plane, d_h.data_ptr(),
+                                 d_o.data_ptr(), fit=True, stream=s)
+    assert e.value.code == -1
     P.close()
 
 

@@ -139,3 +139,79 @@ def test_fit_reports_coefficients_outside_its_range(ctx, oracle):
         P.predict_image(bad, fit=True)
     assert e.value.code == -7
     assert np.array_equal(P.fit_value_sums(co, 0), good)  # and the accumulators were left clean
+
+
+def test_device_solves_return_the_bits_of_the_host_solves(ctx):
+    """The 6 x 6 solves of the asynchronous chain run on the device (fit_solve_kernel) from the source the host functions are built from
+    (csrc/solve6.hpp): for the same sums the same parameters, bit for bit - on the LDL^T route (textured data), on the eigen-decomposition
+    route (rank-deficient and nearly dependent systems) and for all-zero sums."""
+    import torch
+
+    import frave_amd as fa
+
+    P = fa.Plan(ctx, 300, 200, 1)
+    rng = np.random.default_rng(11)
+    iu7, iu6 = np.triu_indices(7), np.triu_indices(6)
+    kinds = ["full", "full", "dependent", "zero column", "nearly dependent", "all zero", "full", "tiny"]
+    n = 3 * len(kinds)
+    gram, wtw, wtr = np.zeros((n, 3, 28), np.int64), np.zeros((n, 3, 21), np.int64), np.zeros((n, 3, 6), np.float64)
+    for k in range(n):
+        for g in range(3):
+            kind = kinds[(k + g) % len(kinds)]
+            rows = 4 if kind == "tiny" else int(rng.integers(50, 4000))
+            a = rng.integers(-255, 256, (rows, 7)).astype(np.int64)
+            if kind == "dependent":
+                a[:, 3] = 2 * a[:, 2] // 2
+                a[:, 2] = a[:, 3]
+            elif kind == "zero column":
+                a[:, 1] = 0
+            elif kind == "nearly dependent":
+                a[:, 4] = a[:, 0] + (rng.random(rows) < 0.001)
+            elif kind == "all zero":
+                a[:] = 0
+            gram[k, g] = (a.T @ a)[iu7]
+            w = np.abs(a[:, :6])
+            w[:, 0] = 0 if kind == "all zero" else 1
+            r = np.abs(rng.standard_normal(rows)) * (0 if kind == "all zero" else 7.5)
+            wtw[k, g] = (w.T @ w)[iu6]
+            wtr[k, g] = (w.astype(np.float64) * r[:, None]).sum(0)
+    d_params = torch.zeros((n, 2, 3, 6), dtype=torch.float32, device="cuda")
+    d_gram, d_wtw, d_wtr = torch.from_numpy(gram).cuda(), torch.from_numpy(wtw).cuda(), torch.from_numpy(wtr).cuda()
+    P.fit_value_params_batch_dev(n, d_gram.data_ptr(), d_params.data_ptr())
+    P.fit_width_params_batch_dev(n, d_wtw.data_ptr(), d_wtr.data_ptr(), d_params.data_ptr())
+    torch.cuda.synchronize()
+    got = d_params.cpu().numpy()
+    rows = np.array([P.num_cells * 256, P.num_cells * 128, P.num_cells * 128], np.uint64)
+    for k in range(n):
+        assert np.array_equal(got[k, 0].view(np.uint32), fa.fit_value_params(gram[k]).view(np.uint32)), k
+        assert np.array_equal(got[k, 1].view(np.uint32), fa.fit_width_params(wtw[k], wtr[k], rows).view(np.uint32)), k
+    P.close()
+
+
+def test_fit_at_4096_against_the_oracle(ctx, oracle):
+    """BASELINE config 2's size: the fit sums of a 4096 x 4096 plane against sums built with numpy from the oracle's get_neighbour_values
+    (17 M rows), then the whole chain with the fit (fri_hip_encode_image: K1 -> sums -> device solves -> sums -> device solves -> K2): the
+    value parameters are the host solve of the oracle's exact sums bit for bit, the width parameters agree to rounding, and the scan's outputs
+    are the oracle's predictor run with the chain's parameters."""
+    import frave_amd as fa
+
+    w = h = 4096
+    img = gen_image("noise", w, h, 1, 33)
+    img[:, : w // 2] = gen_image("smooth", w // 2, h, 1, 34)
+    P = fa.Plan(ctx, w, h, 1)
+    W = oracle.Wavelet(img, h, w, 1)
+    co, vp, wp, b, p, hist, oob = P.encode_image(img, fit=True)
+    assert np.array_equal(co, W.coefficients())
+    iu7, iu6 = np.triu_indices(7), np.triu_indices(6)
+    want_gram, want_wtw, want_wtr = _cpu_sums(oracle, W, 0, vp[0])
+    assert np.array_equal(P.fit_value_sums(co, 0), want_gram)
+    assert np.array_equal(vp[0].view(np.uint32), fa.fit_value_params(np.stack([want_gram[g][iu7] for g in range(3)])).view(np.uint32))
+    wtw, wtr, rows = P.fit_width_sums(co, 0, vp[0])
+    assert np.array_equal(wtw, want_wtw)
+    assert np.allclose(wtr, want_wtr, rtol=1e-6, atol=1e-3)
+    assert np.allclose(wp[0], fa.fit_width_params(np.stack([want_wtw[g][iu6] for g in range(3)]), want_wtr, rows), rtol=1e-4, atol=1e-6)
+    W.quantize(np.ones(32, np.int32))
+    wb, wpred, whist, woob = W.predict(0, vp[0], wp[0])
+    assert np.array_equal(b[0], wb) and np.array_equal(p[0], wpred) and np.array_equal(hist[0], whist) and int(oob[0]) == woob
+    W.close()
+    P.close()

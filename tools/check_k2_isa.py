@@ -3,22 +3,31 @@
 
 The gathers are inline-asm ds_read_u16_d16_hi whose completion the compiler does not track: a block issues the NEXT node's six
 gathers and waits (lgkmcnt(6)) for the current node's. Between the block that issues a register's load and the block that waits for
-it, no instruction may read or write that register - a register copy there would carry stale data on. This script compiles the
-kernel file to assembly and scans the product kernel linearly: registers in flight, any mention of them outside an asm block is an
-error (a compiler-inserted `s_waitcnt lgkmcnt(0)` lands everything and is fine).
+it, no instruction may read or write that register - a register copy there would carry stale data on. This script scans the
+product kernel's assembly linearly: registers in flight, any mention of them outside an asm block is an error (a compiler-inserted
+`s_waitcnt lgkmcnt(0)` lands everything and is fine).
 
-    python tools/check_k2_isa.py          # exit code 0 = clean
+The assembly is produced by frave_amd/csrc/Makefile with the very flags the object file is built with (FLAGS + EXTRA_k2_predict);
+the Makefile runs this scan before it links libfri_hip.so, and tests/test_k2_isa.py runs it in the CPU suite.
+
+    python tools/check_k2_isa.py                 # make the assembly (csrc/build/k2_predict.s), then scan it; exit code 0 = clean
+    python tools/check_k2_isa.py <file.s>        # scan an existing assembly file
 """
 import os
 import re
 import subprocess
 import sys
-import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "frave_amd", "csrc", "k2_predict.hip")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"),
-         "-I" + os.path.join(ROOT, "frave_amd", "csrc"), "-S", "--cuda-device-only", "-x", "hip"]
+CSRC = os.path.join(ROOT, "frave_amd", "csrc")
+KERNEL = "predict_histogram_kernel3"
+
+
+def make_assembly():
+    """csrc/build/k2_predict.s through the Makefile (same compiler, same flags as the object that is linked)."""
+    asm = os.path.join(CSRC, "build", "k2_predict.s")
+    subprocess.run(["make", "-s", "-C", CSRC, asm], check=True)
+    return asm
 
 
 def regs_of(text):
@@ -31,13 +40,19 @@ def regs_of(text):
     return out
 
 
-def main():
-    with tempfile.TemporaryDirectory() as tmp:
-        asm = os.path.join(tmp, "k2.s")
-        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + [SRC, "-o", asm], check=True, stderr=subprocess.DEVNULL)
-        lines = open(asm).read().splitlines()
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN.*predict_histogram_kernel3", l))
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
+def scan(asm):
+    """(number of gather blocks seen, list of problems) for the product kernel in assembly file `asm`."""
+    lines = open(asm).read().splitlines()
+    blocks, errors = 0, []
+    for start in [i for i, l in enumerate(lines) if re.match(r"^_ZN.*" + KERNEL + r".*:", l)]:  # every instantiation of the kernel template
+        end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
+        b, e = scan_function(lines, start, end)
+        blocks += b
+        errors += e
+    return blocks, errors
+
+
+def scan_function(lines, start, end):
     in_flight, errors, blocks, i = set(), [], 0, start
     while i < end:
         line = lines[i].split(";")[0].strip()
@@ -70,9 +85,18 @@ def main():
                 if hit:
                     errors.append(f"line {i + 1}: `{line}` touches v{sorted(hit)} while its gather is in flight")
         i += 1
+    return blocks, errors
+
+
+def main():
+    asm = sys.argv[1] if len(sys.argv) > 1 else make_assembly()
+    blocks, errors = scan(asm)
     print(f"{blocks} gather blocks checked, {len(errors)} problem(s)")
     for e in errors[:20]:
         print("  " + e)
+    if blocks == 0:
+        print("  no gather block found: the scan no longer matches the kernel")
+        return 1
     return 1 if errors else 0
 
 
