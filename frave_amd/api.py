@@ -27,6 +27,7 @@ SYMBOLS = [
     "fri_hip_encode_image_dev", "fri_hip_inverse_transform_batch_dev", "fri_hip_predict_image", "fri_hip_predict_image_dev",
     "fri_hip_fit_params_batch_dev", "fri_hip_encode_image_batch_dev", "fri_hip_fit_value_params_batch_dev", "fri_hip_fit_width_params_batch_dev",
     "fri_hip_plan_assume_forward_coefficients", "fri_hip_encode_image_batch", "fri_hip_multi_encode_image",
+    "fri_hip_plan_set_stream_order", "fri_hip_symbol_stream_batch_dev", "fri_hip_encode_image_symbols",
 ]
 
 
@@ -140,6 +141,9 @@ def load_library():
     L.fri_hip_predict_image_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.fri_hip_fit_params_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp, vp]
     L.fri_hip_plan_assume_forward_coefficients.argtypes = [vp, i32]
+    L.fri_hip_plan_set_stream_order.argtypes = [vp, vp, C.c_uint64]
+    L.fri_hip_symbol_stream_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, vp, sz, vp]
+    L.fri_hip_encode_image_symbols.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.fri_hip_encode_image_batch.argtypes = [vp, u32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.fri_hip_multi_encode_image.argtypes = [vp, u32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.fri_hip_fit_value_params_batch_dev.argtypes = [vp, u32, vp, vp, vp]
@@ -327,6 +331,20 @@ class Plan:
         except Exception:
             pass
 
+    def set_stream_order(self, order=None):
+        """fri_hip_plan_set_stream_order; order = None builds it with the host emitter library (frave_amd.emit.stream_order). Returns the order."""
+        if order is None:
+            from . import emit
+
+            order = emit.stream_order(self.centers(), self.valid_mask())
+        order = np.ascontiguousarray(order, np.uint32)
+        _check(load_library().fri_hip_plan_set_stream_order(self._h, _p(order), order.size), "fri_hip_plan_set_stream_order", self.ctx)
+        return order
+
+    def symbol_stream_batch_dev(self, n_planes, d_coefs, coef_stride, d_bucket, d_prediction, out_stride, d_symbols, symbol_stride, stream=0):
+        _check(load_library().fri_hip_symbol_stream_batch_dev(self._h, n_planes, d_coefs, coef_stride, d_bucket, d_prediction, out_stride, d_symbols, symbol_stride, stream),
+               "fri_hip_symbol_stream_batch_dev", self.ctx)
+
     def assume_forward_coefficients(self, on=True):
         """fri_hip_plan_assume_forward_coefficients: the predict entry points then skip the exact-kernel guard launch."""
         _check(load_library().fri_hip_plan_assume_forward_coefficients(self._h, 1 if on else 0), "fri_hip_plan_assume_forward_coefficients")
@@ -482,6 +500,20 @@ class Plan:
         _check(load_library().fri_hip_encode_image(self._h, _p(px), _p(q), 1 if fit else 0, _p(vp), _p(wp), _p(coefs), _p(bucket) if want_bucket else None,
                                                    _p(pred) if want_prediction else None, _p(hist), _p(oob)), "fri_hip_encode_image", self.ctx)
         return coefs, vp, wp, bucket, pred, hist, oob
+
+    def encode_image_symbols(self, pixels, qmatrix=None, fit=True, value_params=None, width_params=None):
+        """fri_hip_encode_image_symbols: (symbols uint16 [C][num_some], value_params, width_params, hist [C][10][1024], oob [C]); needs set_stream_order()."""
+        px = np.ascontiguousarray(pixels, np.uint8).reshape(-1)
+        assert px.size == self.pixel_bytes
+        c = self.channels
+        vp = np.zeros((c, 3, 6), np.float32) if value_params is None else np.ascontiguousarray(value_params, np.float32).reshape(c, 3, 6).copy()
+        wp = np.zeros((c, 3, 6), np.float32) if width_params is None else np.ascontiguousarray(width_params, np.float32).reshape(c, 3, 6).copy()
+        sym = np.empty((c, self.num_some), np.uint16)
+        hist = np.empty((c, 10, 1024), np.uint32)
+        oob = np.zeros(c, np.uint64)
+        q = _q(qmatrix)
+        _check(load_library().fri_hip_encode_image_symbols(self._h, _p(px), _p(q), 1 if fit else 0, _p(vp), _p(wp), _p(sym), _p(hist), _p(oob)), "fri_hip_encode_image_symbols", self.ctx)
+        return sym, vp, wp, hist, oob
 
     def predict_image(self, coefs, fit=True, value_params=None, width_params=None):
         """fri_hip_predict_image: (value_params, width_params, bucket [C][F][512], prediction, hist [C][10][1024], oob [C])."""

@@ -94,6 +94,17 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Hand-over through device-scope atomics (K2's histogram, K4's sums): a workgroup adds its partial results into a plan accumulator and then
+// draws a ticket; the workgroup whose ticket is the last one reads the totals. That is only correct if every add of a workgroup has been
+// PERFORMED before its ticket is drawn, i.e. if every wave has waited for its own vector-memory counter before the barrier in front of the
+// ticket. __syncthreads() does NOT do that: for relaxed atomics hipcc emits a bare s_barrier (rounds 1 and 2 relied on a wait that was never
+// there, and lost counts whenever the last workgroup's copy-out overtook another workgroup's adds - seen once many workgroups finish together).
+// The wait is inline asm so that no compiler pass can drop it.
+__device__ __forceinline__ void wait_for_own_memory_ops_then_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // wrapping integer arithmetic like a release build of the reference
 __device__ __forceinline__ int iabs_w(int a) { return a < 0 ? (int)(0u - (unsigned)a) : a; }
 __device__ __forceinline__ int sub_w(int a, int b) { return (int)((unsigned)a - (unsigned)b); }

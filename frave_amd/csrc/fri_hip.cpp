@@ -91,9 +91,12 @@ struct fri_hip_plan {
     unsigned long long *d_oob_all = nullptr;  // [C]
     // host-facing fit (fri_hip_encode_image_dev / fri_hip_predict_image_dev with fit != 0): the fitted parameters and the range counts come
     // back through pinned memory behind an event, while the scan kernel that follows them is already queued
-    void *h_fit = nullptr;     // pinned: [3] PredictParams + [3] u64
+    void *h_fit = nullptr;     // pinned + mapped: [3] PredictParams + [3] u64
+    void *d_h_fit = nullptr;   // the device's address of h_fit
     hipEvent_t ev_fit = nullptr;
     bool assume_forward = false; // fri_hip_plan_assume_forward_coefficients
+    uint32_t *d_stream_order = nullptr; // fri_hip_plan_set_stream_order: node index of the i-th symbol of a channel, [geo.n_some]
+    uint16_t *d_symbols = nullptr;      // fri_hip_encode_image_symbols: [C][geo.n_some]
     uint32_t acc_next = 0;
     bool acc_dirty = false; // a launch on this plan failed: the accumulators are re-zeroed before the next use
     hipEvent_t ev_begin = nullptr, ev_end = nullptr; // timing helper's events, created with the plan (creating an event is not work to be timed)
@@ -184,6 +187,7 @@ int acquire_acc(fri_hip_plan *p, hipStream_t stream, uint32_t n_planes = 1) {
             if (a.pred_acc) HIP_TRY(c, hipMemset(a.pred_acc, 0, (size_t)a.planes * kPredAccWords * sizeof(uint32_t)));
             if (a.fit_acc) HIP_TRY(c, hipMemset(a.fit_acc, 0, (size_t)a.planes * kFitAccWords * sizeof(unsigned long long)));
         }
+        HIP_TRY(c, hipDeviceSynchronize()); // (the memsets ran on the null stream: done before any stream launches on the accumulators again)
         p->acc_dirty = false;
     }
     int idx = -1;
@@ -223,8 +227,10 @@ int acquire_acc(fri_hip_plan *p, hipStream_t stream, uint32_t n_planes = 1) {
         if (e == hipSuccess) e = hipMalloc(&sd, (size_t)planes * 18 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc(&rg, (size_t)planes * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMalloc(&pr, (size_t)planes * sizeof(PredictParams));
-        if (e == hipSuccess) e = hipMemset(pa, 0, pb);
-        if (e == hipSuccess) e = hipMemset(fa, 0, fb);
+        // zeroed ON THE LAUNCHING STREAM: a hipMemset on the null stream is not ordered against a non-blocking stream, and a memset that lands while
+        // the first kernel is adding into the accumulator wipes its partial sums (seen with twelve torch streams: an all-zero Gram matrix)
+        if (e == hipSuccess) e = hipMemsetAsync(pa, 0, pb, stream);
+        if (e == hipSuccess) e = hipMemsetAsync(fa, 0, fb, stream);
         if (e != hipSuccess) {
             for (void *d : {pa, fa, si, sd, rg, pr})
                 if (d) (void)hipFree(d);
@@ -551,6 +557,8 @@ int fri_hip_plan_destroy(fri_hip_plan *p) {
         for (void *d : p->retired_acc) (void)hipFree(d);
         for (void *d : {(void *)p->d_bucket_all, (void *)p->d_prediction_all, (void *)p->d_hist_all, (void *)p->d_oob_all})
             if (d) (void)hipFree(d);
+        if (p->d_stream_order) (void)hipFree(p->d_stream_order);
+        if (p->d_symbols) (void)hipFree(p->d_symbols);
         if (p->h_fit) (void)hipHostFree(p->h_fit);
         if (p->ev_fit) (void)hipEventDestroy(p->ev_fit);
         if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
@@ -937,7 +945,7 @@ static int ensure_encode_staging(fri_hip_plan *p) {
 // without a word to the host: value sums -> 6 x 6 solves -> width sums (with the value parameters just written) -> solves. The parameters land
 // in the device array b.params (PredictParams per plane), where the scan kernel reads them. d_range (may be NULL) receives, per plane, the
 // number of waves that staged a Some coefficient outside [-256, 255] (the sums are then not to be trusted).
-static int fit_chain(fri_hip_plan *p, const PredBatch &b, unsigned long long *d_range, hipStream_t s) {
+static int fit_chain(fri_hip_plan *p, const PredBatch &b, unsigned long long *d_range, hipStream_t s, float *host_params = nullptr, unsigned long long *host_range = nullptr) {
     if (!b.params) return FRI_HIP_ERR_INVALID_ARGUMENT;
     const int slot = acquire_acc(p, s, b.n_planes); // the stream's accumulators and fit scratch (the launches below find the same slot)
     if (slot < 0) return slot;
@@ -945,10 +953,11 @@ static int fit_chain(fri_hip_plan *p, const PredBatch &b, unsigned long long *d_
     float *params = const_cast<float *>(reinterpret_cast<const float *>(b.params));
     const uint64_t F = p->geo.centers.size();
     const unsigned long long rows[3] = {F * 256, F * 128, F * 128}; // num_ctx_last_layer / num_ctx_middle_layer, context_modeling.rs:84-85
-    if (int rc = fit_launch(p, 0, b, (int64_t *)k.sums_int, nullptr, d_range ? d_range : k.range, s)) return rc;
-    HIP_TRY(p->ctx, launch_fit_solve(0, b.n_planes, k.sums_int, nullptr, nullptr, params, s));
+    unsigned long long *range = d_range ? d_range : k.range;
+    if (int rc = fit_launch(p, 0, b, (int64_t *)k.sums_int, nullptr, range, s)) return rc;
+    HIP_TRY(p->ctx, launch_fit_solve(0, b.n_planes, k.sums_int, nullptr, nullptr, params, s, host_params, range, host_range));
     if (int rc = fit_launch(p, 1, b, (int64_t *)k.sums_int, k.sums_dbl, nullptr, s)) return rc;
-    HIP_TRY(p->ctx, launch_fit_solve(1, b.n_planes, k.sums_int, k.sums_dbl, rows, params, s));
+    HIP_TRY(p->ctx, launch_fit_solve(1, b.n_planes, k.sums_int, k.sums_dbl, rows, params, s, host_params));
     return FRI_HIP_OK;
 }
 
@@ -977,20 +986,29 @@ static int predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, f
     if (slot < 0) return slot;
     auto &k = p->acc_slots[slot];
     constexpr size_t kFitBytes = 3 * sizeof(PredictParams) + 3 * sizeof(unsigned long long);
-    if (!p->h_fit) {
-        HIP_TRY(c, hipHostMalloc(&p->h_fit, kFitBytes, hipHostMallocDefault));
+    if (!p->h_fit) { // mapped and fine-grained: the solve kernels write the parameters straight into it
+        HIP_TRY(c, hipHostMalloc(&p->h_fit, kFitBytes, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(p->h_fit, 0, kFitBytes);
+        HIP_TRY(c, hipHostGetDevicePointer(&p->d_h_fit, p->h_fit, 0));
     }
     if (!p->ev_fit) HIP_TRY(c, hipEventCreateWithFlags(&p->ev_fit, hipEventDisableTiming));
     b.params = reinterpret_cast<const PredictParams *>(k.params);
-    if (int rc = fit_chain(p, b, k.range, s)) return rc;
-    char *const h = static_cast<char *>(p->h_fit);
-    HIP_TRY(c, hipMemcpyAsync(h, k.params, (size_t)C * sizeof(PredictParams), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(h + 3 * sizeof(PredictParams), k.range, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    char *const h = static_cast<char *>(p->h_fit), *const dh = static_cast<char *>(p->d_h_fit);
+    if (int rc = fit_chain(p, b, k.range, s, reinterpret_cast<float *>(dh), reinterpret_cast<unsigned long long *>(dh + 3 * sizeof(PredictParams)))) return rc;
     HIP_TRY(c, hipEventRecord(p->ev_fit, s));
-    // the scan is queued before the host looks at the fit: it runs while the parameters travel
+    // the scan is queued before the host looks at the fit: it runs while the host picks the parameters up
     const int rc_scan = predict_launch(p, b, d_bucket, d_prediction, d_hist, d_oob, trust, s);
-    HIP_TRY(c, hipEventSynchronize(p->ev_fit));
+    // poll: a sleeping wait (hipEventSynchronize) wakes up 15-20 us late, a tenth of the chain
+    for (uint64_t spins = 0;; spins++) {
+        const hipError_t q = hipEventQuery(p->ev_fit);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIP_TRY(c, q);
+        if (spins > (1ull << 22)) {
+            HIP_TRY(c, hipEventSynchronize(p->ev_fit));
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     const unsigned long long *h_range = reinterpret_cast<const unsigned long long *>(h + 3 * sizeof(PredictParams));
     const PredictParams *h_params = reinterpret_cast<const PredictParams *>(h);
     for (uint32_t ch = 0; ch < C; ch++) {
@@ -1210,6 +1228,63 @@ int fri_hip_multi_encode_image(fri_hip_multi *m, uint32_t n_images, const uint8_
     for (auto &t : threads) t.join();
     for (int rc : rcs)
         if (rc != FRI_HIP_OK) return rc;
+    return FRI_HIP_OK;
+}
+
+/* ---- the ordered symbol stream (K5) ------------------------------------------------------------------------- */
+int fri_hip_plan_set_stream_order(fri_hip_plan *p, const uint32_t *order, uint64_t n) {
+    if (int rc = need_device(p)) return rc;
+    if (!order || n != p->geo.n_some) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    const size_t F = p->geo.centers.size();
+    // a permutation of the Some nodes: every entry a Some node, every Some node once (the kernel indexes the planes with it)
+    std::vector<uint8_t> seen(F * kCell, 0);
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t e = order[i], cell = e >> 9, heap = e & 511u;
+        if (cell >= F || !((p->geo.valid_mask[(size_t)cell * 16 + (heap >> 5)] >> (heap & 31)) & 1u) || seen[e]) return FRI_HIP_ERR_INVALID_ARGUMENT;
+        seen[e] = 1;
+    }
+    fri_hip_ctx *c = p->ctx;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!p->d_stream_order) HIP_TRY(c, hipMalloc((void **)&p->d_stream_order, (n ? n : 1) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpy(p->d_stream_order, order, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return FRI_HIP_OK;
+}
+
+int fri_hip_symbol_stream_batch_dev(fri_hip_plan *p, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, const uint8_t *d_bucket, const int32_t *d_prediction,
+                                    size_t out_stride, uint16_t *d_symbols, size_t symbol_stride, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    if (!p->d_stream_order) return FRI_HIP_ERR_INVALID_ARGUMENT; // fri_hip_plan_set_stream_order first
+    const size_t plane = p->geo.centers.size() * kCell;
+    if (!d_coefs || !d_bucket || !d_prediction || !d_symbols || !n_planes || n_planes > 65535u) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    if (n_planes > 1 && (coef_stride < plane || out_stride < plane || symbol_stride < p->geo.n_some)) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    HIP_TRY(p->ctx, launch_symbol_stream(p->d_stream_order, p->geo.n_some, n_planes, d_coefs, coef_stride, d_bucket, d_prediction, out_stride, d_symbols, symbol_stride,
+                                         (hipStream_t)stream));
+    return FRI_HIP_OK;
+}
+
+// The device part of FRIEncoder::encode_bytes for host buffers: pixels up (1 B per pixel and channel), the whole chain and the symbol stream kernel on
+// the device, and down come 2 bytes per symbol, the histograms and the parameters - the arrays of coefficients, predictions and buckets never leave.
+int fri_hip_encode_image_symbols(fri_hip_plan *p, const uint8_t *pixels, const int32_t qmatrix[32], int fit, float *value_params, float *width_params, uint16_t *symbols,
+                                 uint32_t *hist, uint64_t *n_out_of_alphabet) {
+    if (int rc = need_device(p)) return rc;
+    if (!pixels || !value_params || !width_params || !symbols || !hist || !n_out_of_alphabet || !p->d_stream_order) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    fri_hip_ctx *c = p->ctx;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = ensure_staging(p)) return rc;
+    if (int rc = ensure_encode_staging(p)) return rc;
+    const size_t C = p->geo.channels, plane = p->geo.centers.size() * kCell, n = p->geo.n_some;
+    if (!p->d_symbols) HIP_TRY(c, hipMalloc((void **)&p->d_symbols, (C * n ? C * n : 1) * sizeof(uint16_t)));
+    HIP_TRY(c, hipMemcpy(p->d_pixels, pixels, fri_hip_plan_pixel_bytes(p), hipMemcpyHostToDevice));
+    if (int rc = fri_hip_encode_image_dev(p, p->d_pixels, qmatrix, fit, value_params, width_params, p->d_coefs, p->d_bucket_all, p->d_prediction_all, p->d_hist_all,
+                                          (uint64_t *)p->d_oob_all, nullptr))
+        return rc;
+    HIP_TRY(c, launch_symbol_stream(p->d_stream_order, n, (uint32_t)C, p->d_coefs, plane, p->d_bucket_all, p->d_prediction_all, plane, p->d_symbols, n, nullptr));
+    HIP_TRY(c, hipMemcpy(symbols, p->d_symbols, C * n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(hist, p->d_hist_all, C * 10 * 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(n_out_of_alphabet, p->d_oob_all, C * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (size_t ch = 0; ch < C; ch++)
+        if (n_out_of_alphabet[ch] == ~0ull) return FRI_HIP_ERR_OUT_OF_RANGE;
     return FRI_HIP_OK;
 }
 

@@ -87,9 +87,10 @@ __device__ __forceinline__ void pred_hand_over(const PredArgs &a, const uint32_t
         __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.acc + kAccOob), (unsigned long long)s_hist[kHistBins], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // Order without fences: an agent-scope fence on this multi-XCD part writes back and invalidates the whole L2 (measured:
     // +80 us per launch). The adds above are device-scope atomics, executed at the coherence point and acknowledged through
-    // vmcnt; __syncthreads() waits for vmcnt(0) in every wave, so all of this workgroup's adds are performed before thread 0
-    // draws the ticket. The last workgroup then reads with device-scope loads, which do not hit a stale L2 line.
-    __syncthreads();
+    // vmcnt: every wave waits for its own vmcnt(0) - explicitly, see wait_for_own_memory_ops_then_barrier - so all of this workgroup's
+    // adds are performed before thread 0 draws the ticket. The last workgroup then reads with device-scope loads, which do not hit a
+    // stale L2 line.
+    wait_for_own_memory_ops_then_barrier();
     if (tid == 0) *s_flag = __hip_atomic_fetch_add(a.acc + kAccTicket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (*s_flag == 0) return;
@@ -1080,8 +1081,8 @@ void build_halo_list(const uint16_t *nbr_table, const uint16_t *pair_pos, uint32
     keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
     out[0] = 0xFFFFFFFFu;
     if (keys.size() > (size_t)kP3Threads) return; // (cannot happen with the reference's LITERALS: 902 entries; the plan checks the table it uploads)
-    // threads without an entry stage heap node 0 of slot 0 - a corner of the 6 x 6 window, which no gather ever reads - each into a halfword of its own
-    for (size_t t = keys.size(); t < (size_t)kP3Threads; t++) out[t] = (uint32_t)(2 * (t - keys.size())) << 20;
+    // threads without an entry stage a node of slot 0 - a corner of the 6 x 6 window, which no gather ever reads - each a node (and a halfword) of its own
+    for (size_t t = keys.size(); t < (size_t)kP3Threads; t++) out[t] = (uint32_t)((t - keys.size()) & 511u) << 8 | (uint32_t)(2 * (t - keys.size())) << 20;
     for (size_t i = 0; i < keys.size(); i++) {
         const uint32_t slot = keys[i] >> 16, heap = keys[i] & 511u;
         const uint32_t pos = 2u * (2u * pair_pos[heap >> 1] + (heap & 1u));

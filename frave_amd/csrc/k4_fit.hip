@@ -26,6 +26,7 @@ struct FitArgs {
     uint32_t n_tiles;
     PredictParams pp;
     const uint32_t *pred_off;  // [512][4] packed neighbour offsets per node (build_pred_offsets)
+    const uint32_t *halo_list; // [1024] the halo values a tile needs (build_halo_list), two per thread of kernel2
     unsigned long long *gram; // [3][28]   (MODE 0)
     unsigned long long *wtw;  // [3][21]   (MODE 1)
     double *wtr;              // [3][6]    (MODE 1)
@@ -245,7 +246,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
     }
     if (MODE == 1 && tid < 18) __hip_atomic_fetch_add(reinterpret_cast<double *>(a.acc + kFitAccDbl) + tid, (&s_dbl[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0 && s_range) __hip_atomic_fetch_add(a.acc + kFitAccRange, (unsigned long long)s_range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads(); // vmcnt(0) in every wave: the adds are performed
+    wait_for_own_memory_ops_then_barrier(); // every wave has waited for its adds before the ticket is drawn
     if (tid == 0) s_flag = __hip_atomic_fetch_add(a.acc + kFitAccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (s_flag == 0) return;
@@ -338,55 +339,56 @@ __device__ __forceinline__ void fit2_pair(const uint32_t (&g)[6], uint32_t own, 
     }
 }
 
-// Staging in two steps, so that a tile's global loads fly while the tile before it is worked on: the loads of a wave's cells (five
-// slots at most, 40 registers), and - behind the sums of the current tile - the conversion to int16 and the LDS writes into the OTHER of
-// two cell images. Layout and range check are pred_stage_tile's (gather_common.hpp).
+// Staging in two steps, so that a tile's global loads fly while the tile before it is worked on: the loads (a block cell and a halo value per
+// step), and - behind half of the current tile's sums - the conversion to int16 and the LDS writes into the OTHER of two cell images. Layout and
+// range check are pred_stage_tile's (gather_common.hpp).
 constexpr int kFit2Image = kPredSlots * kSlotStride; // 37 440 B; image 1 sits behind image 0, inside the gathers' 16-bit offset field
 static_assert(kFit2Image + (kPredSide + kPredBlock) * kSlotStride < 65536, "image + cell offset must fit a DS instruction's offset field");
-constexpr int kFit2StageSlots = (kPredSlots + kPredWaves - 1) / kPredWaves; // 5: slots wave, wave + 8, ...
-constexpr int kFit2StageSplit = 3; // the first three behind the barrier, the last two halfway through the tile's sums: 24 registers at most
-template <int N>
-struct Fit2Stage {
-    int4 lo[N], hi[N];
+// Round 3: the same sparse halo as K2 (k2_predict.hip, build_halo_list). A tile's 16 block cells are staged whole - two per wave, one behind each
+// half of the current tile's sums - but of its 20 halo cells only the 902 values a 4 x 4 block ever gathers, two per thread: 45 KB of loads per
+// tile instead of 72, a third of the conversions. Values land in heap order at 2 bytes each (this kernel's layout), None as 0.
+struct Fit2Block {
+    int4 lo, hi;
 };
-template <int I0, int N>
-__device__ __forceinline__ void fit2_stage_load(Fit2Stage<N> &r, const int32_t *__restrict__ coefs, const int32_t *s_slot_cell, int lane, int wave, bool skip = false) {
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        const int slot = wave + kPredWaves * (I0 + i);
-        r.lo[i] = make_int4(0, 0, 0, 0), r.hi[i] = r.lo[i];
-        const int cell = slot < kPredSlots && !skip ? s_slot_cell[slot] : -1;
-        if (cell >= 0) {
-            const int4 *src = reinterpret_cast<const int4 *>(coefs + (size_t)cell * kCell + 8 * lane);
-            r.lo[i] = src[0];
-            r.hi[i] = src[1];
-        }
+__device__ __forceinline__ int fit2_block_slot(int wave, int i) {
+    const int c = 2 * wave + i;
+    return (1 + c / kPredBlock) * kPredSide + 1 + (c % kPredBlock);
+}
+__device__ __forceinline__ void fit2_block_load(Fit2Block &r, const int32_t *__restrict__ coefs, const int32_t *s_slot_cell, int slot, int lane, bool skip) {
+    r.lo = make_int4(0, 0, 0, 0), r.hi = r.lo;
+    const int cell = skip ? -1 : s_slot_cell[slot];
+    if (cell >= 0) {
+        const int4 *src = reinterpret_cast<const int4 *>(coefs + (size_t)cell * kCell + 8 * lane);
+        r.lo = src[0];
+        r.hi = src[1];
     }
 }
-template <int I0, int N>
-__device__ __forceinline__ void fit2_stage_commit(const Fit2Stage<N> &r, const int32_t *s_slot_cell, uint8_t *image, int lane, int wave, uint32_t *range_counter) {
+__device__ __forceinline__ void fit2_block_commit(const Fit2Block &r, const int32_t *s_slot_cell, uint8_t *image, int slot, int lane, uint32_t *range_counter) {
     auto pk = [](int lo16, int hi16) -> uint32_t { return __builtin_amdgcn_perm((uint32_t)hi16, (uint32_t)lo16, 0x05040100u); };
+    const int4 lo = r.lo, hi = r.hi;
+    if (s_slot_cell[slot] >= 0) { // a None is 0x80000000: its low half stages as 0, and it is not an outlier
+        const int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t m = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        const int slot = wave + kPredWaves * (I0 + i);
-        if (slot >= kPredSlots) break;
-        const int4 lo = r.lo[i], hi = r.hi[i];
-        if (pred_is_block_slot(slot) && s_slot_cell[slot] >= 0) { // a None is 0x80000000: its low half stages as 0, and it is not an outlier
-            const int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            uint32_t m = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) m |= v[j] == kNone ? 0u : ((uint32_t)v[j] + 256u) & 0xFFFFFE00u;
-            if (__any(m != 0) && lane == 0) atomicAdd(range_counter, 1u);
-        }
-        uint4 packed;
-        packed.x = pk(lo.x, lo.y);
-        packed.y = pk(lo.z, lo.w);
-        packed.z = pk(hi.x, hi.y);
-        packed.w = pk(hi.z, hi.w);
-        uint8_t *dst = image + slot * kSlotStride;
-        *reinterpret_cast<uint4 *>(dst + 16 * lane) = packed;
-        if (lane == 0) *reinterpret_cast<uint4 *>(dst + 1024) = make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < 8; j++) m |= v[j] == kNone ? 0u : ((uint32_t)v[j] + 256u) & 0xFFFFFE00u;
+        if (__any(m != 0) && lane == 0) atomicAdd(range_counter, 1u);
     }
+    uint4 packed;
+    packed.x = pk(lo.x, lo.y);
+    packed.y = pk(lo.z, lo.w);
+    packed.z = pk(hi.x, hi.y);
+    packed.w = pk(hi.z, hi.w);
+    uint8_t *dst = image + slot * kSlotStride;
+    *reinterpret_cast<uint4 *>(dst + 16 * lane) = packed;
+    if (lane == 0) *reinterpret_cast<uint4 *>(dst + 1024) = make_uint4(0, 0, 0, 0);
+}
+// one halo value: entry = slot | heap << 8 (build_halo_list; threads without an entry stage into the unused corner slot 0)
+__device__ __forceinline__ int fit2_halo_load(const int32_t *__restrict__ coefs, const int32_t *s_slot_cell, uint32_t entry, bool skip) {
+    const int cell = skip ? -1 : s_slot_cell[entry & 63u];
+    return cell >= 0 ? coefs[(size_t)cell * kCell + ((entry >> 8) & 511u)] : 0;
+}
+__device__ __forceinline__ void fit2_halo_commit(int v, uint8_t *image, uint32_t entry) {
+    *reinterpret_cast<short *>(image + (entry & 63u) * kSlotStride + 2u * ((entry >> 8) & 511u)) = (short)v; // None = INT32_MIN: low half 0 (unwrap_or(0))
 }
 
 template <int MODE, int IMG, int C>
@@ -495,6 +497,9 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
 #pragma unroll
     for (int k = 0; k < 6; k++) dacc[k] = 0.0;
     int tiles_since_flush = 0;
+    // the thread's two halo values per tile; entries >= 1024 - 122 of the list stage into the unused corner slot, where two of them may meet: harmless
+    const uint32_t halo_e0 = a0.halo_list[tid], halo_e1 = a0.halo_list[tid + kPredThreads];
+    const int block_a = fit2_block_slot(wave, 0), block_b = fit2_block_slot(wave, 1);
 
     const int ablate = ablate_flags(a0.ablate);
     const PredTileWalk walk(a0.n_tiles);
@@ -514,17 +519,21 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         __syncthreads();                                                                                                                         \
         float facc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                                                                          \
         {                                                                                                                                        \
-            Fit2Stage<kFit2StageSplit> st;                                                                                                       \
-            fit2_stage_load<0>(st, coefs, s_slot_cell[IMG ^ 1], lane, wave, ablate & 2);                                                         \
+            Fit2Block st;                                                                                                                        \
+            fit2_block_load(st, coefs, s_slot_cell[IMG ^ 1], block_a, lane, ablate & 2);                                                         \
+            const int hv = fit2_halo_load(coefs, s_slot_cell[IMG ^ 1], halo_e0, ablate & 2);                                                     \
             if (tid < kPredSlots && tile + 2 * walk.step < walk.end) next_raw = a0.pred_slots[(size_t)(tile + 2 * walk.step) * kPredSlots + tid]; \
             if (!(ablate & 1)) fit2_cells<MODE, IMG, 0>(s_slot_cell[IMG], s_slot_interior[IMG], mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
-            fit2_stage_commit<0>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, lane, wave, &s_range);                               \
+            fit2_block_commit(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_a, lane, &s_range);                              \
+            fit2_halo_commit(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e0);                                                                     \
         }                                                                                                                                        \
         {                                                                                                                                        \
-            Fit2Stage<kFit2StageSlots - kFit2StageSplit> st;                                                                                     \
-            fit2_stage_load<kFit2StageSplit>(st, coefs, s_slot_cell[IMG ^ 1], lane, wave, ablate & 2);                                           \
+            Fit2Block st;                                                                                                                        \
+            fit2_block_load(st, coefs, s_slot_cell[IMG ^ 1], block_b, lane, ablate & 2);                                                         \
+            const int hv = fit2_halo_load(coefs, s_slot_cell[IMG ^ 1], halo_e1, ablate & 2);                                                     \
             if (!(ablate & 1)) fit2_cells<MODE, IMG, 4>(s_slot_cell[IMG], s_slot_interior[IMG], mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
-            fit2_stage_commit<kFit2StageSplit>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, lane, wave, &s_range);                 \
+            fit2_block_commit(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_b, lane, &s_range);                              \
+            fit2_halo_commit(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e1);                                                                     \
         }                                                                                                                                        \
         if (MODE == 1) {                                                                                                                         \
             _Pragma("unroll") for (int k = 0; k < 6; k++) dacc[k] += (double)facc[k];                                                            \
@@ -541,9 +550,14 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         if (tid < kPredSlots && tile + walk.step < walk.end) next_raw = a0.pred_slots[(size_t)(tile + walk.step) * kPredSlots + tid];
         __syncthreads();
         {
-            Fit2Stage<kFit2StageSlots> st;
-            fit2_stage_load<0>(st, coefs, s_slot_cell[0], lane, wave);
-            fit2_stage_commit<0>(st, s_slot_cell[0], s_cells, lane, wave, &s_range);
+            Fit2Block sa, sb;
+            fit2_block_load(sa, coefs, s_slot_cell[0], block_a, lane, false);
+            fit2_block_load(sb, coefs, s_slot_cell[0], block_b, lane, false);
+            const int h0 = fit2_halo_load(coefs, s_slot_cell[0], halo_e0, false), h1 = fit2_halo_load(coefs, s_slot_cell[0], halo_e1, false);
+            fit2_block_commit(sa, s_slot_cell[0], s_cells, block_a, lane, &s_range);
+            fit2_block_commit(sb, s_slot_cell[0], s_cells, block_b, lane, &s_range);
+            fit2_halo_commit(h0, s_cells, halo_e0);
+            fit2_halo_commit(h1, s_cells, halo_e1);
         }
         __syncthreads();
         while (true) {
@@ -576,7 +590,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     }
     if (MODE == 1 && tid < 18) __hip_atomic_fetch_add(reinterpret_cast<double *>(accp + kFitAccDbl) + tid, (&s_dbl[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0 && s_range) __hip_atomic_fetch_add(accp + kFitAccRange, (unsigned long long)s_range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads(); // vmcnt(0) in every wave: the adds are performed
+    wait_for_own_memory_ops_then_barrier(); // every wave has waited for its adds before the ticket is drawn
     if (tid == 0) s_flag = __hip_atomic_fetch_add(accp + kFitAccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (s_flag == 0) return;
@@ -612,6 +626,11 @@ struct SolveArgs {
     float *params;                      // PredictParams[n_planes]: MODE 0 writes .value, MODE 1 .width
     uint32_t n_planes;
     unsigned long long rows[3];         // MODE 1: heights of the reference's matrices (F * {256, 128, 128})
+    // for callers that want the parameters on the host (fri_hip_encode_image_dev with fit): a second copy into pinned host memory, written by the
+    // solving threads themselves (no copy command behind the kernel), and the planes' out-of-range counts next to it
+    float *host_params;                 // PredictParams[n_planes] in mapped host memory, or NULL
+    const unsigned long long *range;    // [n_planes] device, or NULL
+    unsigned long long *host_range;     // [n_planes] mapped host memory, or NULL
 };
 template <int MODE>
 __global__ void __launch_bounds__(64) fit_solve_kernel(const SolveArgs a) {
@@ -625,18 +644,25 @@ __global__ void __launch_bounds__(64) fit_solve_kernel(const SolveArgs a) {
         const unsigned long long rows = g == 0 ? a.rows[0] : g == 1 ? a.rows[1] : a.rows[2]; // (selects: no dynamic index into the argument struct)
         fit_width_group(reinterpret_cast<const long long *>(a.sums_int) + ((size_t)plane * 3 + g) * 21, a.sums_dbl + ((size_t)plane * 3 + g) * 6, rows, out);
     }
+    if (a.host_params) {
+        float *h = a.host_params + (out - a.params);
+#pragma unroll
+        for (int k = 0; k < 6; k++) h[k] = out[k];
+        if (g == 0 && a.range && a.host_range) a.host_range[plane] = a.range[plane];
+    }
 }
 
 } // namespace
 
 hipError_t launch_fit_solve(int mode, uint32_t n_planes, const unsigned long long *sums_int, const double *sums_dbl, const unsigned long long rows[3], float *params,
-                            hipStream_t stream) {
+                            hipStream_t stream, float *host_params, const unsigned long long *range, unsigned long long *host_range) {
     if (!n_planes || !sums_int || !params || (mode == 1 && !sums_dbl)) return hipErrorInvalidValue;
     SolveArgs a{};
     a.sums_int = sums_int;
     a.sums_dbl = sums_dbl;
     a.params = params;
     a.n_planes = n_planes;
+    a.host_params = host_params, a.range = range, a.host_range = host_range;
     for (int g = 0; g < 3; g++) a.rows[g] = rows ? rows[g] : 0;
     const uint32_t blocks = (n_planes * 3u + 63u) / 64u;
     (void)hipGetLastError();
@@ -658,6 +684,7 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
     a.pred_slots = p.pred_slots;
     a.nbr_table = p.nbr_table;
     a.pred_off = p.pred_off;
+    a.halo_list = p.halo_list;
     a.interior = p.interior;
     a.valid_mask = p.valid_mask;
     a.n_tiles = p.n_pred_tiles;

@@ -103,12 +103,19 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
                                  unsigned long long *out_of_range, hipStream_t stream);
 // The fit's 6 x 6 solves on the device: sums of a launch_fit_accumulate (mode 0: sums_int[n_planes][3][28]; mode 1: sums_int[n_planes][3][21],
 // sums_dbl[n_planes][3][6], rows[3] = heights of the reference's matrices) -> params[n_planes] (PredictParams: mode 0 writes .value, mode 1 .width).
+// host_params / host_range (device-visible pointers into mapped host memory, or NULL): the solving threads also leave the parameters - and the
+// planes' out-of-range counts `range` - there, for callers that want them on the host without a copy command.
 hipError_t launch_fit_solve(int mode, uint32_t n_planes, const unsigned long long *sums_int, const double *sums_dbl, const unsigned long long rows[3], float *params,
-                            hipStream_t stream);
+                            hipStream_t stream, float *host_params = nullptr, const unsigned long long *range = nullptr, unsigned long long *host_range = nullptr);
 // K3: (reference-faithful) dequantisation + inverse transform + clamp.
 // n_images images of the plan's shape: image k at coefs + k * coef_stride (int32 elements), pixels + k * pixel_stride (bytes)
 hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, const int32_t *coefs, size_t coef_stride, const QMatrix &q, uint8_t *pixels, size_t pixel_stride,
                                     hipStream_t stream);
+
+// K5: the symbol stream of n_planes planes: out[k][i] = bucket << 10 | pack_signed(coef - prediction) of node order[i] (order: n_symbols entries,
+// cell << 9 | heap index in the reference's stream order with the None nodes taken out).
+hipError_t launch_symbol_stream(const uint32_t *order, uint64_t n_symbols, uint32_t n_planes, const int32_t *coefs, size_t coef_stride, const uint8_t *bucket,
+                                const int32_t *prediction, size_t out_stride, uint16_t *out, size_t stream_stride, hipStream_t stream);
 
 // K2's per-node neighbour offsets (LDS halfword offsets relative to the own slot, two per word) from the static neighbour table
 void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out /* [512][4] */);

@@ -30,6 +30,8 @@ def load_library():
         L.fri_emit_check_image.argtypes = [vp, sz, u32, vp, u32, vp, vp, vp, C.c_char_p, sz]
         L.fri_emit_decode_image.argtypes = [vp, sz, vp, vp, sz, vp, C.c_char_p, sz]
         L.fri_emit_rans_selfcheck.argtypes = [C.c_uint64, C.c_uint64, C.c_char_p, sz]
+        L.fri_emit_stream_order.argtypes = [vp, u32, vp, vp, vp]
+        L.fri_emit_encode_image_from_streams.argtypes = [u32, u32, u32, vp, C.c_uint64, vp, vp, vp, vp, sz, vp, C.c_char_p, sz]
         _lib = L
     return _lib
 
@@ -93,6 +95,34 @@ def encode_image(width, height, centers, coefs, bucket, prediction, hist, value_
         raise EmitError(err.value.decode() or f"fri_emit_encode_image: {rc}")
     out = out[: n.value]
     return out.tobytes()
+
+
+def stream_order(centers, valid_mask):
+    """uint32 [num_some]: cell << 9 | heap index of every symbol of a channel, in stream order (None nodes taken out)."""
+    c = np.ascontiguousarray(centers, np.int32)
+    m = np.ascontiguousarray(valid_mask, np.uint32)
+    out = np.empty(len(c) * 512, np.uint32)
+    n = C.c_uint64(0)
+    if load_library().fri_emit_stream_order(_p(c), len(c), _p(m), _p(out), C.addressof(n)) != 0:
+        raise EmitError("fri_emit_stream_order")
+    return out[: n.value].copy()
+
+
+def encode_image_from_streams(width, height, streams, hist, value_params, width_params):
+    """.frv bytes from the device's symbol streams: streams uint16 [C][n_symbols] (bucket << 10 | symbol), hist [C][10][1024], params [C][3][6]."""
+    st = np.ascontiguousarray(streams, np.uint16)
+    h = np.ascontiguousarray(hist, np.uint32)
+    channels = h.size // 10240
+    n_symbols = st.size // channels
+    vp, wp = np.ascontiguousarray(value_params, np.float32), np.ascontiguousarray(width_params, np.float32)
+    assert st.size == channels * n_symbols and vp.size == channels * 18 and wp.size == channels * 18
+    n = C.c_size_t(0)
+    err = C.create_string_buffer(256)
+    out = np.empty(st.size * 4 + channels * (10 * 2070 + 256) + 64, np.uint8)
+    rc = load_library().fri_emit_encode_image_from_streams(width, height, channels, _p(st), n_symbols, _p(h), _p(vp), _p(wp), _p(out), out.size, C.addressof(n), err, 256)
+    if rc != 0:
+        raise EmitError(err.value.decode() or f"fri_emit_encode_image_from_streams: {rc}")
+    return out[: n.value].tobytes()
 
 
 def check_image(frv, centers, coefs, bucket, prediction):

@@ -540,20 +540,11 @@ int rans_selfcheck(uint64_t n_symbols, uint64_t seed, std::string &err) {
     return 0;
 }
 
+static std::string contexts_from_hist(const uint32_t *hist, ChannelStream &out);
 std::string encode_channel(const SymbolOrder &order, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction, const uint32_t *hist,
                            ChannelStream &out) {
-    for (int b = 0; b < kContexts; b++) { // prediction.rs:302-305
-        AnsContext &c = out.contexts[b];
-        uint64_t sum = 0;
-        for (int j = 0; j < kAlphabet; j++) {
-            c.freqs[j] = hist[b * kAlphabet + j];
-            sum = (uint32_t)(sum + c.freqs[j]);
-        }
-        c.off_distribution_values.clear();
-        c.max_freq_bits = trailing_zeros64(prev_power_two(sum));
-        const std::string err = c.finalize(b);
-        if (!err.empty()) return "context " + std::to_string(b) + ": " + err;
-    }
+    const std::string cerr = contexts_from_hist(hist, out);
+    if (!cerr.empty()) return cerr;
     std::vector<uint16_t> symbols;
     std::vector<uint8_t> buckets;
     channel_symbols(order, coefs, bucket, prediction, symbols, buckets);
@@ -567,6 +558,76 @@ std::string encode_channel(const SymbolOrder &order, const int32_t *coefs, const
     const std::string err = encode_symbols(symbols, buckets, tab, out.data);
     if (!err.empty()) return err;
     out.n_symbols = symbols.size();
+    return "";
+}
+
+// The channel's ANS models from the histogram K2 measured (prediction.rs:302-305)
+static std::string contexts_from_hist(const uint32_t *hist, ChannelStream &out) {
+    for (int b = 0; b < kContexts; b++) {
+        AnsContext &c = out.contexts[b];
+        uint64_t sum = 0;
+        for (int j = 0; j < kAlphabet; j++) {
+            c.freqs[j] = hist[b * kAlphabet + j];
+            sum = (uint32_t)(sum + c.freqs[j]);
+        }
+        c.off_distribution_values.clear();
+        c.max_freq_bits = trailing_zeros64(prev_power_two(sum));
+        const std::string err = c.finalize(b);
+        if (!err.empty()) return "context " + std::to_string(b) + ": " + err;
+    }
+    return "";
+}
+
+// The stream order with the None nodes taken out (which nodes are None is geometry, like the order itself): entry = cell << 9 | heap index of
+// the i-th symbol of a channel - the DC scan, the root scan, then levels 1..8 (entropy_coding.rs:285-330). This is what the device's symbol
+// stream kernel (fri_hip_symbol_stream_batch_dev) walks.
+std::vector<uint32_t> stream_order(const SymbolOrder &order, const uint32_t *valid_mask /* [n_cells][16] */) {
+    std::vector<uint32_t> out;
+    size_t total = 2 * order.level[0].size();
+    for (int level = 1; level < kDepth; level++) total += order.level[level].size();
+    out.reserve(total);
+    auto some = [&](uint32_t cell, uint32_t heap) { return (valid_mask[(size_t)cell * 16 + (heap >> 5)] >> (heap & 31)) & 1u; };
+    for (uint32_t heap0 = 0; heap0 < 2; heap0++)
+        for (uint32_t e : order.level[0])
+            if (some(e >> 9, heap0)) out.push_back((e & ~511u) | heap0);
+    for (int level = 1; level < kDepth; level++)
+        for (uint32_t e : order.level[level])
+            if (some(e >> 9, e & 511u)) out.push_back(e);
+    return out;
+}
+
+// One channel from the symbol stream the device wrote: stream[i] = bucket << 10 | symbol of the i-th Some node in stream order.
+std::string encode_channel_from_stream(const uint16_t *stream, size_t n, const uint32_t *hist, ChannelStream &out) {
+    const std::string cerr = contexts_from_hist(hist, out);
+    if (!cerr.empty()) return cerr;
+    std::vector<uint16_t> symbols(n);
+    std::vector<uint8_t> buckets(n);
+    for (size_t i = 0; i < n; i++) {
+        symbols[i] = stream[i] & 1023u, buckets[i] = (uint8_t)(stream[i] >> 10);
+        if (buckets[i] >= kContexts) return "symbol stream: bucket out of range";
+    }
+    std::vector<RansEncoderMulti::EncSymbol> tab((size_t)kContexts * kAlphabet);
+    for (int b = 0; b < kContexts; b++)
+        for (int j = 0; j < kAlphabet; j++) {
+            const AnsContext &c = out.contexts[b];
+            tab[(size_t)b * kAlphabet + j] = c.freqs[j] ? RansEncoderMulti::make_symbol(c.cdf[j], c.freqs[j], c.max_freq_bits) : RansEncoderMulti::EncSymbol{0, 0, 0, 0, 0, 0};
+        }
+    const std::string err = encode_symbols(symbols, buckets, tab, out.data);
+    if (!err.empty()) return err;
+    out.n_symbols = n;
+    return "";
+}
+
+std::string encode_channels_from_streams(uint32_t channels, const uint16_t *streams, size_t n_symbols, const uint32_t *hist, std::vector<ChannelStream> &out) {
+    out.assign(channels, ChannelStream{});
+    std::vector<std::string> errs(channels);
+    std::vector<std::thread> workers;
+    for (uint32_t ch = 1; ch < channels; ch++)
+        workers.emplace_back([&, ch] { errs[ch] = encode_channel_from_stream(streams + (size_t)ch * n_symbols, n_symbols, hist + (size_t)ch * kContexts * kAlphabet, out[ch]); });
+    if (channels) errs[0] = encode_channel_from_stream(streams, n_symbols, hist, out[0]);
+    for (std::thread &t : workers) t.join();
+    for (uint32_t ch = 0; ch < channels; ch++)
+        if (!errs[ch].empty()) return "channel " + std::to_string(ch) + ": " + errs[ch];
     return "";
 }
 

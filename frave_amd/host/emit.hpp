@@ -117,6 +117,13 @@ std::string encode_symbols(const std::vector<uint16_t> &symbols, const std::vect
 int rans_selfcheck(uint64_t n_symbols, uint64_t seed, std::string &err); // fri_emit_rans_selfcheck, fri_emit.h
 std::string encode_channels(const SymbolOrder &order, uint32_t channels, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction,
                             const uint32_t *hist, std::vector<ChannelStream> &out);
+// The device-side symbol stream (fri_hip_symbol_stream_batch_dev): stream_order = the stream order with the None nodes taken out (cell << 9 | heap
+// per symbol, geometry only: uploaded once per plan); a channel's stream is then stream[i] = bucket << 10 | symbol, 2 bytes per symbol instead of
+// the 9 bytes per node of (coefficient, prediction, bucket), and the emitter is the pure rANS loop.
+std::vector<uint32_t> stream_order(const SymbolOrder &order, const uint32_t *valid_mask /* [n_cells][16] */);
+std::string encode_channel_from_stream(const uint16_t *stream, size_t n_symbols, const uint32_t *hist, ChannelStream &out);
+std::string encode_channels_from_streams(uint32_t channels, const uint16_t *streams /* [channels][n_symbols] */, size_t n_symbols, const uint32_t *hist,
+                                         std::vector<ChannelStream> &out);
 // The (symbol, bucket) sequence in stream order (what encode_channel feeds to the coder); for self-checks.
 void channel_symbols(const SymbolOrder &order, const int32_t *coefs, const uint8_t *bucket, const int32_t *prediction, std::vector<uint16_t> &symbols,
                      std::vector<uint8_t> &buckets);

@@ -87,6 +87,34 @@ int fri_emit_encode_image(uint32_t width, uint32_t height, uint32_t channels, co
     return 0;
 }
 
+// The stream order without the None nodes: out[*n] = cell << 9 | heap index of the i-th symbol of a channel. Capacity n_cells * 512.
+int fri_emit_stream_order(const int32_t *centers_re_im, uint32_t n_cells, const uint32_t *valid_mask, uint32_t *out, uint64_t *n) {
+    if (!centers_re_im || !valid_mask || !out || !n) return -1;
+    const std::vector<uint32_t> v = stream_order(*shared_symbol_order(centers_re_im, n_cells), valid_mask);
+    std::memcpy(out, v.data(), v.size() * sizeof(uint32_t));
+    *n = v.size();
+    return 0;
+}
+
+// The whole .frv from the device's symbol streams: streams [channels][n_symbols] u16 = bucket << 10 | symbol in stream order.
+int fri_emit_encode_image_from_streams(uint32_t width, uint32_t height, uint32_t channels, const uint16_t *streams, uint64_t n_symbols, const uint32_t *hist,
+                                       const float *value_params, const float *width_params, uint8_t *out, size_t cap, size_t *len, char *err, size_t err_cap) {
+    if (!streams || !hist || !value_params || !width_params || !len || (channels != 1 && channels != 3)) return fail(err, err_cap, "invalid argument");
+    std::vector<ChannelStream> chans;
+    std::vector<ChannelParams> params(channels);
+    const std::string e = encode_channels_from_streams(channels, streams, (size_t)n_symbols, hist, chans);
+    if (!e.empty()) return fail(err, err_cap, e, -2);
+    for (uint32_t ch = 0; ch < channels; ch++) {
+        std::memcpy(params[ch].value, value_params + (size_t)ch * 18, sizeof(params[ch].value));
+        std::memcpy(params[ch].width, width_params + (size_t)ch * 18, sizeof(params[ch].width));
+    }
+    const std::vector<uint8_t> bytes = serialize(height, width, channels == 1 ? kLuma : kRGB, chans, params);
+    *len = bytes.size();
+    if (!out || cap < bytes.size()) return -3;
+    std::memcpy(out, bytes.data(), bytes.size());
+    return 0;
+}
+
 // Entropy-layer self-check of a .frv against the arrays it was made from: parse the container, rebuild every context from its
 // two serialised fields, decode all symbols with the known bucket sequence and compare. 0 = identical.
 int fri_emit_check_image(const uint8_t *frv, size_t len, uint32_t channels, const int32_t *centers_re_im, uint32_t n_cells, const int32_t *coefs,

@@ -1,6 +1,7 @@
 // fri_driver.cpp -- command-line driver over the C++ mirror / C ABI (the counterpart of fri-cli's encode/decode/bench
 // for this path; crates/fri-cli/src/commands/*.rs). Synthetic inputs only (SURVEY.md section 8d generators).
 //   fri_driver roundtrip <width> <height> <channels>         encode -> predict -> decode, checks the lossless identity
+//   fri_driver batch <width> <height> <channels> <n> [--gpus N] [--chain]   n images sharded by image over N GPUs: the forward stage, or (--chain) the whole encoder
 //   fri_driver encode <width> <height> <channels> <out.frv>  the whole encode pipeline on a synthetic image: device stages, then
 //                                                            symbol order / ANS models / rANS / frif container on the host; self-checks the stream
 //   fri_driver encode-file <in.pgm|in.ppm|in.bmp> <out.frv>  the same pipeline on a binary PGM (P5, one plane), PPM (P6, RGB) or uncompressed
@@ -173,6 +174,15 @@ static int encode_image_to_file(std::vector<uint8_t> img, uint32_t w, uint32_t h
         std::fprintf(stderr, "self-check failed: %s\n", err.c_str());
         return 1;
     }
+    // the symbol stream route (the emitter's gather on the device, 2 bytes per symbol over PCIe) must give the same file
+    t0 = std::chrono::steady_clock::now();
+    libfri::FRIEncoder streamed_encoder(opts);
+    auto streamed = streamed_encoder.encode_bytes_streamed(img, h, w, cs);
+    const double t_streamed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!streamed.ok || streamed.value != bytes) {
+        std::fprintf(stderr, "self-check failed: %s\n", streamed.ok ? "the symbol stream route gives different bytes" : streamed.error.c_str());
+        return 1;
+    }
     // and the whole way back like FRIDecoder::decode (decoder.rs:47-59): every context recomputed from the symbols decoded so far
     t0 = std::chrono::steady_clock::now();
     auto back = libfri::FRIDecoder().decode(bytes, opts);
@@ -188,8 +198,8 @@ static int encode_image_to_file(std::vector<uint8_t> img, uint32_t w, uint32_t h
         std::fprintf(stderr, "cannot write %s\n", out_path);
         return 1;
     }
-    std::printf("%ux%ux%u: %zu bytes, %.3f bits per pixel; device stages (incl. plan + PCIe) %.3f s, host emit %.3f s (first image of this size: builds the symbol order), %.3f s (every further image); decoded back in %.3f s: lossless\n", w, h, c,
-                bytes.size(), 8.0 * bytes.size() / ((double)w * h), t_dev, t_host, t_host2, t_dec);
+    std::printf("%ux%ux%u: %zu bytes, %.3f bits per pixel; device stages (incl. plan + PCIe) %.3f s, host emit %.3f s (first image of this size: builds the symbol order), %.3f s (every further image); symbol stream route end to end (plan, stream order, chain, emit) %.3f s: same bytes; decoded back in %.3f s: lossless\n", w, h, c,
+                bytes.size(), 8.0 * bytes.size() / ((double)w * h), t_dev, t_host, t_host2, t_streamed, t_dec);
     return 0;
 }
 
@@ -314,6 +324,45 @@ int main(int argc, char **argv) {
             pout[i] = out[i].data();
         }
         std::vector<int32_t> q(32, 1);
+        bool chain = false;
+        for (int i = 6; i < argc; i++) chain = chain || std::string(argv[i]) == "--chain";
+        if (chain) { // the whole encoder per image (K1 -> fit -> K2), sharded the same way: fri_hip_multi_encode_image
+            const size_t C = c;
+            std::vector<std::vector<float>> par(n, std::vector<float>(C * 36));
+            std::vector<std::vector<uint32_t>> hist(n, std::vector<uint32_t>(C * 10 * 1024));
+            std::vector<std::vector<uint64_t>> oob(n, std::vector<uint64_t>(C));
+            std::vector<float *> ppar(n);
+            std::vector<uint32_t *> phist(n);
+            std::vector<uint64_t *> poob(n);
+            for (uint32_t i = 0; i < n; i++) ppar[i] = par[i].data(), phist[i] = hist[i].data(), poob[i] = oob[i].data();
+            int rc = fri_hip_multi_encode_image(multi, n < 3 * gpus ? n : 3 * gpus, pin.data(), q.data(), 1, ppar.data(), pout.data(), nullptr, nullptr, phist.data(), poob.data());
+            auto t0 = std::chrono::steady_clock::now();
+            if (rc == FRI_HIP_OK) rc = fri_hip_multi_encode_image(multi, n, pin.data(), q.data(), 1, ppar.data(), pout.data(), nullptr, nullptr, phist.data(), poob.data());
+            const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const uint64_t some = fri_hip_plan_num_some(fri_hip_multi_plan(multi, 0));
+            fri_hip_multi_destroy(multi);
+            if (rc != FRI_HIP_OK) {
+                std::fprintf(stderr, "%s\n", fri_hip_strerror(rc));
+                return 1;
+            }
+            for (uint32_t i = 0; i < n; i++) {
+                for (size_t ch = 0; ch < C; ch++) {
+                    uint64_t total = oob[i][ch];
+                    for (size_t k = 0; k < 10 * 1024; k++) total += hist[i][ch * 10 * 1024 + k];
+                    if (total != some) {
+                        std::fprintf(stderr, "image %u channel %zu: histogram total %llu, expected %llu\n", i, ch, (unsigned long long)total, (unsigned long long)some);
+                        return 1;
+                    }
+                }
+                if (i >= distinct && (out[i] != out[i % distinct] || hist[i] != hist[i % distinct])) {
+                    std::fprintf(stderr, "image %u differs from image %u (same input)\n", i, i % distinct);
+                    return 1;
+                }
+            }
+            std::printf("batch --chain %u x %ux%ux%u on %u GPU(s) (image i -> GPU i mod %u): whole encoder chain with the fit, %.3f s, %.1f Mpixels/s host-to-host (PCIe inclusive)\n", n, w,
+                        h, c, gpus, gpus, s, (double)n * w * h / s / 1e6);
+            return 0;
+        }
         // warm-up pass on a few images per GPU (allocates the pinned staging), then the timed pass
         int rc = fri_hip_multi_transform_quant(multi, n < 3 * gpus ? n : 3 * gpus, pin.data(), q.data(), pout.data());
         auto t0 = std::chrono::steady_clock::now();

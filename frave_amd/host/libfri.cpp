@@ -315,6 +315,57 @@ Result<RasterImage> FRIDecoder::decode(const std::vector<uint8_t> &data, const E
     return decode(w.value, opts); // quantization::decode + wavelet_transform::decode: one kernel (fri_hip_inverse_transform)
 }
 
+// FRIEncoder::encode (encoder.rs:87-109) end to end through the symbol stream route: the device runs the stage chain AND the emitter's gather
+// (sort_lattice order, entropy_coding.rs:285-336), the host receives 2 bytes per symbol and runs the rANS loop and the serializer. Byte for byte
+// the .frv of encode_bytes below (tests/test_emit.py); 34 MB instead of 153 MB come down per 4096 x 4096 plane.
+Result<std::vector<uint8_t>> FRIEncoder::encode_bytes_streamed(std::vector<uint8_t> data, uint32_t height, uint32_t width, ColorSpace colorspace) {
+    Result<std::vector<uint8_t>> r;
+    auto fail = [&](const std::string &msg) {
+        r.error = "Failed to decode: " + msg; // sic, encoder.rs:106
+        return r;
+    };
+    Device dev(opts_.device);
+    if (!dev.ok()) return fail(dev.error());
+    const uint32_t c = num_channels(colorspace);
+    if (data.size() != (size_t)width * height * c) return fail("raster size does not match its metadata");
+    std::string err;
+    fri_hip_plan *plan = dev.plan(width, height, c, err);
+    if (!plan) return fail(err);
+    const uint32_t F = fri_hip_plan_num_cells(plan);
+    const uint64_t n = fri_hip_plan_num_some(plan);
+    {   // the stream order: geometry only, once per plan (the plan is new here: Device lives for this call, as in encode())
+        std::vector<int32_t> centers((size_t)F * 2);
+        std::vector<uint32_t> mask((size_t)F * 16);
+        int rc = fri_hip_plan_centers(plan, centers.data());
+        if (rc == FRI_HIP_OK) rc = fri_hip_plan_valid_mask(plan, mask.data());
+        if (rc != FRI_HIP_OK) return fail(dev.describe(rc));
+        const std::vector<uint32_t> order = emit::stream_order(*emit::shared_symbol_order(centers.data(), F), mask.data());
+        rc = fri_hip_plan_set_stream_order(plan, order.data(), order.size());
+        if (rc != FRI_HIP_OK) return fail(dev.describe(rc));
+    }
+    std::vector<uint16_t> symbols((size_t)c * n);
+    std::vector<uint32_t> hist((size_t)c * CONTEXT_AMOUNT * ALPHABET_SIZE);
+    float vp[3][3][6], wp[3][3][6];
+    stages::prediction::params_to_flat(opts_, c, vp, wp);
+    uint64_t oob[3] = {0, 0, 0};
+    const int rc = fri_hip_encode_image_symbols(plan, data.data(), opts_.quantization_matrix.data(), opts_.fit_parameters ? 1 : 0, &vp[0][0][0], &wp[0][0][0], symbols.data(),
+                                                hist.data(), oob);
+    if (rc != FRI_HIP_OK) return fail(dev.describe(rc));
+    stages::prediction::params_from_flat(opts_, c, vp, wp);
+    if (oob[0] | oob[1] | oob[2]) return fail("symbol outside the 1024-entry alphabet"); // the reference panics: bump_freq, entropy_coding.rs:99
+    std::vector<emit::ChannelStream> streams;
+    const std::string e = emit::encode_channels_from_streams(c, symbols.data(), (size_t)n, hist.data(), streams);
+    if (!e.empty()) return fail(e);
+    std::vector<emit::ChannelParams> params(c);
+    for (uint32_t ch = 0; ch < c; ch++)
+        for (int g = 0; g < 3; g++)
+            for (int k = 0; k < 6; k++) params[ch].value[g][k] = vp[ch][g][k], params[ch].width[g][k] = wp[ch][g][k];
+    const emit::ColorSpaceCode cs = colorspace == ColorSpace::Luma ? emit::kLuma : colorspace == ColorSpace::RGB ? emit::kRGB : emit::kYCbCr;
+    r.value = emit::serialize(height, width, cs, streams, params);
+    r.ok = true;
+    return r;
+}
+
 Result<std::vector<uint8_t>> FRIEncoder::encode_bytes(std::vector<uint8_t> data, uint32_t height, uint32_t width, ColorSpace colorspace) {
     Result<std::vector<uint8_t>> r;
     auto st = encode(std::move(data), height, width, colorspace);

@@ -158,6 +158,8 @@ class FRIEncoder { // encoder.rs:66-109
     Result<EncodedStages> encode(std::vector<uint8_t> data, uint32_t height, uint32_t width, ColorSpace colorspace);
     // the whole pipeline of encoder.rs:19-48: ... -> EntropyEncoding -> Serialization -> EncodedImage(Vec<u8>)
     Result<std::vector<uint8_t>> encode_bytes(std::vector<uint8_t> data, uint32_t height, uint32_t width, ColorSpace colorspace);
+    // the same bytes through the symbol stream route: the emitter's gather runs on the device (fri_hip_encode_image_symbols), 2 bytes per symbol come down
+    Result<std::vector<uint8_t>> encode_bytes_streamed(std::vector<uint8_t> data, uint32_t height, uint32_t width, ColorSpace colorspace);
     const EncoderOpts &opts() const { return opts_; } // after encode: the fitted predictor parameters
 
   private:

@@ -49,6 +49,16 @@ int fri_emit_encode_image(uint32_t width, uint32_t height, uint32_t channels, co
                           const uint8_t *bucket, const int32_t *prediction, const uint32_t *hist, const float *value_params, const float *width_params,
                           uint8_t *out, size_t cap, size_t *len, char *err, size_t err_cap);
 
+/* The symbol stream route (fri_hip_symbol_stream_batch_dev, include/fri_hip.h): the gather of (symbol, bucket) in sort_lattice order
+ * (entropy_coding.rs:285-336 over wavelet_transform.rs:657-705) runs on the device, the host receives 2 bytes per symbol.
+ * fri_emit_stream_order: the stream order with the None nodes taken out - out[i] = cell << 9 | heap index of the i-th symbol of a channel (DC scan,
+ * root scan, levels 1..8); valid_mask = fri_hip_plan_valid_mask; capacity n_cells * 512, *n = fri_hip_plan_num_some. Geometry only: once per plan.
+ * fri_emit_encode_image_from_streams: the whole `.frv` from streams [channels][n_symbols] u16 = bucket << 10 | symbol, byte for byte what
+ * fri_emit_encode_image makes of the arrays the streams were gathered from. */
+int fri_emit_stream_order(const int32_t *centers_re_im, uint32_t n_cells, const uint32_t *valid_mask, uint32_t *out, uint64_t *n);
+int fri_emit_encode_image_from_streams(uint32_t width, uint32_t height, uint32_t channels, const uint16_t *streams, uint64_t n_symbols, const uint32_t *hist,
+                                       const float *value_params, const float *width_params, uint8_t *out, size_t cap, size_t *len, char *err, size_t err_cap);
+
 /* Entropy-layer self-check of a `.frv` against the arrays it was made from (parse, rebuild the models, decode every symbol
  * with the known bucket sequence, compare). */
 int fri_emit_check_image(const uint8_t *frv, size_t len, uint32_t channels, const int32_t *centers_re_im, uint32_t n_cells, const int32_t *coefs,

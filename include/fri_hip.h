@@ -286,6 +286,25 @@ int fri_hip_predict_image(fri_hip_plan *plan, const int32_t *coefs, int fit, flo
 int fri_hip_predict_image_dev(fri_hip_plan *plan, const int32_t *d_coefs, int fit, float *value_params, float *width_params, uint8_t *d_bucket, int32_t *d_prediction,
                               uint32_t *d_hist, uint64_t *d_n_out_of_alphabet, void *stream);
 
+/* ---- the ordered symbol stream: the emitter's gather on the device ------------------------------ */
+/* The reference's emitter walks a channel's Some nodes in sort_lattice order (ten scans: DC, root, levels 1..8; stages/wavelet_transform.rs:657-705,
+ * stages/entropy_coding.rs:285-336) and feeds pack_signed(value - prediction) with its context bucket to the rANS coder. That walk is a permutation
+ * fixed by the geometry. fri_hip_plan_set_stream_order uploads it once per plan: order[i] = cell << 9 | heap index of the i-th symbol, n =
+ * fri_hip_plan_num_some (fri_emit_stream_order of include/fri_emit.h builds it; the call checks that it is a permutation of the plan's Some nodes).
+ * fri_hip_symbol_stream_batch_dev then writes, per plane k, d_symbols[k * symbol_stride + i] = bucket << 10 | symbol for i < num_some, from the
+ * coefficient / bucket / prediction planes laid out as in fri_hip_predict_histogram_batch_dev: 2 bytes per symbol leave the device instead of the
+ * 9 bytes per node of the three arrays, and the host emitter (fri_emit_encode_image_from_streams) is the pure rANS loop. A symbol >= 1024 cannot be
+ * represented (the reference panics, entropy_coding.rs:99): emit only planes whose n_out_of_alphabet is 0. */
+int fri_hip_plan_set_stream_order(fri_hip_plan *plan, const uint32_t *order, uint64_t n);
+int fri_hip_symbol_stream_batch_dev(fri_hip_plan *plan, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, const uint8_t *d_bucket, const int32_t *d_prediction,
+                                    size_t out_stride, uint16_t *d_symbols, size_t symbol_stride, void *stream);
+
+/* The device part of FRIEncoder::encode all the way to the emitter's input, for host buffers: fri_hip_encode_image's chain followed by the symbol
+ * stream kernel; what comes back is symbols[C][num_some] (2 bytes per symbol) + hist + parameters + n_out_of_alphabet - 17 MB up and 34 MB down per
+ * 4096 x 4096 plane where fri_hip_encode_image moves 17 MB up and 153 MB down. Needs fri_hip_plan_set_stream_order. Argument meaning as fri_hip_encode_image. */
+int fri_hip_encode_image_symbols(fri_hip_plan *plan, const uint8_t *pixels, const int32_t qmatrix[32], int fit, float *value_params, float *width_params, uint16_t *symbols,
+                                 uint32_t *hist, uint64_t *n_out_of_alphabet);
+
 /* ---- inverse: dequantisation + inverse transform (decode side) ------------------------------ */
 /* Replaces quantization::decode (stages/quantization.rs:27-45) + wavelet_transform::decode
  * (stages/wavelet_transform.rs:715-717: RasterImage::from_wavelet :308-356, extract_values

@@ -23,7 +23,7 @@ def test_emit_library_exports_every_declared_symbol():
 
     lib = emit.load_library()
     names = declared_symbols("fri_emit.h", "fri_emit_")
-    assert len(names) == 7
+    assert len(names) == 9
     for name in names:
         assert hasattr(lib, name), name
         assert ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
@@ -85,3 +85,15 @@ def test_plan_argument_errors():
         assert e.value.code == -1
     with pytest.raises(frave_amd.FriHipError):  # larger than the reference's u32 pixel index (images.rs:94)
         frave_amd.Plan(None, 65536, 65536, 3)
+
+
+def test_rust_extern_blocks_are_generated_from_the_headers():
+    """integration/hip_sys.rs and emit_sys.rs (the `extern "C"` blocks of the Rust side; unverifiable here: no Rust toolchain) are generated from
+    include/*.h by tools/gen_hip_sys.py: the committed files are current and declare every symbol the headers declare."""
+    import subprocess
+    import sys
+
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_hip_sys.py"), "--check"]).returncode == 0
+    for header, prefix, rs in (("fri_hip.h", "fri_hip_", "hip_sys.rs"), ("fri_emit.h", "fri_emit_", "emit_sys.rs")):
+        text = open(os.path.join(ROOT, "integration", rs)).read()
+        assert sorted(re.findall(r"pub fn (" + prefix + r"[a-z0-9_]+)\(", text)) == declared_symbols(header, prefix)

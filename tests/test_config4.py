@@ -81,6 +81,46 @@ def test_multi_device_helper_on_the_devices_present(oracle):
     M.close()
 
 
+@pytest.mark.gpu
+def test_sharded_encode_on_the_devices_present(oracle):
+    """fri_hip_multi_encode_image: the reference's per-image loop (bench.rs:15-120 around FRIEncoder::encode) over the GPUs of the node - image i on
+    device i mod N, one host thread per device, each image the whole asynchronous chain (K1 -> fit -> K2) with overlapped copies. Sampled images
+    against the oracle run with the parameters the chain fitted; every image's histogram total; given parameters (fit = 0) as well."""
+    import torch
+
+    import frave_amd as fa
+    from tests.common import gen_image, random_params
+
+    n_dev = min(torch.cuda.device_count(), 2)
+    w, h, c = 640, 360, 3
+    M = fa.Multi(list(range(n_dev)), w, h, c)
+    imgs = [gen_image("noise" if i % 2 else "smooth", w, h, c, 30 + i) for i in range(7)]
+    coefs, par, bucket, pred, hist, oob = M.encode_image(imgs, fit=True)
+    L = fa.load_library()
+    some = L.fri_hip_plan_num_some(L.fri_hip_multi_plan(M._h, 0))
+    for i in range(7):
+        assert all(int(hist[i][ch].sum()) + int(oob[i][ch]) == some for ch in range(c)), i
+    for i in (0, 3, 6):
+        Wv = oracle.Wavelet(imgs[i], h, w, c)
+        assert np.array_equal(coefs[i], Wv.coefficients())
+        Wv.quantize(np.ones(32, np.int32))
+        for ch in range(c):
+            wb, wpred, whist, woob = Wv.predict(ch, par[i][ch, 0], par[i][ch, 1])
+            assert np.array_equal(bucket[i][ch], wb) and np.array_equal(pred[i][ch], wpred) and np.array_equal(hist[i][ch], whist) and int(oob[i][ch]) == woob
+        Wv.close()
+    given = [np.stack([np.stack(random_params(50 + i + ch)) for ch in range(c)]) for i in range(7)]
+    coefs2, par2, bucket2, pred2, hist2, oob2 = M.encode_image(imgs, fit=False, params=given, want_bucket=False)
+    assert bucket2 is None and all(np.array_equal(a, b) for a, b in zip(par2, [g.astype(np.float32) for g in given]))
+    for i in (1, 4):
+        Wv = oracle.Wavelet(imgs[i], h, w, c)
+        Wv.quantize(np.ones(32, np.int32))
+        for ch in range(c):
+            wb, wpred, whist, woob = Wv.predict(ch, given[i][ch, 0], given[i][ch, 1])
+            assert np.array_equal(pred2[i][ch], wpred) and np.array_equal(hist2[i][ch], whist) and int(oob2[i][ch]) == woob
+        Wv.close()
+    M.close()
+
+
 def test_shard_functions_cover_the_batch_once():
     """The C partition itself (host-only: no GPU): disjoint, complete, balanced; image i -> shard i mod n."""
     import frave_amd as fa

@@ -231,6 +231,86 @@ def test_full_decode_rejects_damaged_files():
         pass
 
 
+def _numpy_streams(order, coefs, bucket, pred):
+    """What K5 computes, in numpy: per channel, bucket << 10 | pack_signed(coef - prediction) of the nodes in `order`."""
+    c = coefs.shape[0]
+    out = []
+    for ch in range(c):
+        d = (coefs[ch].reshape(-1)[order].astype(np.int64) - pred[ch].reshape(-1)[order].astype(np.int64)).astype(np.int32)
+        sym = ((d.astype(np.uint32) << 1) ^ (d >> 31).astype(np.uint32)) & 1023
+        out.append((bucket[ch].reshape(-1)[order].astype(np.uint32) << 10 | sym).astype(np.uint16))
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("name", ["emit_mixed_129x65_luma", "emit_mixed_96x257_rgb"])
+def test_stream_route_reproduces_the_golden_files(name):
+    """The symbol-stream route (stream order without the None nodes + 2-byte symbols + fri_emit_encode_image_from_streams) makes the committed
+    .frv files byte for byte; the stream order is the reference's (oracle walk), None nodes taken out."""
+    import frave_amd
+    from tests.golden.make_golden import EMIT_CASES
+
+    w, h, c, seed = EMIT_CASES[name]
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".frv"), "rb") as f:
+        golden = f.read()
+    W, coefs, bucket, pred, hist, vp, wp = _arrays(w, h, c, seed)
+    P = frave_amd.Plan(None, w, h, c)  # host-only plan: geometry getters
+    assert np.array_equal(P.centers(), W.centers())
+    order = emit.stream_order(P.centers(), P.valid_mask())
+    assert len(order) == P.num_some and len(np.unique(order)) == len(order)
+    some = coefs[0].reshape(-1) != fri_oracle.NONE
+    assert some[order].all() and some.sum() == len(order)
+    for ch in range(c):  # the sequence the reference's loop feeds to its coder
+        ref = emit_oracle.stream_symbols(W, ch, coefs[ch], bucket[ch], pred[ch])
+        st = _numpy_streams(order, coefs, bucket, pred)[ch]
+        assert list(zip((st & 1023).tolist(), (st >> 10).tolist())) == ref
+    assert emit.encode_image_from_streams(w, h, _numpy_streams(order, coefs, bucket, pred), hist, vp, wp) == golden
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(129, 65, 1), (640, 360, 3), (4096, 4096, 1)])
+def test_symbol_stream_on_the_device(shape):
+    """K5 (fri_hip_symbol_stream_batch_dev): the stream equals the gather of the device's own arrays in stream order, and the .frv made from it is the
+    one the array route (fri_emit_encode_image: gather on the host) makes."""
+    import torch
+
+    import frave_amd
+
+    w, h, c = shape
+    img = _mixed_image(w, h, c, 13)
+    ctx = frave_amd.Context(0)
+    P = frave_amd.Plan(ctx, w, h, c)
+    order = P.set_stream_order()
+    F, plane, n = P.num_cells, P.num_cells * 512, P.num_some
+    assert len(order) == n
+    d_px = torch.from_numpy(img.reshape(-1)).cuda()
+    d_co = torch.empty((c, plane), dtype=torch.int32, device="cuda")
+    d_b = torch.empty((c, plane), dtype=torch.uint8, device="cuda")
+    d_p = torch.empty((c, plane), dtype=torch.int32, device="cuda")
+    d_h = torch.empty((c, 10, 1024), dtype=torch.int32, device="cuda")
+    d_o = torch.empty(c, dtype=torch.int64, device="cuda")
+    d_par = torch.zeros((c, 2, 3, 6), dtype=torch.float32, device="cuda")
+    d_st = torch.full((c, n + 8), 0xFFFF, dtype=torch.uint16, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    P.encode_image_batch_dev(1, d_px.data_ptr(), P.pixel_bytes, d_par.data_ptr(), d_co.data_ptr(), c * plane, d_b.data_ptr(), d_p.data_ptr(), c * plane, d_h.data_ptr(), d_o.data_ptr(),
+                             fit=True, stream=s)
+    P.symbol_stream_batch_dev(c, d_co.data_ptr(), plane, d_b.data_ptr(), d_p.data_ptr(), plane, d_st.data_ptr(), n + 8, stream=s)
+    torch.cuda.synchronize()
+    assert int(d_o.abs().sum()) == 0
+    st = d_st.cpu().numpy()
+    assert (st[:, n:] == 0xFFFF).all()  # nothing behind a plane's symbols
+    co, b, p = d_co.cpu().numpy().reshape(c, F, 512), d_b.cpu().numpy().reshape(c, F, 512), d_p.cpu().numpy().reshape(c, F, 512)
+    assert np.array_equal(st[:, :n], _numpy_streams(order, co, b, p))
+    par = d_par.cpu().numpy()
+    hist = d_h.cpu().numpy().astype(np.uint32)
+    from_streams = emit.encode_image_from_streams(w, h, np.ascontiguousarray(st[:, :n]), hist, par[:, 0], par[:, 1])
+    from_arrays = emit.encode_image(w, h, P.centers(), co, b, p, hist, par[:, 0], par[:, 1])
+    assert from_streams == from_arrays
+    if w <= 640:
+        dw, dh, dc, centers, coefs = emit.decode_image(from_streams)
+        assert np.array_equal(coefs, co)
+    P.close()
+
+
 @pytest.mark.gpu
 def test_emit_from_device_arrays():
     import frave_amd

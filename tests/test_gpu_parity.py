@@ -177,6 +177,17 @@ def test_inverse_roundtrip_and_oracle(ctx, oracle, shape):
     rnd[~valid] = oracle.NONE
     W.set_coefficients(rnd)
     assert np.array_equal(P.inverse_transform(rnd), W.to_raster())
+    # coefficients inside [-255, 255] that are no image's transform: the packed 16-bit path (two items per wave) with negative low-pass values,
+    # intermediate values up to a few thousand and both ends of the clamp; and a mix in which only some items qualify for it
+    small = rng.integers(-255, 256, co.shape, dtype=np.int32)
+    small[~valid] = oracle.NONE
+    W.set_coefficients(small)
+    assert np.array_equal(P.inverse_transform(small), W.to_raster())
+    mixed = small.copy()
+    F = co.shape[1]
+    mixed[:, ::3] = np.where(valid[:, ::3], rnd[:, ::3], oracle.NONE)  # every third cell gets the wide values
+    W.set_coefficients(mixed)
+    assert np.array_equal(P.inverse_transform(mixed), W.to_raster())
 
 
 def test_trace_is_off_in_the_product_build(ctx):
@@ -334,7 +345,13 @@ def test_large_image_short_shares_against_the_oracle(ctx, oracle):
     co = P.transform_quant(img)
     W = oracle.Wavelet(img, h, w, 1)
     assert np.array_equal(co, W.coefficients())
+    # K2 at this size (32-33 tiles per workgroup, the LF prologue's second and third pass): bucket, prediction and histogram against the oracle
+    vp, wp = random_params(5)
+    b, p, hist, oob = P.predict_histogram(co, 0, vp, wp)
+    W.quantize(np.ones(32, np.int32))
+    wb, wpred, whist, woob = W.predict(0, vp, wp)
     W.close()
+    assert np.array_equal(b, wb) and np.array_equal(p, wpred) and np.array_equal(hist, whist) and oob == woob
     assert np.array_equal(P.inverse_transform(co), img.reshape(-1))
 
 
@@ -373,3 +390,100 @@ def test_unaligned_device_pointers(ctx, oracle, shape, offset):
     out = d_out.cpu().numpy()
     assert np.array_equal(out[guard + offset: guard + offset + P.pixel_bytes], img.reshape(-1))
     assert (out[:guard + offset] == 0x5A).all() and (out[guard + offset + P.pixel_bytes:] == 0x5A).all()
+
+
+def test_predict_and_fit_from_many_streams_and_growing_batches(ctx, oracle):
+    """K2 and K4 hand their sums over through per-stream plan accumulators (eight slots, handed from stream to stream behind an event when more
+    streams are in play) that grow with the batch: launches from twelve streams at once, then batches of 1, 5 and 9 planes on one of them - every
+    result against the oracle / the single-plane entry points - and the plan survives a stream that was destroyed while it owned a slot."""
+    import torch
+
+    w, h = 320, 240
+    P = _plan(ctx, w, h, 1)
+    F, plane = P.num_cells, P.num_cells * 512
+    imgs = [gen_image(["noise", "smooth"][i % 2], w, h, 1, 70 + i) for i in range(12)]
+    params = [random_params(20 + i) for i in range(12)]
+    want = []
+    for img, (vp, wp) in zip(imgs, params):
+        W = oracle.Wavelet(img, h, w, 1)
+        W.quantize(np.ones(32, np.int32))
+        want.append((W.coefficients(), W.predict(0, vp, wp)))
+        W.close()
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    bufs = []
+    for i, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            d_px = torch.from_numpy(imgs[i].reshape(-1)).cuda()
+            d_co = torch.empty(plane, dtype=torch.int32, device="cuda")
+            d_b = torch.empty(plane, dtype=torch.uint8, device="cuda")
+            d_p = torch.empty(plane, dtype=torch.int32, device="cuda")
+            d_h = torch.empty((10, 1024), dtype=torch.int32, device="cuda")
+            d_o = torch.empty(1, dtype=torch.int64, device="cuda")
+            d_g = torch.empty((3, 28), dtype=torch.int64, device="cuda")
+            bufs.append((d_px, d_co, d_b, d_p, d_h, d_o, d_g))
+    torch.cuda.synchronize()
+    for rep in range(3):  # all twelve streams in flight together, three times over (slots change hands)
+        for i, st in enumerate(streams):
+            d_px, d_co, d_b, d_p, d_h, d_o, d_g = bufs[i]
+            P.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=st.cuda_stream)
+            P.fit_value_sums_dev(d_co.data_ptr(), 0, d_g.data_ptr(), stream=st.cuda_stream)
+            P.predict_histogram_dev(d_co.data_ptr(), 0, params[i][0], params[i][1], d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        for i in range(12):
+            d_px, d_co, d_b, d_p, d_h, d_o, d_g = bufs[i]
+            co, (wb, wpred, whist, woob) = want[i]
+            assert np.array_equal(d_co.cpu().numpy().reshape(1, F, 512), co), (rep, i)
+            assert np.array_equal(d_b.cpu().numpy().reshape(F, 512), wb) and np.array_equal(d_p.cpu().numpy().reshape(F, 512), wpred), (rep, i)
+            assert np.array_equal(d_h.cpu().numpy().astype(np.uint32), whist) and int(d_o) == woob, (rep, i)
+            assert np.array_equal(d_g.cpu().numpy(), np.stack([g[np.triu_indices(7)] for g in P.fit_value_sums(co, 0)])), (rep, i)
+    # a stream that owns a slot goes away; later launches must still come out right (the slot is taken over without its event)
+    del streams[:6]
+    import gc
+
+    gc.collect()
+    torch.cuda.synchronize()
+    # growing batches on one stream: 1, 5, 9 planes (the accumulators are re-allocated on the way)
+    s0 = torch.cuda.current_stream().cuda_stream
+    for n in (1, 5, 9):
+        d_co = torch.from_numpy(np.stack([want[k][0].reshape(-1) for k in range(n)])).cuda()
+        d_par = torch.from_numpy(np.stack([np.stack(params[k]) for k in range(n)]).astype(np.float32)).cuda()
+        d_b = torch.empty((n, plane), dtype=torch.uint8, device="cuda")
+        d_p = torch.empty((n, plane), dtype=torch.int32, device="cuda")
+        d_h = torch.empty((n, 10, 1024), dtype=torch.int32, device="cuda")
+        d_o = torch.empty(n, dtype=torch.int64, device="cuda")
+        d_g = torch.empty((n, 3, 28), dtype=torch.int64, device="cuda")
+        P.predict_histogram_batch_dev(n, d_co.data_ptr(), plane, d_par.data_ptr(), d_b.data_ptr(), d_p.data_ptr(), plane, d_h.data_ptr(), d_o.data_ptr(), stream=s0)
+        P.fit_value_sums_batch_dev(n, d_co.data_ptr(), plane, d_g.data_ptr(), stream=s0)
+        torch.cuda.synchronize()
+        for k in range(n):
+            wb, wpred, whist, woob = want[k][1]
+            assert np.array_equal(d_b[k].cpu().numpy().reshape(F, 512), wb) and np.array_equal(d_p[k].cpu().numpy().reshape(F, 512), wpred), (n, k)
+            assert np.array_equal(d_h[k].cpu().numpy().astype(np.uint32), whist) and int(d_o[k]) == woob, (n, k)
+            assert np.array_equal(d_g[k].cpu().numpy(), np.stack([g[np.triu_indices(7)] for g in P.fit_value_sums(want[k][0], 0)])), (n, k)
+
+
+def test_histogram_hand_over_when_all_workgroups_finish_together(ctx):
+    """Regression for a lost-update race in the hand-over of K2 / K4 (every workgroup adds its partial sums into a plan accumulator, the last one
+    copies the totals out): a 1080p plane gives each of the 256 workgroups one or two tiles, so all of them reach the hand-over within a microsecond
+    or so. 300 launches, every total must be the number of Some nodes."""
+    import torch
+
+    w, h = 1920, 1080
+    P = _plan(ctx, w, h, 1)
+    plane = P.num_cells * 512
+    d_px = torch.randint(0, 256, (P.pixel_bytes,), dtype=torch.uint8, device="cuda")
+    d_co = torch.empty(plane, dtype=torch.int32, device="cuda")
+    d_b = torch.empty(plane, dtype=torch.uint8, device="cuda")
+    d_p = torch.empty(plane, dtype=torch.int32, device="cuda")
+    d_h = torch.empty((300, 10, 1024), dtype=torch.int32, device="cuda")
+    d_o = torch.empty(300, dtype=torch.int64, device="cuda")
+    d_g = torch.empty((300, 3, 28), dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    P.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=s)
+    vp, wp = random_params(1)
+    for k in range(300):
+        P.predict_histogram_dev(d_co.data_ptr(), 0, vp, wp, d_b.data_ptr(), d_p.data_ptr(), d_h[k].data_ptr(), d_o[k].data_ptr(), stream=s)
+        P.fit_value_sums_dev(d_co.data_ptr(), 0, d_g[k].data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    assert bool((d_h.sum(dim=(1, 2)) + d_o == P.num_some).all())
+    assert bool((d_h == d_h[0]).all()) and bool((d_g == d_g[0]).all())
