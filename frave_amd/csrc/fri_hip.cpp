@@ -72,8 +72,8 @@ struct fri_hip_plan {
         hipStream_t stream = nullptr;
         bool used = false;
         hipEvent_t handed_over = nullptr;
-        uint32_t *pred_acc = nullptr;           // [planes][kPredAccWords], grown on demand, all zero between launches
-        unsigned long long *fit_acc = nullptr;  // [planes][kFitAccWords]
+        uint32_t *pred_acc = nullptr;           // [planes][kPredShards][kPredAccWords], grown on demand, all zero between launches
+        unsigned long long *fit_acc = nullptr;  // [planes][kFitShards][kFitAccWords]
         // scratch of the device-side fit (fit_chain): the sums of a launch's planes on their way to the solve kernels, their out-of-range
         // counts, and parameter sets for callers that keep theirs on the host. Per stream like the accumulators: chains of several streams
         // (fri_hip_multi_encode_image's slots) run side by side on one plan.
@@ -184,8 +184,8 @@ int acquire_acc(fri_hip_plan *p, hipStream_t stream, uint32_t n_planes = 1) {
     if (p->acc_dirty) { // rare: a previous launch failed part-way; nothing may be in flight on the accumulators when they are cleared
         HIP_TRY(c, hipDeviceSynchronize());
         for (auto &a : p->acc_slots) {
-            if (a.pred_acc) HIP_TRY(c, hipMemset(a.pred_acc, 0, (size_t)a.planes * kPredAccWords * sizeof(uint32_t)));
-            if (a.fit_acc) HIP_TRY(c, hipMemset(a.fit_acc, 0, (size_t)a.planes * kFitAccWords * sizeof(unsigned long long)));
+            if (a.pred_acc) HIP_TRY(c, hipMemset(a.pred_acc, 0, (size_t)a.planes * kPredShards * kPredAccWords * sizeof(uint32_t)));
+            if (a.fit_acc) HIP_TRY(c, hipMemset(a.fit_acc, 0, (size_t)a.planes * kFitShards * kFitAccWords * sizeof(unsigned long long)));
         }
         HIP_TRY(c, hipDeviceSynchronize()); // (the memsets ran on the null stream: done before any stream launches on the accumulators again)
         p->acc_dirty = false;
@@ -220,7 +220,7 @@ int acquire_acc(fri_hip_plan *p, hipStream_t stream, uint32_t n_planes = 1) {
     if (a.planes < n_planes) { // grow: the old buffers may still be in use by queued launches, so they are retired, not freed
         const uint32_t planes = n_planes < 4 ? 4 : n_planes;
         void *pa = nullptr, *fa = nullptr, *si = nullptr, *sd = nullptr, *rg = nullptr, *pr = nullptr;
-        const size_t pb = (size_t)planes * kPredAccWords * sizeof(uint32_t), fb = (size_t)planes * kFitAccWords * sizeof(unsigned long long);
+        const size_t pb = (size_t)planes * kPredShards * kPredAccWords * sizeof(uint32_t), fb = (size_t)planes * kFitShards * kFitAccWords * sizeof(unsigned long long);
         hipError_t e = hipMalloc(&pa, pb);
         if (e == hipSuccess) e = hipMalloc(&fa, fb);
         if (e == hipSuccess) e = hipMalloc(&si, (size_t)planes * 3 * 28 * sizeof(unsigned long long));
@@ -511,6 +511,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         if (const char *e = env_str("FRI_HIP_K1_BATCH_SHARES")) d.k1_batch_shares = std::atoi(e) != 0;
         d.k3_ablate = env_int("FRI_HIP_K3_ABLATE");
         d.k4_ablate = env_int("FRI_HIP_K4_ABLATE");
+        if (const char *e = env_str("FRI_HIP_K4_OLDER_EIGHTHS")) d.k4_older_eighths = std::atoi(e);
         d.k3_scan = env_int("FRI_HIP_K3_SCAN") > 0;
         if (!g.inv_lists.empty()) {
             if ((rc = upload(p, g.inv_lists, d.inv_lists)) || (rc = upload(p, g.inv_quads, d.inv_quads)) || (rc = upload(p, g.inv_dwords, d.inv_dwords)) ||

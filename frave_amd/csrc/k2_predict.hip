@@ -79,9 +79,12 @@ struct PredArgs {
 constexpr int kAccOob = kHistBins, kAccTicket = kHistBins + 2, kAccInexact = kHistBins + 4; // + the exact kernel's ticket at kAccInexact + 1
 static_assert(kHistBins + 8 == (int)kPredAccWords, "accumulator layout");
 __device__ __forceinline__ void pred_hand_over(const PredArgs &a, const uint32_t *s_hist, uint32_t *s_flag, int tid, int n_threads) {
+    // (the counts go to one of kPredShards copies of the accumulator: all workgroups of a launch adding into the same hot bins serialise at ~12 ns
+    // per add and address at the memory side; the last workgroup sums the copies. Copy 0 also holds the counters behind the bins.)
+    uint32_t *const acc_s = a.acc + (size_t)(blockIdx.x % kPredShards) * kPredAccWords;
     for (int i = tid; i < kHistBins; i += n_threads) {
         const uint32_t c = s_hist[i];
-        if (c) __hip_atomic_fetch_add(a.acc + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c) __hip_atomic_fetch_add(acc_s + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0 && s_hist[kHistBins])
         __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.acc + kAccOob), (unsigned long long)s_hist[kHistBins], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -100,22 +103,29 @@ __device__ __forceinline__ void pred_hand_over(const PredArgs &a, const uint32_t
     // (a plane kernel3 could not represent - a.inexact raised - hands over an all-zero histogram: the exact kernel behind it adds the real one)
     const bool inexact = a.inexact && __hip_atomic_load(a.inexact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     if (n_threads == 1024) {
-        uint32_t v[kHistBins / 1024];
+        uint32_t v[kHistBins / 1024][kPredShards];
 #pragma unroll
-        for (int k = 0; k < kHistBins / 1024; k++) v[k] = __hip_atomic_load(a.acc + tid + 1024 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < kHistBins / 1024; k++)
+#pragma unroll
+            for (uint32_t sh = 0; sh < kPredShards; sh++) v[k][sh] = __hip_atomic_load(a.acc + sh * kPredAccWords + tid + 1024 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < kHistBins / 1024; k++) {
-            a.hist[tid + 1024 * k] = inexact ? 0u : v[k];
-            __hip_atomic_store(a.acc + tid + 1024 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t sum = 0;
+#pragma unroll
+            for (uint32_t sh = 0; sh < kPredShards; sh++) {
+                sum += v[k][sh];
+                __hip_atomic_store(a.acc + sh * kPredAccWords + tid + 1024 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            a.hist[tid + 1024 * k] = inexact ? 0u : sum;
         }
-    } else {
-        uint32_t v[kHistBins / 512];
-#pragma unroll
-        for (int k = 0; k < kHistBins / 512; k++) v[k] = __hip_atomic_load(a.acc + tid + 512 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
+    } else { // (the 512-thread kernel of round 1, tuning builds only: it adds into copy blockIdx % kPredShards like everyone else)
         for (int k = 0; k < kHistBins / 512; k++) {
-            a.hist[tid + 512 * k] = v[k];
-            __hip_atomic_store(a.acc + tid + 512 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t sum = 0;
+            for (uint32_t sh = 0; sh < kPredShards; sh++) {
+                sum += __hip_atomic_load(a.acc + sh * kPredAccWords + tid + 512 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.acc + sh * kPredAccWords + tid + 512 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            a.hist[tid + 512 * k] = sum;
         }
     }
     if (tid == 0) {
@@ -635,7 +645,7 @@ __global__ void __launch_bounds__(kCell) exact_predict_kernel(const ExactArgs a0
         if (a.prediction) a.prediction += plane * a0.out_stride;
         a.hist += (size_t)plane * kHistBins;
         a.n_oob += plane;
-        a.acc += (size_t)plane * kPredAccWords;
+        a.acc += (size_t)plane * kPredShards * kPredAccWords;
     }
     // this plane's parameters as scalars (static indices only: a dynamic index into the argument struct would keep all of it in scratch memory);
     // a thread then picks its layer group's set with selects
@@ -976,7 +986,7 @@ __device__ __forceinline__ PredArgs pred_plane_view(const PredArgs &a0, uint32_t
     if (a.prediction) a.prediction += plane * a0.out_stride;
     a.hist += (size_t)plane * kHistBins;
     a.n_oob += plane;
-    a.acc += (size_t)plane * kPredAccWords;
+    a.acc += (size_t)plane * kPredShards * kPredAccWords;
     a.inexact = a.acc + kAccInexact;
     // two branches with their own loads (caller's array / argument segment): a select between the two sources would be a select between
     // address spaces, and the copy behind it would go through scratch memory

@@ -38,6 +38,8 @@ struct FitArgs {
     const PredictParams *params;
     PredictParams pp3[3]; // plane k < 3 of a launch without a params array
     int32_t ablate;       // timing-only (tuning build, FRI_HIP_K4_ABLATE): 1 = no sums, 2 = tiles after the first are staged without their global loads
+    unsigned long long *trace; // diagnostic timeline (tuning build + FRI_HIP_TRACE=1), null in production
+    int32_t older_eighths;     // kernel2 with a full grid: eighths of a CU's tiles its first-dispatched workgroup walks (0: equal shares; see the kernel)
 };
 constexpr int kFitAccInt = 3 * 28, kFitAccDbl = kFitAccInt, kFitAccTicket = kFitAccInt + 18, kFitAccRange = kFitAccTicket + 1;
 static_assert(kFitAccRange + 1 == (int)kFitAccWords, "fit accumulator layout");
@@ -59,7 +61,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const F
     {
         const uint32_t plane = blockIdx.y;
         a.coefs = a0.coefs + plane * a0.coef_stride;
-        a.acc = a0.acc + (size_t)plane * kFitAccWords;
+        a.acc = a0.acc + (size_t)plane * kFitShards * kFitAccWords; // (this kernel uses the first of the plane's copies only)
         a.gram = a0.gram ? a0.gram + (size_t)plane * 3 * NI : nullptr;
         a.wtw = a0.wtw ? a0.wtw + (size_t)plane * 3 * NI : nullptr;
         a.wtr = a0.wtr ? a0.wtr + (size_t)plane * 18 : nullptr;
@@ -443,7 +445,8 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     constexpr int NI = MODE == 0 ? 28 : 21;
     const uint32_t plane = blockIdx.y;
     const int32_t *const coefs = a0.coefs + plane * a0.coef_stride;
-    unsigned long long *const accp = a0.acc + (size_t)plane * kFitAccWords;
+    unsigned long long *const accp = a0.acc + (size_t)plane * kFitShards * kFitAccWords;           // copy 0: ticket, out-of-range count
+    unsigned long long *const accs = accp + (size_t)(blockIdx.x % kFitShards) * kFitAccWords;       // this workgroup's copy of the sums
     PredictParams pp; // static indices only: a dynamic index into the argument struct would keep all of it in scratch memory
     if (a0.params)
         pp = a0.params[plane];
@@ -465,6 +468,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     if (tid < 3 * 28) (&s_int[0][0])[tid] = 0;
     if (tid < 18) (&s_dbl[0][0])[tid] = 0.0;
     if (tid == 0) s_range = 0;
+    trace_stamp(a0.trace, blockIdx.x, 0, tid);
 
     // The wave's pair of nodes per lane: wave & 3 = 0: level 7 (128 + 2 lane, + 1), 1: levels 0..6 (2 lane, + 1), 2 and 3: level 8 (256 + 4 lane +
     // {0, 1} and {2, 3}) - one layer group per wave, so the value parameters are scalars and a wave's sums have one destination.
@@ -496,13 +500,29 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     for (int k = 0; k < 28; k++) acc[k] = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) dacc[k] = 0.0;
-    int tiles_since_flush = 0;
+    int tiles_since_flush = 0, trace_it = 0;
     // the thread's two halo values per tile; entries >= 1024 - 122 of the list stage into the unused corner slot, where two of them may meet: harmless
     const uint32_t halo_e0 = a0.halo_list[tid], halo_e1 = a0.halo_list[tid + kPredThreads];
     const int block_a = fit2_block_slot(wave, 0), block_b = fit2_block_slot(wave, 1);
 
     const int ablate = ablate_flags(a0.ablate);
-    const PredTileWalk walk(a0.n_tiles);
+    PredTileWalk walk(a0.n_tiles);
+    // Two workgroups share a CU, and the one dispatched first keeps most of its issue slots (older waves win the arbitration): per-workgroup time
+    // stamps showed the second one taking 8-9 us per tile beside 4.7 us for the first, then running its last tiles alone on the CU - at the lower
+    // rate of a half-empty CU - long after the first had finished. As in K1 the split follows the dispatch rank: workgroups b and b + gridDim / 2
+    // (the pair of one CU under in-order dispatch; a wrong guess costs speed, never correctness) walk ONE strided sequence of tiles, the older one
+    // its first older_eighths / 8, the younger one the rest.
+    if (a0.older_eighths > 0 && gridDim.x >= 16u && gridDim.x % 16u == 0u) {
+        const uint32_t per_xcd = gridDim.x / 8u, pairs = per_xcd / 2u;                     // workgroups / pairs per XCD range
+        const uint32_t xcd = blockIdx.x % 8u, in_xcd = blockIdx.x / 8u, pair = in_xcd % pairs, younger = in_xcd / pairs;
+        const uint32_t lo = (uint32_t)((uint64_t)a0.n_tiles * xcd / 8u), hi = (uint32_t)((uint64_t)a0.n_tiles * (xcd + 1u) / 8u);
+        const uint32_t n_pair = lo + pair < hi ? (hi - lo - pair + pairs - 1u) / pairs : 0u; // tiles of the pair: lo + pair + pairs * k
+        const uint32_t n_older = min(n_pair, (n_pair * (uint32_t)a0.older_eighths + 3u) / 8u);
+        walk.step = pairs;
+        walk.first = lo + pair + (younger ? n_older * pairs : 0u);
+        walk.end = younger ? hi : min(hi, lo + pair + n_older * pairs);
+        if (walk.first > walk.end) walk.first = walk.end;
+    }
     uint32_t tile = walk.first;
     int next_raw = -1; // thread t < 36: slot t of the tile after the current one, requested a tile ahead
     auto slot_table = [&](int img, int raw) {
@@ -543,6 +563,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             tiles_since_flush = 0;                                                                                                               \
         }                                                                                                                                        \
         __syncthreads();                                                                                                                         \
+        trace_stamp(a0.trace, blockIdx.x, 2 + trace_it++, tid);                                                                                  \
         tile += walk.step;                                                                                                                       \
     }
     if (tile < walk.end) {
@@ -560,6 +581,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             fit2_halo_commit(h1, s_cells, halo_e1);
         }
         __syncthreads();
+        trace_stamp(a0.trace, blockIdx.x, 1, tid);
         while (true) {
             FRI_FIT2_PHASE(0)
             if (tile >= walk.end) break;
@@ -572,6 +594,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     // bound above), the four row totals through readlane into scalars, and lane 0 adds the group totals to LDS - 28 sums cost a wave
     // ~250 instructions. (The first kernel parks all lanes' sums in LDS and lets one thread per sum walk 32-64 of them: ~6 us per
     // workgroup, a tenth of the kernel.)
+    trace_stamp(a0.trace, blockIdx.x, 13, tid);
     fit2_wave_sums<NI>(acc, group, lane, s_int);
     if (MODE == 1) {
 #pragma unroll
@@ -583,28 +606,44 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         }
     }
     __syncthreads();
-    // hand-over: add into the plane's accumulator, draw a ticket, the last workgroup moves the totals out and re-zeroes
+    // hand-over: add into this workgroup's copy of the plane's accumulator, draw a ticket, the last workgroup sums the copies, moves the totals out
+    // and re-zeroes
     if (tid < 3 * NI) {
         const int gg = tid / NI, k = tid % NI;
-        __hip_atomic_fetch_add(accp + tid, s_int[gg][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(accs + tid, s_int[gg][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (MODE == 1 && tid < 18) __hip_atomic_fetch_add(reinterpret_cast<double *>(accp + kFitAccDbl) + tid, (&s_dbl[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (MODE == 1 && tid < 18) __hip_atomic_fetch_add(reinterpret_cast<double *>(accs + kFitAccDbl) + tid, (&s_dbl[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0 && s_range) __hip_atomic_fetch_add(accp + kFitAccRange, (unsigned long long)s_range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wait_for_own_memory_ops_then_barrier(); // every wave has waited for its adds before the ticket is drawn
     if (tid == 0) s_flag = __hip_atomic_fetch_add(accp + kFitAccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
+    trace_exit(a0.trace, blockIdx.x, tid);
     if (s_flag == 0) return;
-    // one wave moves everything out: its own vmcnt(0) then covers every store the flag below has to come after
+    // one wave moves everything out
     if (tid >= 64) return;
     unsigned long long *const out_int = (MODE == 0 ? a0.gram : a0.wtw) + (size_t)plane * 3 * NI;
     for (int i = tid; i < 3 * NI; i += 64) {
-        out_int[i] = __hip_atomic_load(accp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(accp + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long part[kFitShards], sum = 0;
+#pragma unroll
+        for (uint32_t sh = 0; sh < kFitShards; sh++) part[sh] = __hip_atomic_load(accp + sh * kFitAccWords + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // all in flight together
+#pragma unroll
+        for (uint32_t sh = 0; sh < kFitShards; sh++) {
+            sum += part[sh];
+            __hip_atomic_store(accp + sh * kFitAccWords + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        out_int[i] = sum;
     }
     if (MODE == 1 && tid < 18) {
-        const unsigned long long u = __hip_atomic_load(accp + kFitAccDbl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a0.wtr[(size_t)plane * 18 + tid] = __builtin_bit_cast(double, u);
-        __hip_atomic_store(accp + kFitAccDbl + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long part[kFitShards];
+        double sum = 0.0;
+#pragma unroll
+        for (uint32_t sh = 0; sh < kFitShards; sh++) part[sh] = __hip_atomic_load(accp + sh * kFitAccWords + kFitAccDbl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (uint32_t sh = 0; sh < kFitShards; sh++) {
+            sum += __builtin_bit_cast(double, part[sh]);
+            __hip_atomic_store(accp + sh * kFitAccWords + kFitAccDbl + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a0.wtr[(size_t)plane * 18 + tid] = sum;
     }
     if (tid == 0) {
         const unsigned long long r = __hip_atomic_exchange(accp + kFitAccRange, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -694,6 +733,8 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
     a.wtr = sums_dbl;
     a.out_range = out_of_range;
     a.ablate = p.k4_ablate;
+    a.trace = p.trace;
+    a.older_eighths = b.n_planes == 1 && p.hist_blocks <= p.n_pred_tiles ? p.k4_older_eighths : 0; // a plane on the whole machine: two co-resident workgroups per CU
     uint32_t blocks = p.n_pred_tiles < p.hist_blocks ? p.n_pred_tiles : p.hist_blocks;
     if (b.n_planes > 1) { // as in launch_predict_histogram: a plane on an eighth of the machine, eight planes side by side
         const uint32_t share = (p.n_pred_tiles + 7) / 8, eighth = p.hist_blocks / 8 ? p.hist_blocks / 8 : 1;

@@ -31,7 +31,9 @@ __global__ void __launch_bounds__(kStreamThreads) symbol_stream_kernel(const Str
     const uint8_t *bucket = a.bucket + plane * a.out_stride;
     uint16_t *out = a.out + plane * a.stream_stride;
     // a workgroup takes kStreamThreads * kStreamPerThread consecutive symbols; a thread's symbols are kStreamThreads apart (coalesced order reads and stream writes)
-    const uint64_t base = (uint64_t)blockIdx.x * (kStreamThreads * kStreamPerThread) + threadIdx.x;
+    // Consecutive stretches of the stream walk the same cells scan line after scan line, so the stretches an XCD's L2 sees must be neighbours: one contiguous
+    // range of the stream per XCD (dealt round-robin, every one of the 8 L2s fetched every cell: 1.15 GB of fetches for a 151 MB input).
+    const uint64_t base = (uint64_t)xcd_contiguous_share(blockIdx.x, gridDim.x) * (kStreamThreads * kStreamPerThread) + threadIdx.x;
     uint32_t node[kStreamPerThread];
 #pragma unroll
     for (int k = 0; k < kStreamPerThread; k++) {

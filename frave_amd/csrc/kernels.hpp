@@ -59,10 +59,18 @@ struct DevicePlan {
     bool k3_scan = false; // FRI_HIP_K3_SCAN=1: always use the scanning kernel (A/B)
     int32_t k3_ablate = 0; // same for the inverse kernel, see InvArgs::ablate
     int32_t k4_ablate = 0; // same for the fit kernel, see FitArgs::ablate
+    int32_t k4_older_eighths = 5; // fit kernel: share of a CU's tiles that goes to its first-dispatched workgroup, in eighths (FRI_HIP_K4_OLDER_EIGHTHS; 0 = equal shares)
 };
 
 constexpr uint32_t kPredJunkWaves = 16, kPredJunkBytes = 2560; // per wave: 512 B of bucket + 2 KiB of prediction
 constexpr uint32_t kFitAccWords = 3 * 28 + 18 + 2; // integer sums, f64 sums, ticket, out-of-range count
+// The fit kernel's 512 workgroups all add into the same ~100 words: at the memory side same-address atomics take ~12 ns each, so 512 arrivals per
+// word were 5-6 us of every launch (per-workgroup time stamps: "loop done" -> "ticket drawn"). The accumulator of a plane is therefore kept in
+// kFitShards copies, workgroup b adds into copy b % kFitShards, and the workgroup that draws the last ticket (copy 0 holds it) sums the copies.
+constexpr uint32_t kFitShards = 16;
+// (K2's accumulator is NOT sharded like the fit kernel's: tried with 4 copies - the last workgroup's copy-out, 40 loads and 40 stores per thread instead
+// of 10, cost more than the contention on the hot bins: K2 47.2 -> 49.3 us in an A/B on one box)
+constexpr uint32_t kPredShards = 1;
 constexpr uint32_t kPredAccRing = 8, kPredAccWords = 10 * 1024 + 8; // per plane: counts, out-of-alphabet count (u64), ticket, pad, "inexact" flag, the exact kernel's ticket, pad
 
 struct QMatrix {
@@ -88,7 +96,7 @@ struct PredBatch {
     const PredictParams *params = nullptr;
     PredictParams pp[3] = {}; // used when params is NULL: plane k takes pp[min(k, 2)] (one image's channels travel as kernel arguments)
 };
-// K2. acc: n_planes accumulators of kPredAccWords words, all zero between launches. hist [n_planes][10][1024], n_oob [n_planes].
+// K2. acc: n_planes accumulators of kPredShards x kPredAccWords words, all zero between launches. hist [n_planes][10][1024], n_oob [n_planes].
 // trust: what is known about the coefficients. kPredAnyInt32: nothing - the fast kernel checks what it stages and the exact int32 kernel behind it
 // redoes a plane whose values its LDS image cannot hold. kPredPromised: the caller promises the forward kernel's output (magnitudes <= 255,
 // fri_hip_plan_assume_forward_coefficients): still checked, no exact kernel, a broken promise comes back as n_oob = ~0. kPredForwardOutput: this
@@ -97,7 +105,7 @@ constexpr int kPredAnyInt32 = 0, kPredPromised = 1, kPredForwardOutput = 2;
 hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const PredBatch &b, uint8_t *bucket, int32_t *prediction, uint32_t *hist, unsigned long long *n_oob,
                                     int trust, hipStream_t stream);
 // Fit accumulators: mode 0 = value fit (sums_int[n_planes][3][28]), mode 1 = width fit (sums_int[n_planes][3][21], sums_dbl[n_planes][3][6]).
-// acc: n_planes accumulators of kFitAccWords words, all zero between launches.
+// acc: n_planes accumulators of kFitShards x kFitAccWords words, all zero between launches.
 // out_of_range (may be NULL): per plane, the number of waves that staged a Some coefficient outside [-256, 255] - the sums are then not to be trusted.
 hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
                                  unsigned long long *out_of_range, hipStream_t stream);

@@ -33,6 +33,24 @@ for k in range(2):
     t0 = time.perf_counter()
     frv = emit.encode_image(w, h, centers, co, b, pr, hist, vp, wp)
     print(f"encode_image call {k}: {time.perf_counter() - t0:.3f} s, {len(frv)} bytes")
+# The symbol stream route (K5 on the device): what is left for the host is contexts + rANS + container. The stream is built here with numpy from the
+# same arrays (on the device that is fri_hip_symbol_stream_batch_dev); the stream order is geometry and computed once per plan.
+import frave_amd
+
+P = frave_amd.Plan(None, w, h, c)  # host-only plan: the Some/None masks
+t0 = time.perf_counter()
+order = emit.stream_order(centers, P.valid_mask())
+print(f"stream_order (once per plan): {time.perf_counter() - t0:.3f} s, {len(order)} symbols per channel")
+streams = []
+for ch in range(c):
+    d = (co[ch].reshape(-1)[order].astype(np.int64) - pr[ch].reshape(-1)[order].astype(np.int64)).astype(np.int32)
+    sym = ((d.astype(np.uint32) << 1) ^ (d >> 31).astype(np.uint32)) & 1023
+    streams.append((b[ch].reshape(-1)[order].astype(np.uint32) << 10 | sym).astype(np.uint16))
+streams = np.stack(streams)
+for k in range(2):
+    t0 = time.perf_counter()
+    frv2 = emit.encode_image_from_streams(w, h, streams, hist, vp, wp)
+    print(f"encode_image_from_streams call {k}: {time.perf_counter() - t0:.3f} s, same bytes: {frv2 == frv}; device -> host per plane: {2 * len(order) / 1e6:.1f} MB instead of {9 * co[0].size / 1e6:.1f} MB")
 for k in range(2):
     t0 = time.perf_counter()
     out = emit.decode_image(frv)

@@ -44,11 +44,18 @@ def timed(fn, reps=20):
     return ev0.elapsed_time(ev1) / reps * 1e3
 
 
+if os.environ.get("K2_TRUSTED") == "1":  # the coefficients are K1's: no exact-int32 guard launch behind K2 (fri_hip_plan_assume_forward_coefficients)
+    plan.assume_forward_coefficients(True)
 k2 = timed(lambda: plan.predict_histogram_dev(d_co.data_ptr(), 0, vp, wp, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=s))
 k3 = timed(lambda: plan.inverse_transform_dev(d_co.data_ptr(), d_back.data_ptr(), stream=s))
 d_gi = torch.empty(3 * 28, dtype=torch.int64, device="cuda")
 d_gd = torch.empty(18, dtype=torch.float64, device="cuda")
 k4a = timed(lambda: plan.fit_value_sums_dev(d_co.data_ptr(), 0, d_gi.data_ptr(), stream=s))
 k4b = timed(lambda: plan.fit_width_sums_dev(d_co.data_ptr(), 0, vp, d_gi.data_ptr(), d_gd.data_ptr(), stream=s))
+k5 = float("nan")
+if os.environ.get("K5", "1") == "1" and C == 1 and SIZE <= 8192:  # the symbol stream kernel (needs the stream order: ~0.3 s of host time at 4096^2)
+    plan.set_stream_order()
+    d_st = torch.empty(plan.num_some, dtype=torch.uint16, device="cuda")
+    k5 = timed(lambda: plan.symbol_stream_batch_dev(1, d_co.data_ptr(), F * 512, d_b.data_ptr(), d_p.data_ptr(), F * 512, d_st.data_ptr(), plan.num_some, stream=s))
 ok = bool(torch.equal(d_back, d_px))
-print(f"data={kind} hist_blocks={os.environ.get('FRI_HIP_HIST_BLOCKS', 'default')}  K2 {k2:8.2f} us  K3 {k3:8.2f} us  fit_value {k4a:7.2f} us  fit_width {k4b:7.2f} us  roundtrip={ok}  hist_total={int(d_h.sum())} (expect {plan.num_some})")
+print(f"data={kind} hist_blocks={os.environ.get('FRI_HIP_HIST_BLOCKS', 'default')}  K2 {k2:8.2f} us  K3 {k3:8.2f} us  fit_value {k4a:7.2f} us  fit_width {k4b:7.2f} us  K5 {k5:7.2f} us  roundtrip={ok}  hist_total={int(d_h.sum())} (expect {plan.num_some})")
