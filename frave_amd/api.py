@@ -27,7 +27,7 @@ SYMBOLS = [
     "fri_hip_encode_image_dev", "fri_hip_inverse_transform_batch_dev", "fri_hip_predict_image", "fri_hip_predict_image_dev",
     "fri_hip_fit_params_batch_dev", "fri_hip_encode_image_batch_dev", "fri_hip_fit_value_params_batch_dev", "fri_hip_fit_width_params_batch_dev",
     "fri_hip_plan_assume_forward_coefficients", "fri_hip_encode_image_batch", "fri_hip_multi_encode_image",
-    "fri_hip_plan_set_stream_order", "fri_hip_symbol_stream_batch_dev", "fri_hip_encode_image_symbols",
+    "fri_hip_plan_set_stream_order", "fri_hip_symbol_stream_batch_dev", "fri_hip_encode_image_symbols", "fri_hip_encode_symbols_batch_dev",
 ]
 
 
@@ -144,6 +144,7 @@ def load_library():
     L.fri_hip_plan_set_stream_order.argtypes = [vp, vp, C.c_uint64]
     L.fri_hip_symbol_stream_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, vp, sz, vp]
     L.fri_hip_encode_image_symbols.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.fri_hip_encode_symbols_batch_dev.argtypes = [vp, u32, vp, sz, vp, i32, vp, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
     L.fri_hip_encode_image_batch.argtypes = [vp, u32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.fri_hip_multi_encode_image.argtypes = [vp, u32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.fri_hip_fit_value_params_batch_dev.argtypes = [vp, u32, vp, vp, vp]
@@ -344,6 +345,13 @@ class Plan:
     def symbol_stream_batch_dev(self, n_planes, d_coefs, coef_stride, d_bucket, d_prediction, out_stride, d_symbols, symbol_stride, stream=0):
         _check(load_library().fri_hip_symbol_stream_batch_dev(self._h, n_planes, d_coefs, coef_stride, d_bucket, d_prediction, out_stride, d_symbols, symbol_stride, stream),
                "fri_hip_symbol_stream_batch_dev", self.ctx)
+
+    def encode_symbols_batch_dev(self, n_images, d_pixels, pixel_stride, qmatrix, fit, d_params, d_coefs, coef_stride, d_node_words, word_stride, d_symbols, symbol_stride,
+                                 d_hist, d_oob, d_fit_range=0, stream=0):
+        """fri_hip_encode_symbols_batch_dev: forward -> [fit] -> scan (halfword form) -> gather into stream order; everything in device memory, asynchronous."""
+        q = _q(qmatrix)
+        _check(load_library().fri_hip_encode_symbols_batch_dev(self._h, n_images, d_pixels, pixel_stride, _p(q), 1 if fit else 0, d_params, d_coefs, coef_stride, d_node_words,
+                                                               word_stride, d_symbols, symbol_stride, d_hist, d_oob, d_fit_range, stream), "fri_hip_encode_symbols_batch_dev", self.ctx)
 
     def assume_forward_coefficients(self, on=True):
         """fri_hip_plan_assume_forward_coefficients: the predict entry points then skip the exact-kernel guard launch."""

@@ -97,6 +97,7 @@ struct fri_hip_plan {
     bool assume_forward = false; // fri_hip_plan_assume_forward_coefficients
     uint32_t *d_stream_order = nullptr; // fri_hip_plan_set_stream_order: node index of the i-th symbol of a channel, [geo.n_some]
     uint16_t *d_symbols = nullptr;      // fri_hip_encode_image_symbols: [C][geo.n_some]
+    uint16_t *d_words = nullptr;        // ... and the scan's halfword planes [C][F][512] the stream is gathered from
     uint32_t acc_next = 0;
     bool acc_dirty = false; // a launch on this plan failed: the accumulators are re-zeroed before the next use
     hipEvent_t ev_begin = nullptr, ev_end = nullptr; // timing helper's events, created with the plan (creating an event is not work to be timed)
@@ -560,6 +561,7 @@ int fri_hip_plan_destroy(fri_hip_plan *p) {
             if (d) (void)hipFree(d);
         if (p->d_stream_order) (void)hipFree(p->d_stream_order);
         if (p->d_symbols) (void)hipFree(p->d_symbols);
+        if (p->d_words) (void)hipFree(p->d_words);
         if (p->h_fit) (void)hipHostFree(p->h_fit);
         if (p->ev_fit) (void)hipEventDestroy(p->ev_fit);
         if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
@@ -932,11 +934,11 @@ void fri_hip_fit_width_params(const int64_t wtw[3][21], const double wtr[3][6], 
 }
 
 /* ---- the device part of FRIEncoder::encode in one call ------------------------------------------------ */
-static int ensure_encode_staging(fri_hip_plan *p) {
+static int ensure_encode_staging(fri_hip_plan *p, bool node_arrays = true) {
     fri_hip_ctx *c = p->ctx;
     const size_t C = p->geo.channels, plane = p->geo.centers.size() * kCell;
-    if (!p->d_bucket_all) HIP_TRY(c, hipMalloc((void **)&p->d_bucket_all, C * plane));
-    if (!p->d_prediction_all) HIP_TRY(c, hipMalloc((void **)&p->d_prediction_all, C * plane * sizeof(int32_t)));
+    if (node_arrays && !p->d_bucket_all) HIP_TRY(c, hipMalloc((void **)&p->d_bucket_all, C * plane));
+    if (node_arrays && !p->d_prediction_all) HIP_TRY(c, hipMalloc((void **)&p->d_prediction_all, C * plane * sizeof(int32_t)));
     if (!p->d_hist_all) HIP_TRY(c, hipMalloc((void **)&p->d_hist_all, C * 10 * 1024 * sizeof(uint32_t)));
     if (!p->d_oob_all) HIP_TRY(c, hipMalloc((void **)&p->d_oob_all, C * sizeof(unsigned long long)));
     return FRI_HIP_OK;
@@ -967,7 +969,7 @@ static int fit_chain(fri_hip_plan *p, const PredBatch &b, unsigned long long *d_
 // device-side fit above, then the parameters and the range counts come back through pinned memory behind an event the host waits for
 // while the scan kernel, already queued behind them, runs).
 static int predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, float *value_params, float *width_params, uint8_t *d_bucket, int32_t *d_prediction,
-                             uint32_t *d_hist, uint64_t *d_oob, int trust, hipStream_t s) {
+                             uint32_t *d_hist, uint64_t *d_oob, int trust, hipStream_t s, uint16_t *d_words = nullptr) {
     fri_hip_ctx *c = p->ctx;
     const uint32_t C = p->geo.channels;
     const size_t plane = p->geo.centers.size() * kCell;
@@ -976,6 +978,7 @@ static int predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, f
     b.coefs = d_coefs;
     b.coef_stride = plane;
     b.out_stride = plane;
+    b.words = d_words; // (the halfword form of the scan: see fri_hip_encode_image_symbols)
     if (!fit) {
         for (uint32_t ch = 0; ch < C; ch++) {
             std::memcpy(b.pp[ch].value, value_params + ch * 18, sizeof(b.pp[ch].value));
@@ -1060,6 +1063,38 @@ int fri_hip_encode_image_batch_dev(fri_hip_plan *p, uint32_t n_images, const uin
     if (fit)
         if (int rc = fit_chain(p, b, (unsigned long long *)d_fit_out_of_range, s)) return rc;
     return predict_launch(p, b, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, kPredForwardOutput, s);
+}
+
+// The same chain all the way to the emitter's input: the scan kernel writes one halfword per node (bucket << 10 | symbol) instead of bucket and
+// prediction arrays, and the gather kernel puts them in the reference's stream order. Asynchronous like the call above.
+int fri_hip_encode_symbols_batch_dev(fri_hip_plan *p, uint32_t n_images, const uint8_t *d_pixels, size_t pixel_stride, const int32_t qmatrix[32], int fit, float *d_params,
+                                     int32_t *d_coefs, size_t coef_stride, uint16_t *d_node_words, size_t word_stride, uint16_t *d_symbols, size_t symbol_stride,
+                                     uint32_t *d_hist, uint64_t *d_n_out_of_alphabet, uint64_t *d_fit_out_of_range, void *stream) {
+    if (int rc = need_device(p)) return rc;
+    const uint32_t C = p->geo.channels;
+    const size_t plane = p->geo.centers.size() * kCell, image = (size_t)C * plane, n = p->geo.n_some;
+    if (!d_pixels || !d_params || !d_coefs || !d_node_words || !d_symbols || !d_hist || !d_n_out_of_alphabet || !n_images || (uint64_t)n_images * C > 65535u || !p->d_stream_order)
+        return FRI_HIP_ERR_INVALID_ARGUMENT;
+    if (n_images > 1 && (pixel_stride < fri_hip_plan_pixel_bytes(p) || coef_stride < image || word_stride < image || symbol_stride < (size_t)C * n)) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    // evenly spaced planes, as above; a channel's stream follows the previous channel's
+    if (C > 1 && n_images > 1 && (coef_stride != image || word_stride != image || symbol_stride != (size_t)C * n)) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    QMatrix q;
+    if (int rc = check_q(qmatrix, q)) return rc;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, q, s));
+    PredBatch b;
+    b.n_planes = n_images * C;
+    b.coefs = d_coefs;
+    b.coef_stride = C > 1 ? plane : coef_stride;
+    b.out_stride = C > 1 ? plane : word_stride;
+    b.params = reinterpret_cast<const PredictParams *>(d_params);
+    b.words = d_node_words;
+    if (fit)
+        if (int rc = fit_chain(p, b, (unsigned long long *)d_fit_out_of_range, s)) return rc;
+    if (int rc = predict_launch(p, b, nullptr, nullptr, d_hist, d_n_out_of_alphabet, kPredForwardOutput, s)) return rc;
+    HIP_TRY(p->ctx, launch_symbol_gather(p->d_stream_order, n, b.n_planes, d_node_words, b.out_stride, d_symbols, C > 1 ? n : symbol_stride, s));
+    return FRI_HIP_OK;
 }
 
 int fri_hip_fit_value_params_batch_dev(fri_hip_plan *p, uint32_t n_planes, const int64_t *d_gram, float *d_params, void *stream) {
@@ -1273,14 +1308,18 @@ int fri_hip_encode_image_symbols(fri_hip_plan *p, const uint8_t *pixels, const i
     fri_hip_ctx *c = p->ctx;
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = ensure_staging(p)) return rc;
-    if (int rc = ensure_encode_staging(p)) return rc;
+    if (int rc = ensure_encode_staging(p, false)) return rc;
     const size_t C = p->geo.channels, plane = p->geo.centers.size() * kCell, n = p->geo.n_some;
     if (!p->d_symbols) HIP_TRY(c, hipMalloc((void **)&p->d_symbols, (C * n ? C * n : 1) * sizeof(uint16_t)));
+    if (!p->d_words) HIP_TRY(c, hipMalloc((void **)&p->d_words, C * plane * sizeof(uint16_t)));
+    QMatrix q;
+    if (int rc = check_q(qmatrix, q)) return rc;
     HIP_TRY(c, hipMemcpy(p->d_pixels, pixels, fri_hip_plan_pixel_bytes(p), hipMemcpyHostToDevice));
-    if (int rc = fri_hip_encode_image_dev(p, p->d_pixels, qmatrix, fit, value_params, width_params, p->d_coefs, p->d_bucket_all, p->d_prediction_all, p->d_hist_all,
-                                          (uint64_t *)p->d_oob_all, nullptr))
+    HIP_TRY(c, launch_fwd_transform_quant(p->dev, 1, p->d_pixels, 0, p->d_coefs, 0, q, nullptr));
+    // the scan in its halfword form (no bucket / prediction arrays are written at all), then the gather into stream order
+    if (int rc = predict_image_dev(p, p->d_coefs, fit, value_params, width_params, nullptr, nullptr, p->d_hist_all, (uint64_t *)p->d_oob_all, kPredForwardOutput, nullptr, p->d_words))
         return rc;
-    HIP_TRY(c, launch_symbol_stream(p->d_stream_order, n, (uint32_t)C, p->d_coefs, plane, p->d_bucket_all, p->d_prediction_all, plane, p->d_symbols, n, nullptr));
+    HIP_TRY(c, launch_symbol_gather(p->d_stream_order, n, (uint32_t)C, p->d_words, plane, p->d_symbols, n, nullptr));
     HIP_TRY(c, hipMemcpy(symbols, p->d_symbols, C * n * sizeof(uint16_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(hist, p->d_hist_all, C * 10 * 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(n_out_of_alphabet, p->d_oob_all, C * sizeof(uint64_t), hipMemcpyDeviceToHost));

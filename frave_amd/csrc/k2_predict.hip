@@ -67,6 +67,7 @@ struct PredArgs {
     unsigned long long *trace; // diagnostic timeline, null in production
     uint32_t *acc;             // plan scratch, all zero between launches: [kHistBins] counts, then kAccOob (u64), kAccTicket
     uint32_t n_tiles;
+    uint16_t *words;      // predict_histogram_kernel3<., true>: bucket << 10 | symbol per node, [n_planes] planes out_stride apart, INSTEAD of bucket / prediction
     int32_t trusted;      // the caller vouches for |coefficient| <= 256 (this library's forward kernel wrote them) and enqueues no exact kernel: a plane that
                           // raises `inexact` all the same reports n_oob = ~0 (an error the host maps to FRI_HIP_ERR_OUT_OF_RANGE) and lowers the flag itself
     PredictParams pp;     // this plane's parameters (filled per plane inside the kernel)
@@ -487,9 +488,11 @@ __device__ __forceinline__ int p3_node_of(int lane, int n) {
 // registers then never pass through a control-flow merge, where the compiler would copy all twelve. Heap nodes 0 and 1 (lane 0 of
 // role 0) belong to the LF predictor, which the prologue evaluates for all of the workgroup's tiles (p3_lf_finish): here they are computed like any node and masked.
 // Role 1 leaves as one dwordx4 + one dword store, role 0 as two dwordx2 + two short stores.
-template <int IMG, int ROLE, int CELL>
+// WORDS: the cell leaves as one halfword per node, bucket << 10 | symbol - the counter index the node bumped, which is what the emitter codes
+// (k5_stream.hip takes it from there) - instead of 5 bytes of bucket and prediction: role 1 one dwordx2, role 0 two dword stores to `wd`.
+template <int IMG, int ROLE, int CELL, bool WORDS>
 __device__ __forceinline__ void p3_half(const uint32_t (&addr)[4][6], float (&ga)[6], float (&gb)[6], const int (&own)[4], const PredictParams &pp, bool interior, uint32_t some4,
-                                        int lane, uint32_t *s_hist, const uint16_t *s_bkt, uint8_t *bd, int32_t *pd, uint8_t *junk, int ablate) {
+                                        int lane, uint32_t *s_hist, const uint16_t *s_bkt, uint8_t *bd, int32_t *pd, uint16_t *wd, uint8_t *junk, int ablate) {
     constexpr int kOff = IMG * kP3ImageBytes + CELL * kP3SlotBytes;
     uint32_t b12[4], bin[4], sym[4];
     int pred[4];
@@ -533,6 +536,21 @@ __device__ __forceinline__ void p3_half(const uint32_t (&addr)[4][6], float (&ga
         }
     }
     if (ablate & 4) pred[0] ^= (int)(bin[0] ^ bin[1] ^ bin[2] ^ bin[3]); // (timing only: keeps the bin arithmetic alive)
+    if (WORDS) {
+        // bin = 4 x (bucket << 10 | symbol) (out of alphabet: 4 x kHistBins, "bucket 10" - no such symbol may be emitted, n_out_of_alphabet says so);
+        // two nodes per dword: the low two bits of a bin are zero, so bin1 << 14 lands on bit 16
+        const uint32_t w01 = (bin[1] << 14) | (bin[0] >> 2), w23 = (bin[3] << 14) | (bin[2] >> 2);
+        if (ROLE) {
+            if (!(ablate & 32) || ((w01 ^ w23) == 0x12345678)) __builtin_nontemporal_store(i32x2{(int)w01, (int)w23}, reinterpret_cast<i32x2 *>(wd + 256) + lane);
+        } else {
+            uint32_t *q01 = lane == 0 ? reinterpret_cast<uint32_t *>(junk) : reinterpret_cast<uint32_t *>(wd) + lane; // nodes 0 and 1: the LF pass writes them
+            if (!(ablate & 32) || ((w01 ^ w23) == 0x12345678)) {
+                __builtin_nontemporal_store(w01, q01);
+                __builtin_nontemporal_store(w23, reinterpret_cast<uint32_t *>(wd + 128) + lane);
+            }
+        }
+        return;
+    }
     // bucket << 12 in each: byte 1 holds bucket << 4; collect the byte-1s, then one shift moves all the nibbles down.
     // Wave-uniform bases + a 32-bit lane offset: the stores address as saddr + voffset, no 64-bit pointer arithmetic per cell.
     if (ROLE) {
@@ -597,6 +615,7 @@ __device__ __forceinline__ void p3_lf_hop_b(const PredArgs &a, const int32_t *pl
     x.value = (plane + (size_t)cell * kCell)[n];
     x.mask0 = a.valid_mask[(size_t)cell * 16];
 }
+template <bool WORDS>
 __device__ __forceinline__ void p3_lf_finish(const PredArgs &a, uint32_t *s_hist, const P3LfItem &it, const P3LfValues &x) {
     const int cell = pred_slot_cell(it.raw);
     if (cell < 0) return;
@@ -608,7 +627,12 @@ __device__ __forceinline__ void p3_lf_finish(const PredArgs &a, uint32_t *s_hist
     p3_lf(v[0], v[1], v[2], b12, prediction);
     const bool some = pred_slot_interior(it.raw) || ((x.mask0 >> it.node) & 1u);
     const uint32_t sym = pack_signed(sub_w(x.value, prediction));
-    if (some) atomicAdd(&s_hist[sym < 1024u ? (b12 >> 2) + sym : (uint32_t)kHistBins], 1u);
+    const uint32_t counter = sym < 1024u ? (b12 >> 2) + sym : (uint32_t)kHistBins;
+    if (some) atomicAdd(&s_hist[counter], 1u);
+    if (WORDS) {
+        a.words[(size_t)cell * kCell + it.node] = (uint16_t)counter;
+        return;
+    }
     if (a.prediction) a.prediction[(size_t)cell * kCell + it.node] = some ? prediction : 0;
     if (a.bucket) a.bucket[(size_t)cell * kCell + it.node] = (uint8_t)(some ? b12 >> 12 : 0u);
 }
@@ -797,7 +821,7 @@ __device__ __forceinline__ i32x4 p3_load_own(const int32_t *cell_base, uint32_t 
 
 // OWN_CUR / OWN_NXT: the lane's own values (exact int32, for the residuals) of this tile's two cells and, loaded here, of the next
 // tile's; the two register sets swap roles from tile to tile (IMG), so nothing is copied.
-template <int IMG, int ROLE, bool CHECK>
+template <int IMG, int ROLE, bool CHECK, bool WORDS>
 __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane, P3Lds &lds, int it, bool more, uint32_t next2_tile, int tid, int lane, int wave, int slot_a,
                                         const P3Lane &L, float (&ga)[6], float (&gb)[6], const i32x4 (&own_cur)[2], i32x4 (&own_nxt)[2]) {
     uint32_t *s_hist = lds.hist;
@@ -831,6 +855,7 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
         const size_t junk = ((size_t)blockIdx.x * kP3Waves + wave) * kPredJunkBytes;
         uint8_t *bd = has && a.bucket ? a.bucket + (size_t)cell * kCell : a.junk + junk;
         int32_t *pd = has && a.prediction ? a.prediction + (size_t)cell * kCell : reinterpret_cast<int32_t *>(a.junk + junk + 512);
+        uint16_t *wd = WORDS && has ? a.words + (size_t)cell * kCell : reinterpret_cast<uint16_t *>(a.junk + junk + 512);
         uint32_t some4 = 0;
         if (!interior && has) { // boundary cell: node p is bit (p & 31) of mask word p >> 5
             const uint32_t *m = lds.masks[IMG][slot_a + c];
@@ -842,7 +867,14 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
             }
         }
         const int own4[4] = {own_cur[c].x, own_cur[c].y, own_cur[c].z, own_cur[c].w};
-        if (ablate_flags(a.ablate) & 1) {
+        if (WORDS && (ablate_flags(a.ablate) & 1)) {
+            if (ROLE) {
+                __builtin_nontemporal_store(i32x2{0, 0}, reinterpret_cast<i32x2 *>(wd + 256) + lane);
+            } else {
+                __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t *>(wd) + lane);
+                __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t *>(wd + 128) + lane);
+            }
+        } else if (ablate_flags(a.ablate) & 1) {
             if (ROLE) {
                 __builtin_nontemporal_store(i32x4{0, 0, 0, 0}, reinterpret_cast<i32x4 *>(pd + 256) + lane);
                 __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t *>(bd + 256) + lane);
@@ -853,9 +885,9 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
                 __builtin_nontemporal_store((uint16_t)0, reinterpret_cast<uint16_t *>(bd + 128) + lane);
             }
         } else if (c == 0) {
-            p3_half<IMG, ROLE, 0>(L.addr, ga, gb, own4, a.pp, interior, some4, lane, s_hist, s_bkt, bd, pd, a.junk + junk, ablate_flags(a.ablate));
+            p3_half<IMG, ROLE, 0, WORDS>(L.addr, ga, gb, own4, a.pp, interior, some4, lane, s_hist, s_bkt, bd, pd, wd, a.junk + junk, ablate_flags(a.ablate));
         } else {
-            p3_half<IMG, ROLE, 1>(L.addr, ga, gb, own4, a.pp, interior, some4, lane, s_hist, s_bkt, bd, pd, a.junk + junk, ablate_flags(a.ablate));
+            p3_half<IMG, ROLE, 1, WORDS>(L.addr, ga, gb, own4, a.pp, interior, some4, lane, s_hist, s_bkt, bd, pd, wd, a.junk + junk, ablate_flags(a.ablate));
         }
     }
 
@@ -885,7 +917,7 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
     trace_stamp(a.trace, blockIdx.x, 2 + it, tid);
 }
 
-template <int ROLE, bool CHECK>
+template <int ROLE, bool CHECK, bool WORDS>
 __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, int lane, int wave) {
     uint8_t *s_cells = lds.cells[0];
     int32_t *s_ring = &lds.ring[0][0];
@@ -954,7 +986,7 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
         }
         m = __builtin_fmaxf(m, p3_commit_halo<CHECK>(st_halo, s_cells, L.halo_lds));
         if (CHECK) p3_check(m, lane, a.inexact);
-        if (ROLE == 1 && !(ablate_flags(a.ablate) & 1)) p3_lf_finish(a, lds.hist, lf_item, lf_values);
+        if (ROLE == 1 && !(ablate_flags(a.ablate) & 1)) p3_lf_finish<WORDS>(a, lds.hist, lf_item, lf_values);
     }
     if (ROLE == 1) {
         for (uint32_t base = kLfTilesPerPass; base < my_tiles; base += kLfTilesPerPass) { // more than 16 tiles per workgroup (large images): further passes, two round trips each
@@ -963,7 +995,7 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
             P3LfValues x;
             p3_lf_hop_a(a, walk.first + k * walk.step, k < my_tiles, lf_tid, it);
             p3_lf_hop_b(a, plane, it, x);
-            if (!(ablate_flags(a.ablate) & 1)) p3_lf_finish(a, lds.hist, it, x);
+            if (!(ablate_flags(a.ablate) & 1)) p3_lf_finish<WORDS>(a, lds.hist, it, x);
         }
     }
     __syncthreads();
@@ -971,10 +1003,10 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
 
     int it = 0;
     for (uint32_t tile = walk.first; tile < walk.end;) { // unrolled by two: the LDS image a tile lives in is a compile-time constant
-        p3_tile<0, ROLE, CHECK>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_a, own_b);
+        p3_tile<0, ROLE, CHECK, WORDS>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_a, own_b);
         tile += walk.step, it++;
         if (tile >= walk.end) break;
-        p3_tile<1, ROLE, CHECK>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_b, own_a);
+        p3_tile<1, ROLE, CHECK, WORDS>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_b, own_a);
         tile += walk.step, it++;
     }
 }
@@ -984,6 +1016,7 @@ __device__ __forceinline__ PredArgs pred_plane_view(const PredArgs &a0, uint32_t
     a.coefs += plane * a0.coef_stride;
     if (a.bucket) a.bucket += plane * a0.out_stride;
     if (a.prediction) a.prediction += plane * a0.out_stride;
+    if (a.words) a.words += plane * a0.out_stride;
     a.hist += (size_t)plane * kHistBins;
     a.n_oob += plane;
     a.acc += (size_t)plane * kPredShards * kPredAccWords;
@@ -1005,7 +1038,8 @@ __device__ __forceinline__ PredArgs pred_plane_view(const PredArgs &a0, uint32_t
 // CHECK = false: the coefficients were written by this library's forward kernel in the same chain (fri_hip_encode_image*): every magnitude is
 // <= 255 by construction and the staging does not look (18 max operations per lane and tile). CHECK = true: any int32 array; a value the LDS image
 // cannot hold raises the plane's `inexact` flag (see PredArgs::trusted for what happens then).
-template <bool CHECK>
+// WORDS: see p3_half (instantiated for the library's own coefficients only).
+template <bool CHECK, bool WORDS>
 __global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const PredArgs a0) {
     const PredArgs a = pred_plane_view(a0, blockIdx.y);
     __shared__ __attribute__((aligned(16))) P3Lds lds;
@@ -1021,9 +1055,9 @@ __global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const Pr
     for (int i = tid; i < 2 * (kP3ImageBytes - kP3ZeroOff) / 4; i += kP3Threads) // the zero words behind the cells of both images
         reinterpret_cast<uint32_t *>(s_cells + (i / ((kP3ImageBytes - kP3ZeroOff) / 4)) * kP3ImageBytes + kP3ZeroOff)[i % ((kP3ImageBytes - kP3ZeroOff) / 4)] = 0;
     if (wave & 1)
-        p3_run<1, CHECK>(a, lds, tid, lane, wave);
+        p3_run<1, CHECK, WORDS>(a, lds, tid, lane, wave);
     else
-        p3_run<0, CHECK>(a, lds, tid, lane, wave);
+        p3_run<0, CHECK, WORDS>(a, lds, tid, lane, wave);
     __syncthreads();
     trace_stamp(a.trace, blockIdx.x, 13, tid);
     pred_hand_over(a, s_hist, reinterpret_cast<uint32_t *>(s_ring), tid, kP3Threads);
@@ -1122,6 +1156,8 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const Pr
     a.n_oob = n_oob;
     a.n_tiles = p.n_pred_tiles;
     a.trusted = trust != kPredAnyInt32 ? 1 : 0;
+    a.words = b.words;
+    if (b.words && (trust != kPredForwardOutput || p.k2_previous)) return hipErrorInvalidValue; // the halfword form exists for the chain's own coefficients only
     // One plane: a workgroup per CU. Many planes: a plane keeps an eighth of the machine busy (at least ~8 tiles per workgroup, so that
     // the start-up and the hand-over are paid once per 8 tiles) and eight planes run side by side.
     uint32_t blocks = p.n_pred_tiles < p.pred_blocks ? p.n_pred_tiles : p.pred_blocks;
@@ -1148,10 +1184,12 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const Pr
     a.halo_list = p.halo_list;
     a.ablate = p.k2_ablate;
     (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
-    if (trust == kPredForwardOutput)
-        hipLaunchKernelGGL(predict_histogram_kernel3<false>, dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
+    if (b.words)
+        hipLaunchKernelGGL((predict_histogram_kernel3<false, true>), dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
+    else if (trust == kPredForwardOutput)
+        hipLaunchKernelGGL((predict_histogram_kernel3<false, false>), dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
     else
-        hipLaunchKernelGGL(predict_histogram_kernel3<true>, dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
+        hipLaunchKernelGGL((predict_histogram_kernel3<true, false>), dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess || trust != kPredAnyInt32) return e; // the forward kernel's coefficients are differences of 8-bit pixels divided by a quantiser: always representable
     ExactArgs x{};

@@ -54,7 +54,67 @@ __global__ void __launch_bounds__(kStreamThreads) symbol_stream_kernel(const Str
     }
 }
 
+// The same stream from the halfword-per-node planes the scan kernel writes in its WORDS form (k2_predict.hip: bucket << 10 | symbol, the counter the node
+// bumped): one 2-byte gather per symbol out of a 34 MB plane instead of three gathers (4 + 4 + 1 bytes) out of 151 MB, and the scan kernel stores 2 bytes per
+// node instead of 5. A wave takes 512 consecutive symbols (2 KB of order in, 1 KB of stream out). The chunks are laid on the 16-byte grid of the OUTPUT
+// address (a channel's stream starts wherever the previous one ended), so every store but a plane's first and last is one dwordx4.
+struct GatherArgs {
+    const uint32_t *order;
+    const uint16_t *words;
+    uint16_t *out;
+    uint64_t n_symbols;
+    size_t word_stride, stream_stride;
+};
+constexpr int kGatherThreads = 256;
+
+__global__ void __launch_bounds__(kGatherThreads) symbol_gather_kernel(const GatherArgs a) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_t[kGatherThreads * 8];
+    const uint32_t plane = blockIdx.y;
+    const uint16_t *words = a.words + plane * a.word_stride;
+    uint16_t *out = a.out + plane * a.stream_stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t lead = (int64_t)((reinterpret_cast<uintptr_t>(out) >> 1) & 7u); // halfwords between the 16-byte grid and the stream's start
+    // a wave takes 512 consecutive symbols; in gather k lane l fetches symbol 64 k + l, so the 64 gathers of one instruction are 64 NEIGHBOURS of the stream -
+    // a scan-line stretch through three or four cells, a handful of 64-byte lines - where a lane-owns-eight-symbols split touches 64 lines per instruction
+    // (55 us against 118 for the three-array kernel, the texture addresser the limit). The halfwords turn through LDS into the lane-owns-eight layout of the stores.
+    const int64_t wave_first = ((int64_t)xcd_contiguous_share(blockIdx.x, gridDim.x) * (kGatherThreads / 64) + wave) * 512 - lead;
+    const int64_t n = (int64_t)a.n_symbols;
+    if (wave_first >= n) return;
+    uint16_t *t = s_t + wave * 512;
+    if (wave_first >= 0 && wave_first + 512 <= n) {
+        uint32_t o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[k] = __builtin_nontemporal_load(a.order + wave_first + 64 * k + lane);
+        uint16_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = words[o[k]];
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[64 * k + lane] = w[k];
+        // (the wave reads what the wave wrote: no workgroup barrier; the compiler's own waits order the LDS traffic of a wave)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        const u32x4 v = reinterpret_cast<const u32x4 *>(t)[lane];
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out + wave_first) + lane);
+        return;
+    }
+    for (int64_t i = (wave_first < 0 ? 0 : wave_first) + lane; i < wave_first + 512 && i < n; i += 64) out[i] = words[a.order[i]]; // the two ragged ends of a plane
+}
+
 } // namespace
+
+hipError_t launch_symbol_gather(const uint32_t *order, uint64_t n_symbols, uint32_t n_planes, const uint16_t *words, size_t word_stride, uint16_t *out, size_t stream_stride,
+                                hipStream_t stream) {
+    if (!order || !words || !out || !n_planes || n_planes > 65535u || (reinterpret_cast<uintptr_t>(order) & 15u)) return hipErrorInvalidValue;
+    if (!n_symbols) return hipSuccess;
+    GatherArgs a{};
+    a.order = order, a.words = words, a.out = out, a.n_symbols = n_symbols, a.word_stride = word_stride, a.stream_stride = stream_stride;
+    const uint64_t per_wg = (uint64_t)kGatherThreads * 8;
+    const uint64_t blocks = (n_symbols + 7 + per_wg - 1) / per_wg; // + 7: the lead of a stream that does not start on the 16-byte grid
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(symbol_gather_kernel, dim3((uint32_t)blocks, n_planes), dim3(kGatherThreads), 0, stream, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_symbol_stream(const uint32_t *order, uint64_t n_symbols, uint32_t n_planes, const int32_t *coefs, size_t coef_stride, const uint8_t *bucket,
                                 const int32_t *prediction, size_t out_stride, uint16_t *out, size_t stream_stride, hipStream_t stream) {

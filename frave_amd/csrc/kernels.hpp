@@ -95,6 +95,7 @@ struct PredBatch {
     size_t coef_stride = 0, out_stride = 0;
     const PredictParams *params = nullptr;
     PredictParams pp[3] = {}; // used when params is NULL: plane k takes pp[min(k, 2)] (one image's channels travel as kernel arguments)
+    uint16_t *words = nullptr; // K2 only, with kPredForwardOutput only: write bucket << 10 | symbol per node ([n_planes] planes, out_stride apart) and neither bucket nor prediction
 };
 // K2. acc: n_planes accumulators of kPredShards x kPredAccWords words, all zero between launches. hist [n_planes][10][1024], n_oob [n_planes].
 // trust: what is known about the coefficients. kPredAnyInt32: nothing - the fast kernel checks what it stages and the exact int32 kernel behind it
@@ -120,8 +121,11 @@ hipError_t launch_fit_solve(int mode, uint32_t n_planes, const unsigned long lon
 hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, const int32_t *coefs, size_t coef_stride, const QMatrix &q, uint8_t *pixels, size_t pixel_stride,
                                     hipStream_t stream);
 
-// K5: the symbol stream of n_planes planes: out[k][i] = bucket << 10 | pack_signed(coef - prediction) of node order[i] (order: n_symbols entries,
-// cell << 9 | heap index in the reference's stream order with the None nodes taken out).
+// K5, gather form: out[i] = words[order[i]] for the halfword planes K2 writes with PredBatch::words (order: n_symbols entries, cell << 9 | heap index in
+// the reference's stream order with the None nodes taken out; 16-byte aligned).
+hipError_t launch_symbol_gather(const uint32_t *order, uint64_t n_symbols, uint32_t n_planes, const uint16_t *words, size_t word_stride, uint16_t *out, size_t stream_stride,
+                                hipStream_t stream);
+// K5 from the three arrays of the scan's array form: out[k][i] = bucket << 10 | pack_signed(coef - prediction) of node order[i].
 hipError_t launch_symbol_stream(const uint32_t *order, uint64_t n_symbols, uint32_t n_planes, const int32_t *coefs, size_t coef_stride, const uint8_t *bucket,
                                 const int32_t *prediction, size_t out_stride, uint16_t *out, size_t stream_stride, hipStream_t stream);
 

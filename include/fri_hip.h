@@ -299,8 +299,18 @@ int fri_hip_plan_set_stream_order(fri_hip_plan *plan, const uint32_t *order, uin
 int fri_hip_symbol_stream_batch_dev(fri_hip_plan *plan, uint32_t n_planes, const int32_t *d_coefs, size_t coef_stride, const uint8_t *d_bucket, const int32_t *d_prediction,
                                     size_t out_stride, uint16_t *d_symbols, size_t symbol_stride, void *stream);
 
-/* The device part of FRIEncoder::encode all the way to the emitter's input, for host buffers: fri_hip_encode_image's chain followed by the symbol
- * stream kernel; what comes back is symbols[C][num_some] (2 bytes per symbol) + hist + parameters + n_out_of_alphabet - 17 MB up and 34 MB down per
+/* The asynchronous chain of fri_hip_encode_image_batch_dev all the way to the emitter's input, everything in device memory: forward transform ->
+ * [fit] -> the scan kernel in its halfword form -> gather into stream order. The scan then writes ONE halfword per node, d_node_words[k][C][F][512] =
+ * bucket << 10 | symbol (the index of the counter the node bumped; None nodes: unspecified; a symbol >= 1024: 10 << 10, "bucket 10" - such a plane has
+ * n_out_of_alphabet != 0 and must not be emitted), and neither bucket nor prediction arrays: 2 bytes per node of stores instead of 5, and the gather
+ * reads 2 bytes per symbol instead of 9. d_symbols[k][C][num_some] as in fri_hip_symbol_stream_batch_dev (image k at k * symbol_stride halfwords, a
+ * channel's stream directly behind the previous channel's). With channels == 3 and n_images > 1 the images must lie back to back (coef_stride ==
+ * word_stride == 3 * F * 512, symbol_stride == 3 * num_some). Other arguments as in fri_hip_encode_image_batch_dev. Needs fri_hip_plan_set_stream_order. */
+int fri_hip_encode_symbols_batch_dev(fri_hip_plan *plan, uint32_t n_images, const uint8_t *d_pixels, size_t pixel_stride, const int32_t qmatrix[32], int fit, float *d_params,
+                                     int32_t *d_coefs, size_t coef_stride, uint16_t *d_node_words, size_t word_stride, uint16_t *d_symbols, size_t symbol_stride,
+                                     uint32_t *d_hist, uint64_t *d_n_out_of_alphabet, uint64_t *d_fit_out_of_range, void *stream);
+
+/* The device part of FRIEncoder::encode all the way to the emitter's input, for host buffers: the chain above for one image; what comes back is symbols[C][num_some] (2 bytes per symbol) + hist + parameters + n_out_of_alphabet - 17 MB up and 34 MB down per
  * 4096 x 4096 plane where fri_hip_encode_image moves 17 MB up and 153 MB down. Needs fri_hip_plan_set_stream_order. Argument meaning as fri_hip_encode_image. */
 int fri_hip_encode_image_symbols(fri_hip_plan *plan, const uint8_t *pixels, const int32_t qmatrix[32], int fit, float *value_params, float *width_params, uint16_t *symbols,
                                  uint32_t *hist, uint64_t *n_out_of_alphabet);

@@ -308,6 +308,38 @@ def test_symbol_stream_on_the_device(shape):
     if w <= 640:
         dw, dh, dc, centers, coefs = emit.decode_image(from_streams)
         assert np.array_equal(coefs, co)
+    # The halfword route (fri_hip_encode_symbols_batch_dev: the scan writes bucket << 10 | symbol per node, one 2-byte gather per symbol): two images in one
+    # chain, the first the image above - same streams, histograms and parameters as the array route; the node words are the counters the nodes bumped.
+    n_img = 2
+    img2 = np.stack([img, _mixed_image(w, h, c, 14)])
+    d_px2 = torch.from_numpy(img2.reshape(-1)).cuda()
+    d_co2 = torch.empty((n_img, c, plane), dtype=torch.int32, device="cuda")
+    d_w2 = torch.full((n_img, c, plane), 0xEEEE, dtype=torch.uint16, device="cuda")
+    d_st2 = torch.full((n_img * c * n + 8,), 0xFFFF, dtype=torch.uint16, device="cuda")
+    d_h2 = torch.empty((n_img, c, 10, 1024), dtype=torch.int32, device="cuda")
+    d_o2 = torch.empty((n_img, c), dtype=torch.int64, device="cuda")
+    d_par2 = torch.zeros((n_img, c, 2, 3, 6), dtype=torch.float32, device="cuda")
+    d_r2 = torch.zeros((n_img, c), dtype=torch.int64, device="cuda")
+    P.encode_symbols_batch_dev(n_img, d_px2.data_ptr(), P.pixel_bytes, None, True, d_par2.data_ptr(), d_co2.data_ptr(), c * plane, d_w2.data_ptr(), c * plane, d_st2.data_ptr(),
+                               c * n, d_h2.data_ptr(), d_o2.data_ptr(), d_r2.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    assert int(d_o2.abs().sum()) == 0 and int(d_r2.abs().sum()) == 0
+    st2 = d_st2.cpu().numpy()
+    assert (st2[n_img * c * n:] == 0xFFFF).all()
+    st2 = st2[: n_img * c * n].reshape(n_img, c, n)
+    assert np.array_equal(st2[0], st[:, :n]) and np.array_equal(d_h2[0].cpu().numpy(), d_h.cpu().numpy()) and np.array_equal(d_par2[0].cpu().numpy(), par)
+    assert np.array_equal(d_co2[0].cpu().numpy().reshape(c, F, 512), co)
+    words = d_w2.cpu().numpy().reshape(n_img, c, -1)
+    for k in range(n_img):
+        for ch in range(c):
+            assert np.array_equal(words[k, ch][order], st2[k, ch])  # the stream is the gather of the node words ...
+            assert np.array_equal(np.bincount(st2[k, ch], minlength=10240), d_h2[k, ch].cpu().numpy().reshape(-1))  # ... and the histogram counts exactly them
+    # second image against the array route run on it alone
+    P.encode_image_batch_dev(1, d_px2[P.pixel_bytes:].data_ptr(), P.pixel_bytes, d_par.data_ptr(), d_co.data_ptr(), c * plane, d_b.data_ptr(), d_p.data_ptr(), c * plane, d_h.data_ptr(),
+                             d_o.data_ptr(), fit=True, stream=s)
+    torch.cuda.synchronize()
+    co, b, p = d_co.cpu().numpy().reshape(c, F, 512), d_b.cpu().numpy().reshape(c, F, 512), d_p.cpu().numpy().reshape(c, F, 512)
+    assert np.array_equal(st2[1], _numpy_streams(order, co, b, p))
     P.close()
 
 

@@ -57,5 +57,13 @@ if os.environ.get("K5", "1") == "1" and C == 1 and SIZE <= 8192:  # the symbol s
     plan.set_stream_order()
     d_st = torch.empty(plan.num_some, dtype=torch.uint16, device="cuda")
     k5 = timed(lambda: plan.symbol_stream_batch_dev(1, d_co.data_ptr(), F * 512, d_b.data_ptr(), d_p.data_ptr(), F * 512, d_st.data_ptr(), plan.num_some, stream=s))
+    # the halfword route: forward -> scan (2 B per node out) -> gather (2 B per symbol in), next to the array route's forward -> scan
+    d_par = torch.from_numpy(np.concatenate([np.asarray(vp, np.float32).reshape(-1), np.asarray(wp, np.float32).reshape(-1)])).cuda()
+    d_w = torch.empty(F * 512, dtype=torch.uint16, device="cuda")
+    ca = timed(lambda: plan.encode_image_batch_dev(1, d_px.data_ptr(), plan.pixel_bytes, d_par.data_ptr(), d_co.data_ptr(), F * 512, d_b.data_ptr(), d_p.data_ptr(), F * 512,
+                                                   d_h.data_ptr(), d_o.data_ptr(), fit=False, stream=s))
+    cw = timed(lambda: plan.encode_symbols_batch_dev(1, d_px.data_ptr(), plan.pixel_bytes, None, False, d_par.data_ptr(), d_co.data_ptr(), F * 512, d_w.data_ptr(), F * 512,
+                                                     d_st.data_ptr(), plan.num_some, d_h.data_ptr(), d_o.data_ptr(), stream=s))
+    print(f"chain forward -> scan (arrays) {ca:7.2f} us; forward -> scan (halfwords) -> gather {cw:7.2f} us")
 ok = bool(torch.equal(d_back, d_px))
 print(f"data={kind} hist_blocks={os.environ.get('FRI_HIP_HIST_BLOCKS', 'default')}  K2 {k2:8.2f} us  K3 {k3:8.2f} us  fit_value {k4a:7.2f} us  fit_width {k4b:7.2f} us  K5 {k5:7.2f} us  roundtrip={ok}  hist_total={int(d_h.sum())} (expect {plan.num_some})")
