@@ -56,7 +56,7 @@ struct PredArgs {
     size_t coef_stride, out_stride;
     const PredictParams *params;
     int32_t ablate;            // timing-only (tuning build, FRI_HIP_K2_ABLATE): 1 = no predict phase (zeros are stored), 2 = tiles after the first are not staged,
-                               // 4 = no histogram update, 8 = no bucket-table read, 16 = no gathers, 32 = no output stores
+                               // 4 = no histogram update, 32 = no output stores (8 = no bucket-table read and 16 = no gathers are retired: see p3_half)
     const uint8_t *interior;   // [F]
     const uint32_t *valid_mask; // [F][16]
     uint8_t *bucket;
@@ -444,9 +444,33 @@ __device__ __forceinline__ void p3_issue_wait(float (&nxt)[6], const uint32_t (&
                    "+v"(cur[5])
                  : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "n"(OFFSET));
 }
-__device__ __forceinline__ void p3_wait(float (&cur)[6]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]));
+// The bucket-table read of the PREVIOUS node (assign_bucket as a 32-entry LDS table) rides in front of the block's gathers: it is older than the six
+// loads lgkmcnt(6) leaves in flight, so it has landed when the block ends. As a plain C++ load the compiler tracked it with its own counter - which does
+// not know the asm's loads - and put `s_waitcnt lgkmcnt(0)` in front of its first use, directly behind the block that had just issued the next node's
+// gathers: every node then waited for the full latency of the gathers meant to fly during its arithmetic.
+template <int OFFSET>
+__device__ __forceinline__ void p3_issue_wait_tbl(float (&nxt)[6], const uint32_t (&a)[6], float (&cur)[6], uint32_t &tbl, uint32_t tbl_addr) {
+    asm volatile("ds_read_u16 %12, %19\n\t"
+                 "ds_read_u16_d16_hi %0, %13 offset:%20\n\t"
+                 "ds_read_u16_d16_hi %1, %14 offset:%20\n\t"
+                 "ds_read_u16_d16_hi %2, %15 offset:%20\n\t"
+                 "ds_read_u16_d16_hi %3, %16 offset:%20\n\t"
+                 "ds_read_u16_d16_hi %4, %17 offset:%20\n\t"
+                 "ds_read_u16_d16_hi %5, %18 offset:%20\n\t"
+                 "s_waitcnt lgkmcnt(6)"
+                 : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]), "+v"(nxt[5]), "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]),
+                   "+v"(cur[5]), "=&v"(tbl)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(tbl_addr), "n"(OFFSET));
 }
+__device__ __forceinline__ void p3_wait_tbl(float (&cur)[6], uint32_t &tbl, uint32_t tbl_addr) {
+    asm volatile("ds_read_u16 %6, %7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "=&v"(tbl)
+                 : "v"(tbl_addr));
+}
+// the last node's table read: issued, landed a few instructions later (p3_tbl_land) - nothing else of the wave is in flight in LDS then
+__device__ __forceinline__ void p3_tbl_issue(uint32_t &tbl, uint32_t tbl_addr) { asm volatile("ds_read_u16 %0, %1" : "=&v"(tbl) : "v"(tbl_addr)); }
+__device__ __forceinline__ void p3_tbl_land(uint32_t &tbl) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tbl)); }
 
 // get_hf_context_bucket (prediction.rs:151-207) on f32 neighbour values: left to right, one rounding per operation. The reference
 // takes |a - b| on i32 and converts; for |a|, |b| <= 256 the difference of the two floats is the same exact value, and the
@@ -496,25 +520,38 @@ __device__ __forceinline__ void p3_half(const uint32_t (&addr)[4][6], float (&ga
     constexpr int kOff = IMG * kP3ImageBytes + CELL * kP3SlotBytes;
     uint32_t b12[4], bin[4], sym[4];
     int pred[4];
-    if (!(ablate & 16)) p3_issue<kOff>(ga, addr[0]);
+    const uint32_t bkt_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint16_t *)s_bkt;
+    uint32_t tbl_addr[4];
+    p3_issue<kOff>(ga, addr[0]);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        // the next node's gathers fly while this node is evaluated; the two register sets alternate
+        // the next node's gathers fly while this node is evaluated; the two register sets alternate. (No timing-only switch in here: a runtime branch
+        // around a block makes the compiler copy gather registers at the merge - while their loads are in flight.)
         float(&g)[6] = (j & 1) ? gb : ga;
         float(&gn)[6] = (j & 1) ? ga : gb;
-        if (ablate & 16) { // timing only: no gathers
-        } else if (j < 3)
-            p3_issue_wait<kOff>(gn, addr[j + 1], g);
+        // Issue priority falls with the wave's progress through the tile (3, 3, 2, 2 | 1, 1, 0, 0 over its eight nodes): the arbiter otherwise prefers the
+        // OLDER of a SIMD's four waves at every conflict, waves 0-3 reach the tile's barrier 1.2-1.5 us before waves 12-15 (tools/trace_k2_waves.py), and
+        // each tile ends with SIMDs issuing from a single wave. With the laggard always the preferred one the four advance together (K2 -2.3 us at 4096^2;
+        // a static priority per wave only changes who waits for whom and gained nothing).
+        if (j == 0) __builtin_amdgcn_s_setprio(CELL ? 1 : 3);
+        if (j == 2) __builtin_amdgcn_s_setprio(CELL ? 0 : 2);
+        if (j == 0)
+            p3_issue_wait<kOff>(gn, addr[1], g);
+        else if (j < 3)
+            p3_issue_wait_tbl<kOff>(gn, addr[j + 1], g, b12[j - 1], tbl_addr[j - 1]);
         else
-            p3_wait(g);
+            p3_wait_tbl(g, b12[2], tbl_addr[2]);
+        if (j > 0) bin[j - 1] = b12[j - 1] + (sym[j - 1] << 2); // byte offset of the counter in the 10 x 1024 table
         const P3Group q = p3_group(pp, ROLE ? 0 : j < 2 ? 2 : 1); // uniform: scalar registers
         float width, pf;
         p3_node_math(g, q, width, pf);
-        b12[j] = (ablate & 8) ? (f32_as_u32(width) & 7u) << 12 : s_bkt[min(f32_as_u32(width), 31u)]; // assign_bucket (prediction.rs:55-68) as a 32-entry table of bucket << 12
+        tbl_addr[j] = bkt_lds + 2u * min(f32_as_u32(width), 31u); // assign_bucket (prediction.rs:55-68) as a 32-entry table of bucket << 12
         pred[j] = f32_as_i32(pf);
         sym[j] = pack_signed(sub_w(own[j], pred[j]));
-        bin[j] = b12[j] + (sym[j] << 2); // byte offset of the counter in the 10 x 1024 table
     }
+    p3_tbl_issue(b12[3], tbl_addr[3]);
+    p3_tbl_land(b12[3]);
+    bin[3] = b12[3] + (sym[3] << 2);
     // out of alphabet (entropy_coding.rs:99 would panic): counted apart. One test for the four nodes.
     if (__builtin_expect(__any((sym[0] | sym[1] | sym[2] | sym[3]) >= 1024u), 0)) {
 #pragma unroll

@@ -3,7 +3,8 @@
 
 The gathers are inline-asm ds_read_u16_d16_hi whose completion the compiler does not track: a block issues the NEXT node's six
 gathers and waits (lgkmcnt(6)) for the current node's. Between the block that issues a register's load and the block that waits for
-it, no instruction may read or write that register - a register copy there would carry stale data on. This script scans the
+it, no instruction may read or write that register - a register copy there would carry stale data on. The bucket-table read of the previous
+node (ds_read_u16) rides at the FRONT of a block, where lgkmcnt(6) covers it. This script scans the
 product kernel's assembly linearly: registers in flight, any mention of them outside an asm block is an error (a compiler-inserted
 `s_waitcnt lgkmcnt(0)` lands everything and is fine).
 
@@ -63,9 +64,14 @@ def scan_function(lines, start, end):
                 body.append(lines[j].strip())
                 j += 1
             loads = [b for b in body if b.startswith("ds_read_u16_d16_hi")]
-            if loads or any("lgkmcnt" in b for b in body):
+            table = [k for k, b in enumerate(body) if re.match(r"ds_read_u16 v\d+", b)]  # the previous node's bucket-table read rides in front of the gathers
+            if table and loads and table[-1] > body.index(loads[0]):
+                errors.append(f"line {j}: a table read behind the block's gathers is not covered by lgkmcnt(6)")
+            if loads or table or any("lgkmcnt" in b for b in body):
                 blocks += 1
                 issued = {int(re.match(r"ds_read_u16_d16_hi v(\d+)", b).group(1)) for b in loads}
+                if table and not any(b.startswith("s_waitcnt") for b in body):  # issued alone (the last node's): in flight until the next lgkmcnt(0)
+                    issued |= {int(re.match(r"ds_read_u16 v(\d+)", body[k]).group(1)) for k in table}
                 waits = [b for b in body if b.startswith("s_waitcnt")]
                 if waits and "lgkmcnt(0)" in waits[-1]:
                     in_flight = set()
