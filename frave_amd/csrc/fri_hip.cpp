@@ -776,10 +776,11 @@ static int predict_launch(fri_hip_plan *p, const PredBatch &b, uint8_t *d_bucket
     return FRI_HIP_OK;
 }
 // d_range (may be NULL): per plane, how many waves staged a Some coefficient outside [-256, 255] (include/fri_hip.h: the fit's precondition)
-static int fit_launch(fri_hip_plan *p, int mode, const PredBatch &b, int64_t *d_int, double *d_dbl, unsigned long long *d_range, hipStream_t stream) {
+static int fit_launch(fri_hip_plan *p, int mode, const PredBatch &b, int64_t *d_int, double *d_dbl, unsigned long long *d_range, hipStream_t stream,
+                      const FitSolve *solve = nullptr) {
     const int slot = acquire_acc(p, stream, b.n_planes);
     if (slot < 0) return slot;
-    if (hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream)) {
+    if (hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream, solve)) {
         p->acc_dirty = true;
         return fail_hip(p->ctx, e, "launch_fit_accumulate");
     }
@@ -922,15 +923,21 @@ int fri_hip_fit_width_sums(fri_hip_plan *p, const int32_t *coefs, uint32_t chann
 
 /* ---- the 6 x 6 solves behind the fit (solve6.hpp: one source for these host functions and for the device's solve kernel) ------ */
 void fri_hip_solve6(const double m[6][6], const double y[6], double x[6]) {
-    solve6(*reinterpret_cast<const double(*)[6][6]>(m), *reinterpret_cast<const double(*)[6]>(y), *reinterpret_cast<double(*)[6]>(x));
+    Solve6Work w;
+    std::memcpy(w.m, m, sizeof(w.m));
+    std::memcpy(w.y, y, sizeof(w.y));
+    solve6(w);
+    std::memcpy(x, w.x, sizeof(w.x));
 }
 
 void fri_hip_fit_value_params(const int64_t gram[3][28], float value_params[3][6]) {
-    for (int g = 0; g < 3; g++) fit_value_group(reinterpret_cast<const long long *>(gram[g]), value_params[g]); // optimize_value_prediction, context_modeling.rs:175-202
+    Solve6Work w;
+    for (int g = 0; g < 3; g++) fit_value_group(reinterpret_cast<const long long *>(gram[g]), value_params[g], w); // optimize_value_prediction, context_modeling.rs:175-202
 }
 
 void fri_hip_fit_width_params(const int64_t wtw[3][21], const double wtr[3][6], const uint64_t rows[3], float width_params[3][6]) {
-    for (int g = 0; g < 3; g++) fit_width_group(reinterpret_cast<const long long *>(wtw[g]), wtr[g], rows[g], width_params[g]); // optimize_width_prediction, :144-173
+    Solve6Work w;
+    for (int g = 0; g < 3; g++) fit_width_group(reinterpret_cast<const long long *>(wtw[g]), wtr[g], rows[g], width_params[g], w); // optimize_width_prediction, :144-173
 }
 
 /* ---- the device part of FRIEncoder::encode in one call ------------------------------------------------ */
@@ -957,11 +964,13 @@ static int fit_chain(fri_hip_plan *p, const PredBatch &b, unsigned long long *d_
     const uint64_t F = p->geo.centers.size();
     const unsigned long long rows[3] = {F * 256, F * 128, F * 128}; // num_ctx_last_layer / num_ctx_middle_layer, context_modeling.rs:84-85
     unsigned long long *range = d_range ? d_range : k.range;
-    if (int rc = fit_launch(p, 0, b, (int64_t *)k.sums_int, nullptr, range, s)) return rc;
-    HIP_TRY(p->ctx, launch_fit_solve(0, b.n_planes, k.sums_int, nullptr, nullptr, params, s, host_params, range, host_range));
-    if (int rc = fit_launch(p, 1, b, (int64_t *)k.sums_int, k.sums_dbl, nullptr, s)) return rc;
-    HIP_TRY(p->ctx, launch_fit_solve(1, b.n_planes, k.sums_int, k.sums_dbl, rows, params, s, host_params));
-    return FRI_HIP_OK;
+    // two launches: each sums kernel solves in its tail (the workgroup that moves a plane's totals out)
+    FitSolve solve;
+    solve.params = params, solve.host_params = host_params, solve.host_range = host_range;
+    for (int g = 0; g < 3; g++) solve.rows[g] = rows[g];
+    if (int rc = fit_launch(p, 0, b, (int64_t *)k.sums_int, nullptr, range, s, &solve)) return rc;
+    solve.host_range = nullptr; // (the width pass does not count)
+    return fit_launch(p, 1, b, (int64_t *)k.sums_int, k.sums_dbl, nullptr, s, &solve);
 }
 
 // prediction::encode for all channels of one image whose coefficients are in device memory (prediction.rs:224-323 minus the host's ANS

@@ -40,6 +40,12 @@ struct FitArgs {
     int32_t ablate;       // timing-only (tuning build, FRI_HIP_K4_ABLATE): 1 = no sums, 2 = tiles after the first are staged without their global loads
     unsigned long long *trace; // diagnostic timeline (tuning build + FRI_HIP_TRACE=1), null in production
     int32_t older_eighths;     // kernel2 with a full grid: eighths of a CU's tiles its first-dispatched workgroup walks (0: equal shares; see the kernel)
+    // kernel2, the solve in the tail (NULL: sums only): the workgroup that moves a plane's totals out also solves its three 6 x 6 systems and writes
+    // the parameters - MODE 0: .value, MODE 1: .width of solve_params[plane] - where the next kernel of the chain reads them
+    float *solve_params;            // PredictParams[n_planes] in device memory
+    float *host_params;             // the same into mapped host memory (or NULL), with the plane's out-of-range count next to it:
+    unsigned long long *host_range; // [n_planes] mapped host memory (or NULL)
+    unsigned long long rows[3];     // MODE 1: heights of the reference's matrices (F * {256, 128, 128})
 };
 constexpr int kFitAccInt = 3 * 28, kFitAccDbl = kFitAccInt, kFitAccTicket = kFitAccInt + 18, kFitAccRange = kFitAccTicket + 1;
 static_assert(kFitAccRange + 1 == (int)kFitAccWords, "fit accumulator layout");
@@ -348,7 +354,9 @@ constexpr int kFit2Image = kPredSlots * kSlotStride; // 37 440 B; image 1 sits b
 static_assert(kFit2Image + (kPredSide + kPredBlock) * kSlotStride < 65536, "image + cell offset must fit a DS instruction's offset field");
 // Round 3: the same sparse halo as K2 (k2_predict.hip, build_halo_list). A tile's 16 block cells are staged whole - two per wave, one behind each
 // half of the current tile's sums - but of its 20 halo cells only the 902 values a 4 x 4 block ever gathers, two per thread: 45 KB of loads per
-// tile instead of 72, a third of the conversions. Values land in heap order at 2 bytes each (this kernel's layout), None as 0.
+// tile instead of 72, a third of the conversions. Values land in heap order at 2 bytes each (this kernel's layout), None as 0. (K2's annealed pair
+// positions inside a slot - this kernel's waves gather exactly the node patterns of K2's roles - were tried in round 3: the bank conflicts are not what
+// limits this kernel, 37.2 / 55.1 us either way, and the four scattered dword writes per lane cost the width pass its last free registers.)
 struct Fit2Block {
     int4 lo, hi;
 };
@@ -437,6 +445,24 @@ __device__ __forceinline__ void fit2_wave_sums(int (&acc)[28], int group, int la
         const long long sum = ((long long)__builtin_amdgcn_readlane(r, 0) + __builtin_amdgcn_readlane(r, 16)) +
                               ((long long)__builtin_amdgcn_readlane(r, 32) + __builtin_amdgcn_readlane(r, 48));
         if (lane == 0) atomicAdd(&s_int[group][k], (unsigned long long)sum);
+    }
+}
+
+// One layer group's solve at the end of the sums kernel. A function of its own, not inlined: as part of the kernel's body its ~90 registers' worth of f64
+// temporaries pushed the tile loop of the width pass (122 registers of 128) into spilling.
+template <int MODE>
+__device__ __attribute__((noinline)) void fit2_tail_solve(const long long *sums_int, const double *sums_dbl, unsigned long long rows, Solve6Work *w, float *params,
+                                                          float *host_params) {
+    float out[6];
+    if (MODE == 0)
+        fit_value_group(sums_int, out, *w);
+    else
+        fit_width_group(sums_int, sums_dbl, rows, out, *w);
+#pragma unroll
+    for (int k = 0; k < 6; k++) params[k] = out[k];
+    if (host_params) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) host_params[k] = out[k];
     }
 }
 
@@ -632,6 +658,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             __hip_atomic_store(accp + sh * kFitAccWords + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         out_int[i] = sum;
+        s_int[i / NI][i % NI] = sum; // (for the solve below)
     }
     if (MODE == 1 && tid < 18) {
         unsigned long long part[kFitShards];
@@ -644,11 +671,27 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             __hip_atomic_store(accp + sh * kFitAccWords + kFitAccDbl + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         a0.wtr[(size_t)plane * 18 + tid] = sum;
+        (&s_dbl[0][0])[tid] = sum;
     }
     if (tid == 0) {
         const unsigned long long r = __hip_atomic_exchange(accp + kFitAccRange, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a0.out_range) a0.out_range[plane] = r;
+        if (a0.host_range) a0.host_range[plane] = r;
         __hip_atomic_store(accp + kFitAccTicket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ContextModeler::optimize_value_prediction / optimize_width_prediction (context_modeling.rs:144-202) right here: lane g solves layer group g from the
+    // totals this wave has just parked in LDS, its workspace a piece of the (now idle) cell images. As kernels of their own between the sums kernels and
+    // the scan the two solves were 12 us each of the 175 us chain (launch, three lanes walking arrays in scratch memory, drain).
+    if (!a0.solve_params) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (tid < 3) {
+        static_assert(3 * sizeof(Solve6Work) <= 2 * kFit2Image, "the solve's workspace lives in the cell images");
+        const unsigned long long rows = tid == 0 ? a0.rows[0] : tid == 1 ? a0.rows[1] : a0.rows[2]; // (selects: no dynamic index into the argument struct)
+        const size_t at = (size_t)plane * (sizeof(PredictParams) / sizeof(float)) + (MODE ? 18 : 0) + tid * 6;
+        fit2_tail_solve<MODE>(reinterpret_cast<const long long *>(s_int[tid]), s_dbl[tid], rows, reinterpret_cast<Solve6Work *>(s_cells) + tid, a0.solve_params + at,
+                              a0.host_params ? a0.host_params + at : nullptr);
     }
 }
 
@@ -656,9 +699,8 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
 // context_modeling.rs:144-202, behind prediction.rs:232-235): one thread per (plane, layer group) turns the sums a fit_accumulate launch
 // left in device memory into that group's six parameters, written into the device parameter array the next kernel of the chain reads
 // (the width pass of the fit, then K2) - so the chain K1 -> sums -> solve -> sums -> solve -> K2 is enqueued without the host in between.
-// The arithmetic is solve6.hpp's, shared with the host entry points. A kernel of its own rather than the tail of fit_accumulate_kernel2:
-// the eigen-decomposition route wants ~150 f64 registers (scratch), which must not become the sums kernel's register budget, and a
-// dependent kernel boundary (~1.5 us) costs what the solve would cost serially at the end of the sums kernel.
+// The arithmetic is solve6.hpp's, shared with the host entry points. The chain itself solves in the tail of fit_accumulate_kernel2 (FitArgs::solve_params);
+// this kernel serves the entry points that take sums from the caller (fri_hip_fit_value_params_batch_dev, fri_hip_fit_width_params_batch_dev).
 struct SolveArgs {
     const unsigned long long *sums_int; // [n_planes][3][28] (MODE 0) / [n_planes][3][21] (MODE 1)
     const double *sums_dbl;             // [n_planes][3][6] (MODE 1)
@@ -671,17 +713,20 @@ struct SolveArgs {
     const unsigned long long *range;    // [n_planes] device, or NULL
     unsigned long long *host_range;     // [n_planes] mapped host memory, or NULL
 };
+constexpr uint32_t kSolveThreads = 32; // a thread's workspace is 1.4 KB of LDS
 template <int MODE>
-__global__ void __launch_bounds__(64) fit_solve_kernel(const SolveArgs a) {
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+__global__ void __launch_bounds__(kSolveThreads) fit_solve_kernel(const SolveArgs a) {
+    __shared__ Solve6Work s_work[kSolveThreads];
+    Solve6Work &w = s_work[threadIdx.x];
+    const uint32_t t = blockIdx.x * kSolveThreads + threadIdx.x;
     if (t >= a.n_planes * 3u) return;
     const uint32_t plane = t / 3u, g = t % 3u;
     float *out = a.params + (size_t)plane * (sizeof(PredictParams) / sizeof(float)) + (MODE ? 18 : 0) + g * 6;
     if (MODE == 0) {
-        fit_value_group(reinterpret_cast<const long long *>(a.sums_int) + ((size_t)plane * 3 + g) * 28, out);
+        fit_value_group(reinterpret_cast<const long long *>(a.sums_int) + ((size_t)plane * 3 + g) * 28, out, w);
     } else {
         const unsigned long long rows = g == 0 ? a.rows[0] : g == 1 ? a.rows[1] : a.rows[2]; // (selects: no dynamic index into the argument struct)
-        fit_width_group(reinterpret_cast<const long long *>(a.sums_int) + ((size_t)plane * 3 + g) * 21, a.sums_dbl + ((size_t)plane * 3 + g) * 6, rows, out);
+        fit_width_group(reinterpret_cast<const long long *>(a.sums_int) + ((size_t)plane * 3 + g) * 21, a.sums_dbl + ((size_t)plane * 3 + g) * 6, rows, out, w);
     }
     if (a.host_params) {
         float *h = a.host_params + (out - a.params);
@@ -703,17 +748,17 @@ hipError_t launch_fit_solve(int mode, uint32_t n_planes, const unsigned long lon
     a.n_planes = n_planes;
     a.host_params = host_params, a.range = range, a.host_range = host_range;
     for (int g = 0; g < 3; g++) a.rows[g] = rows ? rows[g] : 0;
-    const uint32_t blocks = (n_planes * 3u + 63u) / 64u;
+    const uint32_t blocks = (n_planes * 3u + kSolveThreads - 1u) / kSolveThreads;
     (void)hipGetLastError();
     if (mode == 0)
-        hipLaunchKernelGGL(fit_solve_kernel<0>, dim3(blocks), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL(fit_solve_kernel<0>, dim3(blocks), dim3(kSolveThreads), 0, stream, a);
     else
-        hipLaunchKernelGGL(fit_solve_kernel<1>, dim3(blocks), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL(fit_solve_kernel<1>, dim3(blocks), dim3(kSolveThreads), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
-                                 unsigned long long *out_of_range, hipStream_t stream) {
+                                 unsigned long long *out_of_range, hipStream_t stream, const FitSolve *solve) {
     if (!acc || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
     FitArgs a{};
     a.coefs = b.coefs;
@@ -732,6 +777,11 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
     a.wtw = sums_int;
     a.wtr = sums_dbl;
     a.out_range = out_of_range;
+    if (solve) {
+        if (p.k4_previous || !solve->params) return hipErrorInvalidValue;
+        a.solve_params = solve->params, a.host_params = solve->host_params, a.host_range = solve->host_range;
+        for (int g = 0; g < 3; g++) a.rows[g] = solve->rows[g];
+    }
     a.ablate = p.k4_ablate;
     a.trace = p.trace;
     a.older_eighths = b.n_planes == 1 && p.hist_blocks <= p.n_pred_tiles ? p.k4_older_eighths : 0; // a plane on the whole machine: two co-resident workgroups per CU

@@ -108,8 +108,16 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const Pr
 // Fit accumulators: mode 0 = value fit (sums_int[n_planes][3][28]), mode 1 = width fit (sums_int[n_planes][3][21], sums_dbl[n_planes][3][6]).
 // acc: n_planes accumulators of kFitShards x kFitAccWords words, all zero between launches.
 // out_of_range (may be NULL): per plane, the number of waves that staged a Some coefficient outside [-256, 255] - the sums are then not to be trusted.
+// solve (may be NULL): the workgroup that moves a plane's totals out also solves the plane's three 6 x 6 systems (solve6.hpp) and writes the parameters -
+// mode 0: .value, mode 1: .width of params[plane] - in device memory, and, when given, into mapped host memory together with the out-of-range count.
+struct FitSolve {
+    float *params = nullptr;                 // PredictParams[n_planes], device memory
+    float *host_params = nullptr;            // PredictParams[n_planes], mapped host memory (device-visible pointer), or NULL
+    unsigned long long *host_range = nullptr; // [n_planes] mapped host memory, or NULL (written by the mode-0 launch, which counts)
+    unsigned long long rows[3] = {0, 0, 0};  // mode 1: heights of the reference's matrices (F * {256, 128, 128})
+};
 hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
-                                 unsigned long long *out_of_range, hipStream_t stream);
+                                 unsigned long long *out_of_range, hipStream_t stream, const FitSolve *solve = nullptr);
 // The fit's 6 x 6 solves on the device: sums of a launch_fit_accumulate (mode 0: sums_int[n_planes][3][28]; mode 1: sums_int[n_planes][3][21],
 // sums_dbl[n_planes][3][6], rows[3] = heights of the reference's matrices) -> params[n_planes] (PredictParams: mode 0 writes .value, mode 1 .width).
 // host_params / host_range (device-visible pointers into mapped host memory, or NULL): the solving threads also leave the parameters - and the

@@ -37,3 +37,22 @@ for fit in (False, True):
     torch.cuda.synchronize()
     us = (time.perf_counter() - t0) / reps * 1e6
     print(f"4096x4096x{C} encode chain, fit={fit}: {us:8.1f} us per image (wall clock, {reps} images back to back)")
+
+# the asynchronous form (fri_hip_encode_image_batch_dev: parameters stay in device memory, nothing but enqueues), timed with events on the stream
+d_par = torch.zeros((C, 2, 3, 6), dtype=torch.float32, device="cuda")
+d_par[:, 0] = torch.from_numpy(vp).cuda()
+d_par[:, 1] = torch.from_numpy(wp).cuda()
+d_r = torch.zeros(C, dtype=torch.int64, device="cuda")
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for fit in (False, True):
+    call = lambda: plan.encode_image_batch_dev(1, d_px.data_ptr(), plan.pixel_bytes, d_par.data_ptr(), d_co.data_ptr(), C * F * 512, d_b.data_ptr(), d_p.data_ptr(), C * F * 512,
+                                               d_h.data_ptr(), d_o.data_ptr(), fit=fit, d_fit_out_of_range=d_r.data_ptr(), stream=s)
+    for _ in range(5):
+        call()
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(50):
+        call()
+    ev1.record()
+    torch.cuda.synchronize()
+    print(f"4096x4096x{C} asynchronous chain, fit={fit}: {ev0.elapsed_time(ev1) / 50 * 1e3:8.1f} us per image (events, 50 images back to back)")
