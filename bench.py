@@ -31,7 +31,7 @@ def measured_traffic():
     """HBM bytes per K1 launch from the committed rocprofv3 PMC pass (profiles/), or None. bench.py cannot collect
     hardware counters itself; the number is tied to the kernel named in the file."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_k1_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_k1_traffic.json")) as f:
             return int(json.load(f)["hbm_bytes_per_launch"])
     except Exception:
         return None
@@ -165,7 +165,7 @@ def extras(plan, ctx, torch, np, px0, co0, pstride, cstride, slots, alg_bytes, s
     res["k4_fit_value_sums"] = entry(timed(lambda: plan.fit_value_sums_dev(co0, 0, d_g.data_ptr(), stream=stream)), k4_bytes)
     res["k4_fit_width_sums"] = entry(timed(lambda: plan.fit_width_sums_dev(co0, 0, vp, d_g.data_ptr(), d_w.data_ptr(), stream=stream)), k4_bytes)
     # the device part of FRIEncoder::encode for one image, everything in HBM, nothing but enqueues (fri_hip_encode_image_batch_dev): with the
-    # parameters given (K1 -> K2) and with the fit (K1 -> value sums -> solves -> width sums -> solves -> K2, the solves on the device)
+    # parameters given (K1 -> K2) and with the fit (K1 -> value sums + solves -> width sums + solves -> K2: four launches, each sums kernel solves in its tail)
     d_par.copy_(torch.from_numpy(np.stack([vp, wp]).reshape(-1)))
     given = timed(lambda: plan.encode_image_batch_dev(1, px0, pstride, d_par.data_ptr(), co0, cstride, d_b.data_ptr(), d_p.data_ptr(), plane, d_h.data_ptr(), d_o.data_ptr(),
                                                       fit=False, stream=stream))
@@ -173,6 +173,20 @@ def extras(plan, ctx, torch, np, px0, co0, pstride, cstride, slots, alg_bytes, s
     fit = timed(lambda: plan.encode_image_batch_dev(1, px0, pstride, d_par.data_ptr(), co0, cstride, d_b.data_ptr(), d_p.data_ptr(), plane, d_h.data_ptr(), d_o.data_ptr(),
                                                     fit=True, stream=stream))
     res["chain_with_fit"] = entry(fit, alg_bytes + k2_bytes + 2 * k4_bytes)
+    # ... and all the way to the emitter's input (fri_hip_encode_symbols_batch_dev): the scan writes one halfword per node instead of bucket + prediction,
+    # the gather kernel (K5) puts them in the reference's stream order: 2 bytes per symbol is all that has to leave the device
+    plan.set_stream_order()
+    n_sym = plan.num_some
+    d_words = torch.empty(plane, dtype=torch.uint16, device="cuda")
+    d_sym = torch.empty(n_sym, dtype=torch.uint16, device="cuda")
+    k2w_bytes = plane * (4 + 2) + 10 * 1024 * 4
+    k5_bytes = n_sym * (4 + 2 + 2)  # order + halfword gathered + halfword written
+    sym = timed(lambda: plan.encode_symbols_batch_dev(1, px0, pstride, None, False, d_par.data_ptr(), co0, cstride, d_words.data_ptr(), plane, d_sym.data_ptr(), n_sym,
+                                                      d_h.data_ptr(), d_o.data_ptr(), stream=stream))
+    res["chain_to_symbol_stream_given_params"] = entry(sym, alg_bytes + k2w_bytes + k5_bytes)
+    res["k5_symbol_gather"] = entry(sym - given, k5_bytes)
+    res["k5_symbol_gather"]["note"] = "difference of the two chains above (the scan's halfword form is ~1.5 us faster than its array form, so this slightly understates K5)"
+    del d_words, d_sym
     # K1 on RGB, the colour space libfri really encodes (wavelet_transform.rs:191, 415-416)
     plan3 = frave_amd.Plan(ctx, W, H, 3)
     d_px3 = torch.randint(0, 256, (2, plan3.pixel_bytes), dtype=torch.uint8, device="cuda")

@@ -67,37 +67,43 @@ struct GatherArgs {
 };
 constexpr int kGatherThreads = 256;
 
+constexpr int kGatherChunks = 2; // 512-symbol chunks per wave: all their order loads, then all their gathers, are in flight together
 __global__ void __launch_bounds__(kGatherThreads) symbol_gather_kernel(const GatherArgs a) {
-    __shared__ __attribute__((aligned(16))) uint16_t s_t[kGatherThreads * 8];
+    __shared__ __attribute__((aligned(16))) uint16_t s_t[kGatherThreads * 8 * kGatherChunks];
     const uint32_t plane = blockIdx.y;
     const uint16_t *words = a.words + plane * a.word_stride;
     uint16_t *out = a.out + plane * a.stream_stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t lead = (int64_t)((reinterpret_cast<uintptr_t>(out) >> 1) & 7u); // halfwords between the 16-byte grid and the stream's start
-    // a wave takes 512 consecutive symbols; in gather k lane l fetches symbol 64 k + l, so the 64 gathers of one instruction are 64 NEIGHBOURS of the stream -
-    // a scan-line stretch through three or four cells, a handful of 64-byte lines - where a lane-owns-eight-symbols split touches 64 lines per instruction
-    // (55 us against 118 for the three-array kernel, the texture addresser the limit). The halfwords turn through LDS into the lane-owns-eight layout of the stores.
-    const int64_t wave_first = ((int64_t)xcd_contiguous_share(blockIdx.x, gridDim.x) * (kGatherThreads / 64) + wave) * 512 - lead;
+    // a wave takes kGatherChunks x 512 consecutive symbols; in gather k lane l fetches symbol 64 k + l, so the 64 gathers of one instruction are 64 NEIGHBOURS
+    // of the stream - a scan-line stretch through three or four cells, a handful of 64-byte lines - where a lane-owns-eight-symbols split touches 64 lines
+    // per instruction (55 us against 118 for the three-array kernel, the texture addresser the limit). The halfwords turn through LDS into the
+    // lane-owns-eight layout of the stores.
+    constexpr int kPerWave = 512 * kGatherChunks;
+    const int64_t wave_first = ((int64_t)xcd_contiguous_share(blockIdx.x, gridDim.x) * (kGatherThreads / 64) + wave) * kPerWave - lead;
     const int64_t n = (int64_t)a.n_symbols;
     if (wave_first >= n) return;
-    uint16_t *t = s_t + wave * 512;
-    if (wave_first >= 0 && wave_first + 512 <= n) {
-        uint32_t o[8];
+    uint16_t *t = s_t + wave * kPerWave;
+    if (wave_first >= 0 && wave_first + kPerWave <= n) {
+        uint32_t o[8 * kGatherChunks];
 #pragma unroll
-        for (int k = 0; k < 8; k++) o[k] = __builtin_nontemporal_load(a.order + wave_first + 64 * k + lane);
-        uint16_t w[8];
+        for (int k = 0; k < 8 * kGatherChunks; k++) o[k] = __builtin_nontemporal_load(a.order + wave_first + 64 * k + lane);
+        uint16_t w[8 * kGatherChunks];
 #pragma unroll
-        for (int k = 0; k < 8; k++) w[k] = words[o[k]];
+        for (int k = 0; k < 8 * kGatherChunks; k++) w[k] = words[o[k]];
 #pragma unroll
-        for (int k = 0; k < 8; k++) t[64 * k + lane] = w[k];
-        // (the wave reads what the wave wrote: no workgroup barrier; the compiler's own waits order the LDS traffic of a wave)
+        for (int k = 0; k < 8 * kGatherChunks; k++) t[64 * k + lane] = w[k];
+        // (the wave reads what the wave wrote: no workgroup barrier; LDS operations of a wave complete in order)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-        const u32x4 v = reinterpret_cast<const u32x4 *>(t)[lane];
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out + wave_first) + lane);
+#pragma unroll
+        for (int c = 0; c < kGatherChunks; c++) {
+            const u32x4 v = reinterpret_cast<const u32x4 *>(t + 512 * c)[lane];
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out + wave_first + 512 * c) + lane);
+        }
         return;
     }
-    for (int64_t i = (wave_first < 0 ? 0 : wave_first) + lane; i < wave_first + 512 && i < n; i += 64) out[i] = words[a.order[i]]; // the two ragged ends of a plane
+    for (int64_t i = (wave_first < 0 ? 0 : wave_first) + lane; i < wave_first + kPerWave && i < n; i += 64) out[i] = words[a.order[i]]; // the two ragged ends of a plane
 }
 
 } // namespace
@@ -108,7 +114,7 @@ hipError_t launch_symbol_gather(const uint32_t *order, uint64_t n_symbols, uint3
     if (!n_symbols) return hipSuccess;
     GatherArgs a{};
     a.order = order, a.words = words, a.out = out, a.n_symbols = n_symbols, a.word_stride = word_stride, a.stream_stride = stream_stride;
-    const uint64_t per_wg = (uint64_t)kGatherThreads * 8;
+    const uint64_t per_wg = (uint64_t)kGatherThreads * 8 * kGatherChunks;
     const uint64_t blocks = (n_symbols + 7 + per_wg - 1) / per_wg; // + 7: the lead of a stream that does not start on the 16-byte grid
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     (void)hipGetLastError();

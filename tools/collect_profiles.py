@@ -1,0 +1,42 @@
+"""Copies the summaries of a tools/profile_round3.sh run (gpurun_out/<tag>/) into profiles/ under this round's names and derives
+profiles/r03_k1_traffic.json (what bench.py reports as roofline.traffic) from the K1 PMC passes.   python tools/collect_profiles.py <tag> [round]"""
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+copies = {
+    "kernel_stats_round3.csv": f"{rnd}_kernel_stats.csv",
+    "pmc_k2_summary.txt": f"{rnd}_k2_pmc_summary.txt",
+    "pmc_k2_k4_k3_k5_summary.txt": f"{rnd}_k2_k4_k3_k5_pmc_summary.txt",
+    "pmc_k1_summary.txt": f"{rnd}_k1_pmc_summary.txt",
+    "bench.json": f"{rnd}_bench_line.json",
+    "bench_traced.json": f"{rnd}_bench_line_under_rocprofv3.json",
+}
+for a, b in copies.items():
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
+        print("copied", a, "->", b)
+    else:
+        print("missing", a)
+# K1 plane traffic: FETCH_SIZE / WRITE_SIZE are in KB; gfx950 reports half the bytes of 16 B/lane coalesced reads (MI355X_MICROARCH.md, HBM section)
+txt = open(os.path.join(src, "pmc_k1_summary.txt")).read().split("== K1 RGB")[0]
+val = lambda name: float(re.search(name + r"\s+n=\s*\d+\s+mean=\s*([0-9.]+)", txt).group(1))
+fetch, write = val("FETCH_SIZE"), val("WRITE_SIZE")
+out = {
+    "kernel": "fwd_transform_quant_kernel<1,false,true,4,true>",
+    "workload": "4096x4096x1",
+    "source": f"profiles/{rnd}_k1_pmc_summary.txt",
+    "fetch_size_kb_raw": round(fetch, 1),
+    "write_size_kb": round(write, 1),
+    "correction": "FETCH_SIZE x2 (gfx950 reports half the bytes of 16 B/lane coalesced reads, MI355X_MICROARCH.md section HBM); WRITE_SIZE exact for 16 B/lane stores",
+    "hbm_bytes_per_launch": int(round((2 * fetch + write) * 1024)),
+}
+json.dump(out, open(os.path.join(dst, f"{rnd}_k1_traffic.json"), "w"), indent=1)
+print(out)
