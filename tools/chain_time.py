@@ -1,5 +1,5 @@
-"""Time the device-resident encode chain (fri_hip_encode_image_dev) at 4096x4096xC with and without the fit. GPU only.
-FRI_HIP_TUNING=1 FRI_HIP_FIT_NO_POLL=1: the fit sums come back by copy + stream synchronisation instead of the polled hand-over (A/B)."""
+"""Time the device-resident encode chain at 4096x4096xC with and without the fit, through the host-parameter entry point (fri_hip_encode_image_dev: wall
+clock) and the asynchronous one (fri_hip_encode_image_batch_dev: HIP events). GPU only. Under `rocprofv3 --kernel-trace` its trace feeds tools/chain_gaps.py."""
 import os
 import sys
 import time
