@@ -557,57 +557,65 @@ __device__ __forceinline__ void p3_half(const uint32_t (&addr)[4][6], float (&ga
 #pragma unroll
         for (int j = 0; j < 4; j++) bin[j] = sym[j] < 1024u ? bin[j] : (uint32_t)kHistBins * 4u;
     }
+    if (ablate & 4) pred[0] ^= (int)(bin[0] ^ bin[1] ^ bin[2] ^ bin[3]); // (timing only: keeps the bin arithmetic alive)
+    // How the four nodes leave. Called at the end of BOTH branches below rather than behind their merge: the boundary branch changes predictions and
+    // buckets, and behind a merge the common path paid six register copies per cell for that.
+    auto leave = [&](const int (&pr)[4], const uint32_t (&bk)[4]) {
+        if (WORDS) {
+            // bin = 4 x (bucket << 10 | symbol) (out of alphabet: 4 x kHistBins, "bucket 10" - no such symbol may be emitted, n_out_of_alphabet says so);
+            // two nodes per dword: the low two bits of a bin are zero, so bin1 << 14 lands on bit 16
+            const uint32_t w01 = (bin[1] << 14) | (bin[0] >> 2), w23 = (bin[3] << 14) | (bin[2] >> 2);
+            if (ROLE) {
+                if (!(ablate & 32) || ((w01 ^ w23) == 0x12345678)) __builtin_nontemporal_store(i32x2{(int)w01, (int)w23}, reinterpret_cast<i32x2 *>(wd + 256) + lane);
+            } else {
+                uint32_t *q01 = lane == 0 ? reinterpret_cast<uint32_t *>(junk) : reinterpret_cast<uint32_t *>(wd) + lane; // nodes 0 and 1: the LF pass writes them
+                if (!(ablate & 32) || ((w01 ^ w23) == 0x12345678)) {
+                    __builtin_nontemporal_store(w01, q01);
+                    __builtin_nontemporal_store(w23, reinterpret_cast<uint32_t *>(wd + 128) + lane);
+                }
+            }
+            return;
+        }
+        // bucket << 12 in each: byte 1 holds bucket << 4; collect the byte-1s, then one shift moves all the nibbles down.
+        // Wave-uniform bases + a 32-bit lane offset: the stores address as saddr + voffset, no 64-bit pointer arithmetic per cell.
+        if (ROLE) {
+            const uint32_t lo = __builtin_amdgcn_perm(bk[1], bk[0], 0x0C0C0501u), hi = __builtin_amdgcn_perm(bk[3], bk[2], 0x05010C0Cu);
+            if (!(ablate & 32) || ((lo ^ hi ^ pr[0] ^ pr[1] ^ pr[2] ^ pr[3]) == 0x12345678)) { // (32: timing only, no stores; the test keeps the arithmetic alive)
+                __builtin_nontemporal_store(i32x4{pr[0], pr[1], pr[2], pr[3]}, reinterpret_cast<i32x4 *>(pd + 256) + lane);
+                __builtin_nontemporal_store((lo | hi) >> 4, reinterpret_cast<uint32_t *>(bd + 256) + lane);
+            }
+        } else {
+            const uint32_t lo = __builtin_amdgcn_perm(bk[1], bk[0], 0x0C0C0501u) >> 4, hi = __builtin_amdgcn_perm(bk[3], bk[2], 0x0C0C0501u) >> 4;
+            // Nodes 0 and 1 are written by the LF pass: lane 0's pair goes to the wave's junk lines instead. By address, not under a branch -
+            // the number of stores per cell must be the same on every path, or the wait for the staging loads turns into a wait for stores.
+            i32x2 *p01 = lane == 0 ? reinterpret_cast<i32x2 *>(junk + 512) : reinterpret_cast<i32x2 *>(pd) + lane;
+            uint16_t *b01 = lane == 0 ? reinterpret_cast<uint16_t *>(junk) : reinterpret_cast<uint16_t *>(bd) + lane;
+            if (!(ablate & 32) || ((lo ^ hi ^ pr[0] ^ pr[1] ^ pr[2] ^ pr[3]) == 0x12345678)) {
+                __builtin_nontemporal_store(i32x2{pr[0], pr[1]}, p01);
+                __builtin_nontemporal_store((uint16_t)lo, b01);
+                __builtin_nontemporal_store(i32x2{pr[2], pr[3]}, reinterpret_cast<i32x2 *>(pd + 128) + lane);
+                __builtin_nontemporal_store((uint16_t)hi, reinterpret_cast<uint16_t *>(bd + 128) + lane);
+            }
+        }
+    };
     if (__builtin_expect(interior, 1)) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const bool lf = ROLE == 0 && j < 2 && lane == 0;
             if (!lf && !(ablate & 4)) atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(s_hist) + bin[j]), 1u); // bump_freq, entropy_coding.rs:98-100
         }
+        leave(pred, b12);
     } else { // a None node is not counted and stays (0, 0) in the outputs (wavelet_transform.rs:60-64)
+        int pm[4];
+        uint32_t bm[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const bool some = (some4 >> j) & 1u; // (the LF nodes' bits are already cleared)
             if (some && !(ablate & 4)) atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(s_hist) + bin[j]), 1u);
-            pred[j] = some ? pred[j] : 0;
-            b12[j] = some ? b12[j] : 0u;
+            pm[j] = some ? pred[j] : 0;
+            bm[j] = some ? b12[j] : 0u;
         }
-    }
-    if (ablate & 4) pred[0] ^= (int)(bin[0] ^ bin[1] ^ bin[2] ^ bin[3]); // (timing only: keeps the bin arithmetic alive)
-    if (WORDS) {
-        // bin = 4 x (bucket << 10 | symbol) (out of alphabet: 4 x kHistBins, "bucket 10" - no such symbol may be emitted, n_out_of_alphabet says so);
-        // two nodes per dword: the low two bits of a bin are zero, so bin1 << 14 lands on bit 16
-        const uint32_t w01 = (bin[1] << 14) | (bin[0] >> 2), w23 = (bin[3] << 14) | (bin[2] >> 2);
-        if (ROLE) {
-            if (!(ablate & 32) || ((w01 ^ w23) == 0x12345678)) __builtin_nontemporal_store(i32x2{(int)w01, (int)w23}, reinterpret_cast<i32x2 *>(wd + 256) + lane);
-        } else {
-            uint32_t *q01 = lane == 0 ? reinterpret_cast<uint32_t *>(junk) : reinterpret_cast<uint32_t *>(wd) + lane; // nodes 0 and 1: the LF pass writes them
-            if (!(ablate & 32) || ((w01 ^ w23) == 0x12345678)) {
-                __builtin_nontemporal_store(w01, q01);
-                __builtin_nontemporal_store(w23, reinterpret_cast<uint32_t *>(wd + 128) + lane);
-            }
-        }
-        return;
-    }
-    // bucket << 12 in each: byte 1 holds bucket << 4; collect the byte-1s, then one shift moves all the nibbles down.
-    // Wave-uniform bases + a 32-bit lane offset: the stores address as saddr + voffset, no 64-bit pointer arithmetic per cell.
-    if (ROLE) {
-        const uint32_t lo = __builtin_amdgcn_perm(b12[1], b12[0], 0x0C0C0501u), hi = __builtin_amdgcn_perm(b12[3], b12[2], 0x05010C0Cu);
-        if (!(ablate & 32) || ((lo ^ hi ^ pred[0] ^ pred[1] ^ pred[2] ^ pred[3]) == 0x12345678)) { // (32: timing only, no stores; the test keeps the arithmetic alive)
-            __builtin_nontemporal_store(i32x4{pred[0], pred[1], pred[2], pred[3]}, reinterpret_cast<i32x4 *>(pd + 256) + lane);
-            __builtin_nontemporal_store((lo | hi) >> 4, reinterpret_cast<uint32_t *>(bd + 256) + lane);
-        }
-    } else {
-        const uint32_t lo = __builtin_amdgcn_perm(b12[1], b12[0], 0x0C0C0501u) >> 4, hi = __builtin_amdgcn_perm(b12[3], b12[2], 0x0C0C0501u) >> 4;
-        // Nodes 0 and 1 are written by the LF pass: lane 0's pair goes to the wave's junk lines instead. By address, not under a branch -
-        // the number of stores per cell must be the same on every path, or the wait for the staging loads turns into a wait for stores.
-        i32x2 *p01 = lane == 0 ? reinterpret_cast<i32x2 *>(junk + 512) : reinterpret_cast<i32x2 *>(pd) + lane;
-        uint16_t *b01 = lane == 0 ? reinterpret_cast<uint16_t *>(junk) : reinterpret_cast<uint16_t *>(bd) + lane;
-        if (!(ablate & 32) || ((lo ^ hi ^ pred[0] ^ pred[1] ^ pred[2] ^ pred[3]) == 0x12345678)) {
-            __builtin_nontemporal_store(i32x2{pred[0], pred[1]}, p01);
-            __builtin_nontemporal_store((uint16_t)lo, b01);
-            __builtin_nontemporal_store(i32x2{pred[2], pred[3]}, reinterpret_cast<i32x2 *>(pd + 128) + lane);
-            __builtin_nontemporal_store((uint16_t)hi, reinterpret_cast<uint16_t *>(bd + 128) + lane);
-        }
+        leave(pm, bm);
     }
 }
 
