@@ -404,6 +404,10 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
             stage_issue<C, EDGE, FAST, NCH>(a, tn, img, tid, cm, st); // loads stay in flight across the transform below
         }
 
+        // Issue priority falls with a wave's progress through the tile (3 -> 2 -> 1, 0 for the stores), so that at every conflict the wave that is furthest
+        // behind - of any of the CU's workgroups - is the preferred one (the arbiter otherwise prefers the oldest): planes -1 % (16.43-16.54 against 16.61-16.69 us
+        // in three interleaved pairs), RGB +2 % (three workgroups per CU with five-cell tiles: not for C = 3).
+        if constexpr (C == 1) __builtin_amdgcn_s_setprio(3);
         const TileCell *meta = reinterpret_cast<const TileCell *>(cur + a.meta_off);
         const int n_items = (ablate_flags(a.ablate) & 2) ? 0 : t.cell_count * C;
         const uint32_t sh_base = a16 + (uint32_t)t.x_lo * C;
@@ -464,11 +468,18 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
                     }
                 }
                 fwd_wave_pk(leaf, lane, res[c]);
+                if constexpr (C == 1) {
+                    if (c == 0)
+                        __builtin_amdgcn_s_setprio(2);
+                    else
+                        __builtin_amdgcn_s_setprio(1);
+                }
                 if (__builtin_amdgcn_readfirstlane(meta[itA / C].interior & meta[itB / C].interior) == 0)
                     valid[c] = validity_tree_pk(A.leaf_mask | (B.leaf_mask << 16), lane);
             }
         }
         if (more) stage_commit<NCH>(a, tn, nxt, junk, tid, st);
+        if constexpr (C == 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int c = 0; c < kMaxPairsPerWave; c++) {
             const int itA = 2 * (wave + kFwdWaves * c);
