@@ -16,7 +16,7 @@ def run(n_cases, seed, ctx=None):
     """n_cases random (shape, content, channel count, quantiser, parameters) cases; returns the number of mismatching ones."""
     rng = np.random.default_rng(seed)
     ctx = ctx or frave_amd.Context(0)
-    bad = 0
+    bad = chains = 0
     t0 = time.time()
     for case in range(n_cases):
         kind = ["noise", "smooth", "const"][int(rng.integers(0, 3))]
@@ -57,12 +57,47 @@ def run(n_cases, seed, ctx=None):
         torch.cuda.synchronize()
         if not bool((d_co.cpu().numpy().reshape(9, -1) == co.reshape(1, -1)).all()):
             msgs.append("K1-batch")
+        # the chain with the fit (device-side solves) and the symbol stream route on the same image: the fitted parameters equal the host solves of the
+        # stage-by-stage sums bit for bit, the scan with them equals the oracle's, the stream is the gather of the array route's outputs
+        if P.num_some > 0 and not (kind == "const" and rng.random() < 0.5):
+            try:
+                co2, vpf, wpf, b2, p2, h2, oob2 = P.encode_image(img, q, fit=True)
+                chains += 1
+                if not np.array_equal(co2, co):
+                    msgs.append("chain-K1")
+                ok_fit = True
+                for cc in range(c):
+                    gram = P.fit_value_sums(co, cc)
+                    iu = np.triu_indices(7)
+                    vh = frave_amd.api.fit_value_params(np.stack([gram[g][iu] for g in range(3)]))
+                    wtw, wtr, rows = P.fit_width_sums(co, cc, vh)
+                    iu6 = np.triu_indices(6)
+                    wh = frave_amd.api.fit_width_params(np.stack([wtw[g][iu6] for g in range(3)]), wtr, rows)
+                    ok_fit = ok_fit and np.array_equal(vh.view(np.uint32), vpf[cc].view(np.uint32)) and np.array_equal(wh.view(np.uint32), wpf[cc].view(np.uint32))
+                if not ok_fit:
+                    msgs.append("fit(device solve != host solve)")
+                if np.isfinite(vpf).all() and np.isfinite(wpf).all():
+                    wb2, wp2, wh2, wo2 = W.predict(ch, vpf[ch].reshape(-1), wpf[ch].reshape(-1))
+                    if not (np.array_equal(b2[ch], wb2) and np.array_equal(p2[ch], wp2) and np.array_equal(h2[ch], wh2) and int(oob2[ch]) == wo2):
+                        msgs.append("chain-K2")
+                order = P.set_stream_order()
+                sym, vps, wps, hs, oobs = P.encode_image_symbols(img, q, fit=True)
+                if not (np.array_equal(vps.view(np.uint32), vpf.view(np.uint32)) and np.array_equal(wps.view(np.uint32), wpf.view(np.uint32)) and np.array_equal(hs, h2)):
+                    msgs.append("symbols-route(params/hist)")
+                if int(oob2.sum()) == 0:
+                    for cc in range(c):
+                        d = (co[cc].reshape(-1)[order].astype(np.int64) - p2[cc].reshape(-1)[order].astype(np.int64)).astype(np.int32)
+                        ref = (b2[cc].reshape(-1)[order].astype(np.uint32) << 10 | (((d.astype(np.uint32) << 1) ^ (d >> 31).astype(np.uint32)) & 1023)).astype(np.uint16)
+                        if not np.array_equal(sym[cc], ref):
+                            msgs.append(f"K5 ch{cc}")
+            except frave_amd.api.FriHipError as e:
+                msgs.append(f"chain error {e}")
         if msgs:
             bad += 1
             print(f"case {case}: {w}x{h}x{c} {kind} q={q[:10].tolist()}: MISMATCH in {msgs}", flush=True)
         P.close()
         W.close()
-    print(f"{n_cases} cases, {bad} mismatching, {time.time() - t0:.0f} s")
+    print(f"{n_cases} cases ({chains} with the fitted chain and the symbol stream route), {bad} mismatching, {time.time() - t0:.0f} s")
     return bad
 
 
