@@ -80,7 +80,7 @@ def kernels(w, h, c, slots, label):
     line("encode chain K1 -> K2 (params given)", enc, w * h, alg1 + c * (F * 512 * 9 + 40960))
     vpf, wpf = np.zeros((c, 3, 6), np.float32), np.zeros((c, 3, 6), np.float32)
     encf = timed(lambda: P.encode_image_dev(px0, co0, d_ba.data_ptr(), d_pa.data_ptr(), d_ha.data_ptr(), d_oa.data_ptr(), vpf, wpf, fit=True, stream=s), 20)
-    line("encode chain with the fit (2 host syncs)", encf, w * h, alg1 + c * (F * 512 * 17 + 40960))
+    line("encode chain with the fit (device solves)", encf, w * h, alg1 + c * (F * 512 * 17 + 40960))
     ok = bool(torch.equal(d_back, d_px[0]))
     tot = int(d_h.sum()) + int(d_o.item())
     print(f"    lossless K3(K1(x)) == x: {ok};  histogram total {tot} == Some coefficients {P.num_some}: {tot == P.num_some}")

@@ -35,6 +35,9 @@ pc = lambda a: " ".join(f"{np.percentile(a, q):7.2f}" for q in (0, 10, 50, 90, 1
 print(f"{len(tr)} workgroups")
 print("                      min     p10     p50     p90     max   [us since first entry]")
 print("entry              ", pc(us(tr[:, 0])))
+if (tr[:, 11] > 0).all():  # (one-off stamps of a hacked tuning build: slot lists in LDS / the first tile's loads have landed)
+    print("ring in LDS        ", pc(us(tr[:, 11])))
+    print("tile 0 data landed ", pc(us(tr[:, 12])))
 print("prologue done      ", pc(us(tr[:, 1])))
 prev = tr[:, 1]
 for i in range(11):
