@@ -357,6 +357,9 @@ def main():
     if rank == 0:
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        elif world > 1:
+            out["cpu_baseline"] = None  # measured at N = 1 only (the contract: rank 0 at N = 1); the N = 1 line of the same round carries it
+            out["cpu_baseline_note"] = "timed on rank 0 at N = 1 only; see the N = 1 line"
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
