@@ -199,7 +199,9 @@ def extras(plan, ctx, torch, np, px0, co0, pstride, cstride, slots, alg_bytes, s
         it[0] += 1
         plan3.transform_quant_dev(d_px3[k].data_ptr(), d_co3[k].data_ptr(), stream=stream)
 
-    res["k1_rgb"] = entry(timed(k1_rgb, reps=30), plan3.pixel_bytes + plan3.coef_count * 4)
+    for _ in range(60):  # this plan's first launches: tables and buffers are cold, and 30 launches alone measured 58 us where the steady state is 54
+        k1_rgb()
+    res["k1_rgb"] = entry(timed(k1_rgb, reps=120), plan3.pixel_bytes + plan3.coef_count * 4)
     del d_px3, d_co3
     plan3.close()
     # K1 with many images per launch (the batch entry point; BASELINE config 4 runs like this). Two figures that must not be confused: a launch
