@@ -509,6 +509,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
         d.k2_ablate = env_int("FRI_HIP_K2_ABLATE");
+        if (const char *v3 = env_str("FRI_HIP_K4_VALUE3")) d.k4_value3 = std::atoi(v3) != 0;
         if (const char *e = env_str("FRI_HIP_K1_BATCH_SHARES")) d.k1_batch_shares = std::atoi(e) != 0;
         d.k3_ablate = env_int("FRI_HIP_K3_ABLATE");
         d.k4_ablate = env_int("FRI_HIP_K4_ABLATE");
@@ -780,7 +781,10 @@ static int fit_launch(fri_hip_plan *p, int mode, const PredBatch &b, int64_t *d_
                       const FitSolve *solve = nullptr) {
     const int slot = acquire_acc(p, stream, b.n_planes);
     if (slot < 0) return slot;
-    if (hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream, solve)) {
+    const hipError_t e = mode == 0 && p->dev.k4_value3 && !p->dev.k4_previous
+                             ? launch_fit_value3(p->dev, p->acc_slots[slot].fit_acc, b, (unsigned long long *)d_int, d_range, stream, solve)
+                             : launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream, solve);
+    if (e != hipSuccess) {
         p->acc_dirty = true;
         return fail_hip(p->ctx, e, "launch_fit_accumulate");
     }

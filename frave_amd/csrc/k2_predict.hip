@@ -1,6 +1,7 @@
 // k2_predict.hip -- K2 predict_histogram: 6-neighbour gather + context bucket + prediction + ANS symbol histogram for one
 // channel plane (context_modeling.rs:25-77; stages/prediction.rs:86-207, 237-298).
 #include "gather_common.hpp"
+#include "solve6.hpp"
 
 #include <algorithm>
 #include <vector>
@@ -1111,7 +1112,405 @@ __global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const Pr
     trace_exit(a.trace, blockIdx.x, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// K4, value pass, on THIS kernel's skeleton (round 3): fit_value_kernel3. The sums of optimize_value_prediction (context_modeling.rs:175-202) are
+// the Gram matrix of u = [v0..v5, value] per layer group - the same six gathers per node as the predictor plus the node itself. fit_accumulate_kernel2
+// (k4_fit.hip: 512 threads, int16 cell images, v_dot2 on packed pairs, gathers the compiler schedules) spends a fifth of its time on those products and
+// the rest waiting; here the values arrive as f32 through the hand-pipelined ds_read_u16_d16_hi blocks of K2 (seven per node: the node's own value is a
+// seventh gather instead of a register) and a product-sum is one v_fma_f32. Everything is an integer of magnitude <= 65 536 = 256^2 in f32, exact while a
+// lane's sum stays below 2^24: a lane sees eight rows per tile, so the sums are flushed (as integers) every 16 tiles. One layer group per wave, and
+// every wave works on ONE pair of a lane's nodes in the FOUR block cells of its block row (slots 1 KiB apart, like K2's two): role-0 waves take 2 lane,
+// 2 lane + 1 (levels 0..6, group 2; even wave pairs) or 128 + 2 lane, + 1 (level 7, group 1; odd pairs), role-1 waves 256 + 4 lane + {0, 1} or + {2, 3}
+// (level 8, group 0) - fourteen addresses per lane where K2's four nodes need twenty-four. The roles differ in what they STAGE of the wave pair's two cells: K2's split.
+// Staging, images, slot ring and tile walk are K2's; hand-over, accumulator and the solve in the tail are fit_accumulate_kernel2's.
+// STATUS: an experiment, NOT the product path (DevicePlan::k4_value3, FRI_HIP_K4_VALUE3=1 under FRI_HIP_TUNING=1; tests/test_gpu_fit.py checks it bit for bit
+// against the product kernel). It is exact and it is slower: 41.7 us against 37.5 us for a 4096^2 plane. What the time stamps say: a tile takes 3.2-3.4 us here
+// too - K2's figure, with a third of K2's arithmetic, with one or two gather sets, with the staging loads one or two tiles ahead - and the wave sums of sixteen
+// waves cost ~4 us at the end. One 1024-thread workgroup per CU with a barrier per tile does not keep the CU busy; fit_accumulate_kernel2's two independent
+// 512-thread workgroups per CU cover each other's stalls (28 us for its tiles against 33.5 us here). The skeleton to carry over is that one, not K2's.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Fit3Args {
+    const int32_t *coefs;
+    size_t coef_stride;
+    const int32_t *pred_slots;
+    const uint32_t *gather_off; // [512][4] byte offsets of the six neighbours in the permuted 1 KiB layout (build_gather_tables)
+    const uint16_t *pair_pos;
+    const uint32_t *halo_list;
+    const uint32_t *valid_mask;
+    uint32_t n_tiles;
+    unsigned long long *acc;       // per plane: kFitShards copies of kFitAccWords words, zero between launches (the layout of k4_fit.hip)
+    unsigned long long *gram;      // [n_planes][3][28]
+    unsigned long long *out_range; // [n_planes] or NULL
+    float *solve_params;           // as FitArgs (k4_fit.hip): NULL = sums only
+    float *host_params;
+    unsigned long long *host_range;
+    unsigned long long *trace;
+};
+constexpr int kF3AccInt = 3 * 28, kF3AccTicket = kF3AccInt + 18, kF3AccRange = kF3AccTicket + 1; // = kFitAcc* of k4_fit.hip
+static_assert(kF3AccRange + 1 == (int)kFitAccWords, "fit accumulator layout");
+
+// "never a node" entries read the zero words behind an image's cells at the cell's distance from the wave's first cell: up to 3 KiB for role 0's four cells
+// (K2's two cells: 1 KiB), so this kernel's images carry 4 KiB + 64 bytes of zeros
+constexpr int kF3ImageBytes = kP3ZeroOff + 4 * kP3SlotBytes + 64;
+struct F3Lds {
+    uint8_t cells[2][kF3ImageBytes];
+    int32_t ring[4][kPredSlots]; // slot lists of tiles i .. i + 3: the loads of tile i + 2 are issued during tile i
+    uint32_t masks[2][kPredSlots][16];
+    unsigned long long s_int[3][28];
+    uint32_t flag, range;
+    Solve6Work work[3];
+};
+static_assert(sizeof(F3Lds) <= 160 * 1024 && kF3ImageBytes + 3 * kP3SlotBytes < 65536, "LDS budget / image + cell offset must fit a DS instruction's 16-bit offset field");
+
+template <int OFFSET>
+__device__ __forceinline__ void f3_issue(float (&g)[7], const uint32_t (&a)[7]) {
+    asm volatile("ds_read_u16_d16_hi %0, %7 offset:%14\n\t"
+                 "ds_read_u16_d16_hi %1, %8 offset:%14\n\t"
+                 "ds_read_u16_d16_hi %2, %9 offset:%14\n\t"
+                 "ds_read_u16_d16_hi %3, %10 offset:%14\n\t"
+                 "ds_read_u16_d16_hi %4, %11 offset:%14\n\t"
+                 "ds_read_u16_d16_hi %5, %12 offset:%14\n\t"
+                 "ds_read_u16_d16_hi %6, %13 offset:%14"
+                 : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "n"(OFFSET));
+}
+template <int OFFSET>
+__device__ __forceinline__ void f3_issue_wait(float (&nxt)[7], const uint32_t (&a)[7], float (&cur)[7]) {
+    asm volatile("ds_read_u16_d16_hi %0, %14 offset:%21\n\t"
+                 "ds_read_u16_d16_hi %1, %15 offset:%21\n\t"
+                 "ds_read_u16_d16_hi %2, %16 offset:%21\n\t"
+                 "ds_read_u16_d16_hi %3, %17 offset:%21\n\t"
+                 "ds_read_u16_d16_hi %4, %18 offset:%21\n\t"
+                 "ds_read_u16_d16_hi %5, %19 offset:%21\n\t"
+                 "ds_read_u16_d16_hi %6, %20 offset:%21\n\t"
+                 "s_waitcnt lgkmcnt(7)"
+                 : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]), "+v"(nxt[5]), "+v"(nxt[6]), "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]),
+                   "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "n"(OFFSET));
+}
+__device__ __forceinline__ void f3_wait(float (&cur)[7]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]));
+}
+// one row: acc += upper triangle of u u^T, u = [v0..v5, value]; MASKED: the row counts only when m = 1 (a None node / an LF node is no row of the fit)
+template <bool MASKED>
+__device__ __forceinline__ void f3_row(const float (&u)[7], float m, float (&acc)[28]) {
+    float mu[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) mu[i] = MASKED ? __fmul_rn(m, u[i]) : u[i];
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++)
+#pragma unroll
+        for (int j = i; j < 7; j++, n++) acc[n] = __builtin_fmaf(mu[i], u[j], acc[n]);
+}
+// one pair of a lane's nodes in the four block cells of the wave's block row: eight rows in one pipeline. MASKED: m says which of them are rows
+// (the staged Some/None masks; heap nodes 0 and 1); without it all four cells are interior cells and every node is a row.
+template <int IMG, bool MASKED>
+__device__ __forceinline__ void f3_row_of_cells(const uint32_t (&addr)[2][7], uint32_t rows, float (&acc)[28]) {
+    constexpr int kOff = IMG * kF3ImageBytes;
+    // the two gather sets live inside this function (low halves zero: a d16_hi load writes bits 31:16): carried from tile to tile like K2's, they crossed the
+    // interior / boundary branch of the caller and cost fourteen registers there plus copies at its merge
+    float g[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // ONE gather set: issue, wait, 28 multiply-adds - the other three waves of the SIMD cover the wait. (Two alternating sets, as in K2, are fourteen registers
+    // this kernel spends on the second staging set instead: it spilled with both.)
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        if ((t >> 1) == 0) f3_issue<kOff>(g, addr[t & 1]);
+        if ((t >> 1) == 1) f3_issue<kOff + kP3SlotBytes>(g, addr[t & 1]);
+        if ((t >> 1) == 2) f3_issue<kOff + 2 * kP3SlotBytes>(g, addr[t & 1]);
+        if ((t >> 1) == 3) f3_issue<kOff + 3 * kP3SlotBytes>(g, addr[t & 1]);
+        f3_wait(g);
+        f3_row<MASKED>(g, (rows >> t) & 1u ? 1.f : 0.f, acc);
+    }
+}
+// A wave's 28 sums, exact integers in f32, into the workgroup's table. A lane's sum is below 2^24, so the wave's is below 2^30: the whole reduction stays in
+// 32 bits - four butterfly steps inside the rows of 16, then row_bcast:15 / row_bcast:31 carry the row totals into lane 63, which adds the total to LDS
+// (fit2_wave_sums of k4_fit.hip, whose 32-bit bound holds per row only, reads four row totals through readlane into 64-bit scalar adds: four times the instructions).
+__device__ __forceinline__ void f3_wave_sums(float (&acc)[28], int group, int lane, F3Lds &lds) {
+#pragma unroll
+    for (int k = 0; k < 28; k++) {
+        int v = (int)acc[k];
+        acc[k] = 0.f;
+        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
+        if (lane == 63) atomicAdd(&lds.s_int[group][k], (unsigned long long)(long long)v);
+    }
+}
+// staging of one of the wave's own block cells, K2's (p3_commit4) plus the fit's range rule: a Some coefficient outside [-256, 255] is reported
+template <bool CHECK>
+__device__ __forceinline__ void f3_commit4(int raw, i32x4 v, uint8_t *dst, uint32_t pos0, uint32_t pos1, int lane, uint32_t *range_counter) {
+    if (CHECK && raw >= 0) { // a None is 0x80000000: it is not an outlier
+        const int w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) m |= w[j] == kNone ? 0u : ((uint32_t)w[j] + 256u) & 0xFFFFFE00u;
+        if (__any(m != 0) && lane == 0) atomicAdd(range_counter, 1u);
+    }
+    (void)p3_commit4<false>(raw, v, dst, pos0, pos1);
+}
+template <bool CHECK>
+__device__ __forceinline__ void f3_commit_halo(const P3Halo &h, uint8_t *image, uint32_t lds_off, int lane, uint32_t *range_counter) {
+    if (CHECK) {
+        const uint32_t m = (h.raw < 0 || h.v == kNone) ? 0u : ((uint32_t)h.v + 256u) & 0xFFFFFE00u;
+        if (__any(m != 0) && lane == 0) atomicAdd(range_counter, 1u);
+    }
+    (void)p3_commit_halo<false>(h, image, lds_off);
+}
+
+struct F3Lane {
+    uint32_t addr[2][7]; // the six neighbours and the node itself, for the lane's two nodes (first cell of the block row)
+    uint32_t opos[2], halo_ring, halo_heap, halo_lds;
+};
+
+// What a wave stages of one tile: its half of its two block cells, their Some/None masks (role 1), one halo value per lane.
+struct F3Stage {
+    i32x4 own[2];
+    uint32_t mask[2];
+    P3Halo halo;
+    int raw[2];
+};
+template <int ROLE>
+__device__ __forceinline__ void f3_stage_issue(const Fit3Args &a, const int32_t *plane, const int32_t *slots, int slot_a, int lane, const F3Lane &L, F3Stage &st) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        st.raw[c] = __builtin_amdgcn_readfirstlane(slots[slot_a + c]);
+        const int cell = max(pred_slot_cell(st.raw[c]), 0);
+        st.own[c] = p3_load_own<ROLE>(plane + (size_t)cell * kCell, (uint32_t)lane);
+        if (ROLE == 1) st.mask[c] = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u];
+    }
+    p3_issue_halo(plane, slots, L.halo_ring, L.halo_heap, st.halo);
+}
+template <int ROLE, bool CHECK>
+__device__ __forceinline__ void f3_stage_commit(F3Lds &lds, uint32_t img, int slot_a, int lane, const F3Lane &L, const F3Stage &st) {
+    asm volatile("" : "+s"(img)); // (as in p3_tile: keeps the write addresses from being hoisted out of the loop into registers it does not have)
+    uint8_t *image = lds.cells[0] + img * kF3ImageBytes;
+    uint32_t *masks = &lds.masks[0][0][0] + img * (kPredSlots * 16);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        f3_commit4<CHECK>(st.raw[c], st.own[c], image + (slot_a + c) * kP3SlotBytes, L.opos[0], L.opos[1], lane, &lds.range);
+        if (ROLE == 1 && lane < 16) masks[(slot_a + c) * 16 + lane] = st.mask[c];
+    }
+    f3_commit_halo<CHECK>(st.halo, image, L.halo_lds, lane, &lds.range);
+}
+
+// One tile out of image IMG. The loads of tile i + 2 are issued here, into `issue`; `commit` holds tile i + 1, requested a tile ago, and goes into the other
+// image behind this tile's sums: a staging load has two tile times to arrive. (With K2's one-tile window the tile time of this kernel was the latency of
+// those loads - 3.2 us, K2's figure, with a third of K2's arithmetic.)
+template <int IMG, int ROLE, bool CHECK>
+__device__ __forceinline__ void f3_tile(const Fit3Args &a, const int32_t *plane, F3Lds &lds, int it, bool more1, bool more2, uint32_t next3_tile, int tid, int lane, int slot_a,
+                                        int slot_row, uint32_t mask_word, uint32_t mask_shift, bool lf_lane, bool lf_wave, const F3Lane &L, F3Stage &issue, const F3Stage &commit,
+                                        float (&acc)[28]) {
+    const int32_t *cur_slots = lds.ring[it & 3];
+    const int32_t slot_pre = a.pred_slots[(size_t)next3_tile * kPredSlots + tid % kPredSlots];
+    if (more2) f3_stage_issue<ROLE>(a, plane, lds.ring[(it + 2) & 3], slot_a, lane, L, issue);
+    {
+        // all four cells interior and no LF lane in the wave: every node is a row (wave-uniform; decided before the first gather is issued)
+        int all_interior = lf_wave ? 0 : 1;
+#pragma unroll
+        for (int c = 0; c < 4; c++) all_interior &= pred_slot_interior(__builtin_amdgcn_readfirstlane(cur_slots[slot_row + c])) ? 1 : 0;
+        if (all_interior) {
+            f3_row_of_cells<IMG, false>(L.addr, 255u, acc);
+        } else {
+            // the pair's Some bits in the four cells, read before the first gather is issued. A slot without a cell has no rows at all (its own values are
+            // zeros, but its gathers would see the neighbouring cells).
+            uint32_t rows = 0; // bit 2 c + n: node n of the pair in cell c is a row
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const bool absent = __builtin_amdgcn_readfirstlane(cur_slots[slot_row + c]) < 0;
+                const uint32_t bits = (lf_lane || absent) ? 0u : lds.masks[IMG][slot_row + c][mask_word] >> mask_shift;
+                rows |= (bits & 3u) << (2 * c);
+            }
+            asm volatile("" : "+v"(rows)); // (complete now: no LDS wait of the compiler's between the blocks below)
+            f3_row_of_cells<IMG, true>(L.addr, rows, acc);
+        }
+    }
+    if (more1) f3_stage_commit<ROLE, CHECK>(lds, IMG ^ 1, slot_a, lane, L, commit);
+    if (tid < kPredSlots) lds.ring[(it + 3) & 3][tid] = slot_pre;
+    lds_barrier();
+    trace_stamp(a.trace, blockIdx.x, 2 + it, tid);
+}
+
+template <int ROLE, bool CHECK>
+__device__ __forceinline__ void f3_run(const Fit3Args &a, const int32_t *plane, F3Lds &lds, int tid, int lane, int wave) {
+    uint8_t *s_cells = lds.cells[0];
+    int32_t *s_ring = &lds.ring[0][0];
+    const int pair = wave >> 1;
+    const int slot_a = (1 + (pair >> 1)) * kPredSide + 1 + 2 * (pair & 1); // the wave's two block cells (staging; role 1 also works on them)
+    const int slot_row = (1 + (pair >> 1)) * kPredSide + 1;               // role 0 works on the four cells of its block row
+    const int group = ROLE ? 0 : (pair & 1) ? 1 : 2;
+    const int node0 = ROLE ? 256 + 4 * lane + 2 * (pair & 1) : (pair & 1) ? 128 + 2 * lane : 2 * lane;
+    const bool lf_wave = ROLE == 0 && !(pair & 1), lf_lane = lf_wave && lane == 0; // heap nodes 0 and 1 are the LF predictor's: no rows of the fit
+    const uint32_t mask_word = (uint32_t)node0 >> 5, mask_shift = (uint32_t)node0 & 31u;
+
+    F3Lane L;
+    const uint32_t cells_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_cells;
+    const int base_slot = slot_row;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int node = node0 + j;
+        const u32x4 o = reinterpret_cast<const u32x4 *>(a.gather_off)[node];
+        const uint32_t rel[3] = {o.x, o.y, o.z};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int r = (int)(short)((rel[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+            // "never a node": the image's zero words; the further cells of the wave read them up to 3 KiB further on - zeros too (see the kernel)
+            L.addr[j][k] = r == 0x7FFF ? cells_lds + kP3ZeroOff : cells_lds + (uint32_t)(base_slot * kP3SlotBytes + r);
+        }
+        L.addr[j][6] = cells_lds + (uint32_t)(base_slot * kP3SlotBytes) + 2u * (2u * a.pair_pos[node >> 1] + (uint32_t)(node & 1)); // the node itself
+    }
+    L.opos[0] = 4u * a.pair_pos[ROLE ? 128 + 2 * lane : lane];
+    L.opos[1] = 4u * a.pair_pos[ROLE ? 129 + 2 * lane : 64 + lane];
+    {
+        const uint32_t e = a.halo_list[tid];
+        L.halo_ring = 4u * (e & 63u), L.halo_heap = 4u * ((e >> 8) & 511u), L.halo_lds = (e & 63u) * (uint32_t)kP3SlotBytes + (e >> 20);
+    }
+    float acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; k++) acc[k] = 0.f;
+
+    const PredTileWalk walk(a.n_tiles);
+    if (walk.first >= walk.end) return;
+    const uint32_t last = walk.first + ((walk.end - 1 - walk.first) / walk.step) * walk.step;
+    if (tid < kPredSlots) {
+        s_ring[tid] = a.pred_slots[(size_t)walk.first * kPredSlots + tid];
+        s_ring[kPredSlots + tid] = a.pred_slots[(size_t)min(walk.first + walk.step, last) * kPredSlots + tid];
+        s_ring[2 * kPredSlots + tid] = a.pred_slots[(size_t)min(walk.first + 2 * walk.step, last) * kPredSlots + tid];
+    }
+    __syncthreads();
+    F3Stage st_a, st_b; // tiles of even / odd index
+    f3_stage_issue<ROLE>(a, plane, s_ring, slot_a, lane, L, st_a);
+    if (walk.first + walk.step < walk.end) f3_stage_issue<ROLE>(a, plane, s_ring + kPredSlots, slot_a, lane, L, st_b); // tile 1: in flight through tile 0
+    f3_stage_commit<ROLE, CHECK>(lds, 0u, slot_a, lane, L, st_a);                                                       // tile 0 straight into image 0
+    lds_barrier();
+    trace_stamp(a.trace, blockIdx.x, 1, tid);
+
+    int it = 0, since_flush = 0;
+    for (uint32_t tile = walk.first; tile < walk.end;) { // unrolled by two: the LDS image a tile lives in is a compile-time constant
+        f3_tile<0, ROLE, CHECK>(a, plane, lds, it, tile + walk.step < walk.end, tile + 2 * walk.step < walk.end, min(tile + 3 * walk.step, last), tid, lane, slot_a, slot_row, mask_word,
+                                mask_shift, lf_lane, lf_wave, L, st_a, st_b, acc);
+        tile += walk.step, it++;
+        if (tile < walk.end) {
+            f3_tile<1, ROLE, CHECK>(a, plane, lds, it, tile + walk.step < walk.end, tile + 2 * walk.step < walk.end, min(tile + 3 * walk.step, last), tid, lane, slot_a, slot_row,
+                                    mask_word, mask_shift, lf_lane, lf_wave, L, st_b, st_a, acc);
+            tile += walk.step, it++;
+        }
+        since_flush += 2;
+        if (since_flush >= 16) { // eight rows per tile and lane, each product <= 2^16: sixteen tiles stay below 2^24 - exact in f32
+            f3_wave_sums(acc, group, lane, lds);
+            since_flush = 0;
+        }
+    }
+    f3_wave_sums(acc, group, lane, lds);
+}
+
+// the three solves at the end of the kernel (as fit2_tail_solve of k4_fit.hip: not inlined, so that its f64 temporaries stay out of the tile loop's budget)
+__device__ __attribute__((noinline)) void f3_tail_solve(const long long *sums_int, Solve6Work *w, float *params, float *host_params) {
+    float out[6];
+    fit_value_group(sums_int, out, *w);
+#pragma unroll
+    for (int k = 0; k < 6; k++) params[k] = out[k];
+    if (host_params) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) host_params[k] = out[k];
+    }
+}
+
+template <bool CHECK>
+__global__ void __launch_bounds__(kP3Threads) fit_value_kernel3(const Fit3Args a) {
+    const uint32_t plane_i = blockIdx.y;
+    const int32_t *const plane = a.coefs + plane_i * a.coef_stride;
+    unsigned long long *const accp = a.acc + (size_t)plane_i * kFitShards * kFitAccWords;
+    unsigned long long *const accs = accp + (size_t)(blockIdx.x % kFitShards) * kFitAccWords;
+    __shared__ __attribute__((aligned(16))) F3Lds lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    trace_stamp(a.trace, blockIdx.x, 0, tid);
+    if (tid < 3 * 28) (&lds.s_int[0][0])[tid] = 0;
+    if (tid == 0) lds.range = 0;
+    for (int i = tid; i < 2 * (kF3ImageBytes - kP3ZeroOff) / 4; i += kP3Threads) // the zero words behind the cells of both images
+        reinterpret_cast<uint32_t *>(lds.cells[0] + (i / ((kF3ImageBytes - kP3ZeroOff) / 4)) * kF3ImageBytes + kP3ZeroOff)[i % ((kF3ImageBytes - kP3ZeroOff) / 4)] = 0;
+    if (wave & 1)
+        f3_run<1, CHECK>(a, plane, lds, tid, lane, wave);
+    else
+        f3_run<0, CHECK>(a, plane, lds, tid, lane, wave);
+    __syncthreads();
+    trace_stamp(a.trace, blockIdx.x, 13, tid);
+    // hand-over as in fit_accumulate_kernel2: adds into this workgroup's copy of the plane's accumulator, a ticket, the last workgroup sums the copies
+    if (tid < kF3AccInt) __hip_atomic_fetch_add(accs + tid, (&lds.s_int[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && lds.range) __hip_atomic_fetch_add(accp + kF3AccRange, (unsigned long long)lds.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    wait_for_own_memory_ops_then_barrier();
+    if (tid == 0) lds.flag = __hip_atomic_fetch_add(accp + kF3AccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    trace_exit(a.trace, blockIdx.x, tid);
+    if (lds.flag == 0 || tid >= 64) return;
+    unsigned long long *const out_int = a.gram + (size_t)plane_i * kF3AccInt;
+    for (int i = tid; i < kF3AccInt; i += 64) {
+        unsigned long long part[kFitShards], sum = 0;
+#pragma unroll
+        for (uint32_t sh = 0; sh < kFitShards; sh++) part[sh] = __hip_atomic_load(accp + sh * kFitAccWords + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (uint32_t sh = 0; sh < kFitShards; sh++) {
+            sum += part[sh];
+            __hip_atomic_store(accp + sh * kFitAccWords + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        out_int[i] = sum;
+        (&lds.s_int[0][0])[i] = sum;
+    }
+    if (tid == 0) {
+        const unsigned long long r = __hip_atomic_exchange(accp + kF3AccRange, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.out_range) a.out_range[plane_i] = r;
+        if (a.host_range) a.host_range[plane_i] = r;
+        __hip_atomic_store(accp + kF3AccTicket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!a.solve_params) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (tid < 3) {
+        const size_t at = (size_t)plane_i * (sizeof(PredictParams) / sizeof(float)) + tid * 6;
+        f3_tail_solve(reinterpret_cast<const long long *>(lds.s_int[tid]), &lds.work[tid], a.solve_params + at, a.host_params ? a.host_params + at : nullptr);
+    }
+}
+
 } // namespace
+
+hipError_t launch_fit_value3(const DevicePlan &p, unsigned long long *acc, const PredBatch &b, unsigned long long *sums_int, unsigned long long *out_of_range, hipStream_t stream,
+                             const FitSolve *solve) {
+    if (!acc || !sums_int || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
+    Fit3Args a{};
+    a.coefs = b.coefs;
+    a.coef_stride = b.coef_stride;
+    a.pred_slots = p.pred_slots;
+    a.gather_off = p.gather_off;
+    a.pair_pos = p.pair_pos;
+    a.halo_list = p.halo_list;
+    a.valid_mask = p.valid_mask;
+    a.n_tiles = p.n_pred_tiles;
+    a.acc = acc;
+    a.gram = sums_int;
+    a.out_range = out_of_range;
+    a.trace = p.trace;
+    if (solve) {
+        if (!solve->params) return hipErrorInvalidValue;
+        a.solve_params = solve->params, a.host_params = solve->host_params, a.host_range = solve->host_range;
+    }
+    // the grid of launch_predict_histogram: one plane = a workgroup per CU; many planes = an eighth of the machine each, eight side by side
+    uint32_t blocks = p.n_pred_tiles < p.pred_blocks ? p.n_pred_tiles : p.pred_blocks;
+    if (b.n_planes > 1) {
+        const uint32_t share = (p.n_pred_tiles + 7) / 8, eighth = p.pred_blocks / 8 ? p.pred_blocks / 8 : 1;
+        blocks = share < eighth ? eighth : share;
+        if (blocks > p.pred_blocks) blocks = p.pred_blocks;
+        if (blocks > p.n_pred_tiles) blocks = p.n_pred_tiles;
+    }
+    if (!blocks) blocks = 1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((fit_value_kernel3<true>), dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
+    return hipGetLastError();
+}
 
 void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out) {
     for (int p = 0; p < kCell; p++) {

@@ -50,6 +50,7 @@ struct DevicePlan {
     bool k1_batch_shares = true; // FRI_HIP_K1_BATCH_SHARES=0 disables the merged shares (A/B)
     int32_t k1_ablate = 0; // timing-only ablation flags, see FwdArgs::ablate
     int32_t k2_ablate = 0; // the same for K2, see PredArgs::ablate
+    bool k4_value3 = false; // tuning (FRI_HIP_K4_VALUE3=1): the fit's value pass as fit_value_kernel3, the experiment on K2's skeleton (k2_predict.hip) - exact, 4 us slower
     unsigned long long *trace = nullptr; // [n_wg][16] diagnostic timeline (FRI_HIP_TRACE=1), else null
     // K3's static write-out lists (null = not built: the kernel scans the rectangle)
     const InvTileLists *inv_lists = nullptr;
@@ -118,6 +119,9 @@ struct FitSolve {
 };
 hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
                                  unsigned long long *out_of_range, hipStream_t stream, const FitSolve *solve = nullptr);
+// The value pass (mode 0 above) on K2's skeleton: fit_value_kernel3 (k2_predict.hip). Same accumulator, same sums, same solve in the tail.
+hipError_t launch_fit_value3(const DevicePlan &p, unsigned long long *acc, const PredBatch &b, unsigned long long *sums_int, unsigned long long *out_of_range, hipStream_t stream,
+                             const FitSolve *solve = nullptr);
 // The fit's 6 x 6 solves on the device: sums of a launch_fit_accumulate (mode 0: sums_int[n_planes][3][28]; mode 1: sums_int[n_planes][3][21],
 // sums_dbl[n_planes][3][6], rows[3] = heights of the reference's matrices) -> params[n_planes] (PredictParams: mode 0 writes .value, mode 1 .width).
 // host_params / host_range (device-visible pointers into mapped host memory, or NULL): the solving threads also leave the parameters - and the

@@ -76,6 +76,29 @@ def test_fit_sums_match_cpu(ctx, oracle, shape, kind):
         assert rows.tolist() == [P.num_cells * 256, P.num_cells * 128, P.num_cells * 128]
 
 
+@pytest.mark.parametrize("shape", [(37, 100, 1), (700, 500, 3), (2048, 1536, 1)])
+def test_value_sums_on_the_scan_kernels_skeleton(ctx, shape, monkeypatch):
+    """fit_value_kernel3 (the value pass on K2's skeleton: an experiment behind a tuning switch, k2_predict.hip): bit for bit the sums of the product kernel,
+    for sums alone and with the solve in its tail (the chain's parameters)."""
+    import frave_amd
+
+    w, h, c = shape
+    img = gen_image("noise", w, h, c, 5)
+    img[:, : w // 2] = gen_image("smooth", w // 2, h, c, 6)
+    P = frave_amd.Plan(ctx, w, h, c)
+    monkeypatch.setenv("FRI_HIP_TUNING", "1")
+    monkeypatch.setenv("FRI_HIP_K4_VALUE3", "1")
+    P3 = frave_amd.Plan(ctx, w, h, c)  # (the switch is read at plan creation)
+    monkeypatch.delenv("FRI_HIP_K4_VALUE3")
+    monkeypatch.delenv("FRI_HIP_TUNING")
+    co = P.transform_quant(img)
+    for ch in range(c):
+        assert np.array_equal(P3.fit_value_sums(co, ch), P.fit_value_sums(co, ch))
+    a, b = P.encode_image(img, fit=True), P3.encode_image(img, fit=True)
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))  # value / width parameters
+    assert np.array_equal(a[5], b[5])  # histograms
+
+
 def test_fitted_parameters_reduce_the_residual(ctx, oracle):
     """Solve the two 6 x 6 systems on the host and use the result: it must be the least-squares optimum (no worse than
     numpy's lstsq on the explicit design matrix), and K2 must run with it."""

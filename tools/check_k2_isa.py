@@ -21,7 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "frave_amd", "csrc")
-KERNEL = "predict_histogram_kernel3"
+KERNEL = "(predict_histogram_kernel3|fit_value_kernel3)"  # every kernel of the file with hand-pipelined gather blocks
 
 
 def make_assembly():
@@ -45,7 +45,7 @@ def scan(asm):
     """(number of gather blocks seen, list of problems) for the product kernel in assembly file `asm`."""
     lines = open(asm).read().splitlines()
     blocks, errors = 0, []
-    for start in [i for i, l in enumerate(lines) if re.match(r"^_ZN.*" + KERNEL + r".*:", l)]:  # every instantiation of the kernel template
+    for start in [i for i, l in enumerate(lines) if re.match(r"^_ZN.*" + KERNEL + r".*:", l)]:  # every instantiation of the kernel templates
         end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
         b, e = scan_function(lines, start, end)
         blocks += b
@@ -75,9 +75,11 @@ def scan_function(lines, start, end):
                 waits = [b for b in body if b.startswith("s_waitcnt")]
                 if waits and "lgkmcnt(0)" in waits[-1]:
                     in_flight = set()
-                elif waits and "lgkmcnt(6)" in waits[-1]:
-                    if len(loads) != 6:
-                        errors.append(f"line {j}: lgkmcnt(6) behind {len(loads)} loads")
+                elif waits and re.search(r"lgkmcnt\((\d+)\)", waits[-1]):
+                    # lgkmcnt(N) behind N gathers: exactly the block's own loads stay in flight (K2: 6 per node, the fit's value pass: 7)
+                    n = int(re.search(r"lgkmcnt\((\d+)\)", waits[-1]).group(1))
+                    if len(loads) != n:
+                        errors.append(f"line {j}: lgkmcnt({n}) behind {len(loads)} loads")
                     in_flight = set(issued)
                 else:
                     in_flight |= issued

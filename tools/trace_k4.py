@@ -37,7 +37,7 @@ print("                      min     p10     p50     p90     max   [us since fir
 print("entry              ", pc(us(tr[:, 0])))
 print("prologue done      ", pc(us(tr[:, 1])))
 prev = tr[:, 1]
-for i in range(6):
+for i in range(11):
     m = tr[:, 2 + i] > tr[:, 1]
     if not m.any():
         break
