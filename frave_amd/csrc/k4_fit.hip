@@ -428,23 +428,39 @@ __device__ __forceinline__ void fit2_cells(const int32_t *s_slot_cell, const int
     fit2_cell<MODE, IMG, C0 + 3>(s_slot_cell, s_slot_interior, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
 }
 
-// Sum of v over the 16 lanes of the lane's DPP row, in every lane of the row: quad_perm(1,0,3,2), quad_perm(2,3,0,1), row_half_mirror, row_mirror
-__device__ __forceinline__ int fit2_row_sum(int v) {
+// Sum of v over the 64 lanes of the wave, in lane 63: quad_perm(1,0,3,2), quad_perm(2,3,0,1), row_half_mirror, row_mirror leave every row's total in all of its
+// lanes; row_bcast:15 carries it into rows 1 and 3, row_bcast:31 the total of rows 0-1 into rows 2 and 3. 32-bit throughout: a lane adds at most 8 cells x
+// 2 x 256^2 = 2^20 per tile to a sum, a wave 2^26, so with a flush every 16 tiles the wave's total stays below 2^30.
+__device__ __forceinline__ int fit2_wave_total(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
     v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
     v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
     v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
     return v;
 }
 template <int NI>
 __device__ __forceinline__ void fit2_wave_sums(int (&acc)[28], int group, int lane, unsigned long long (*s_int)[28]) {
 #pragma unroll
     for (int k = 0; k < NI; k++) {
-        const int r = fit2_row_sum(acc[k]);
-        acc[k] = 0;
-        const long long sum = ((long long)__builtin_amdgcn_readlane(r, 0) + __builtin_amdgcn_readlane(r, 16)) +
-                              ((long long)__builtin_amdgcn_readlane(r, 32) + __builtin_amdgcn_readlane(r, 48));
-        if (lane == 0) atomicAdd(&s_int[group][k], (unsigned long long)sum);
+        if (NI == 28) { // the value pass: |u| <= 256, see fit2_wave_total
+            const int total = fit2_wave_total(acc[k]);
+            acc[k] = 0;
+            // (round 2 read the four row totals out through readlane and added them as 64-bit scalars: a vector -> scalar -> vector chain per sum, three
+            // times the instructions - a good part of the 5 us between a workgroup's last tile and its ticket)
+            if (lane == 63) atomicAdd(&s_int[group][k], (unsigned long long)(long long)total);
+        } else { // the width pass: features up to 511, a product up to 2^18 - four times the value pass's: 32 bits hold a ROW of 16 lanes for 16 tiles, not the wave
+            int r = acc[k];
+            acc[k] = 0;
+            r += __builtin_amdgcn_update_dpp(0, r, 0xB1, 0xF, 0xF, true);
+            r += __builtin_amdgcn_update_dpp(0, r, 0x4E, 0xF, 0xF, true);
+            r += __builtin_amdgcn_update_dpp(0, r, 0x141, 0xF, 0xF, true);
+            r += __builtin_amdgcn_update_dpp(0, r, 0x140, 0xF, 0xF, true);
+            const long long sum = ((long long)__builtin_amdgcn_readlane(r, 0) + __builtin_amdgcn_readlane(r, 16)) +
+                                  ((long long)__builtin_amdgcn_readlane(r, 32) + __builtin_amdgcn_readlane(r, 48));
+            if (lane == 0) atomicAdd(&s_int[group][k], (unsigned long long)sum);
+        }
     }
 }
 
