@@ -11,7 +11,7 @@ import torch
 import frave_amd
 
 ctx = frave_amd.Context(0)
-ctx_cus = int(os.environ.get("FRI_HIP_PRED_BLOCKS", "256"))
+ctx_cus = int(os.environ.get("TRACE_ROWS", os.environ.get("FRI_HIP_PRED_BLOCKS", "256")))  # rows of the trace = workgroups of the launch
 plan = frave_amd.Plan(ctx, 4096, 4096, 1)
 F = plan.num_cells
 s = torch.cuda.current_stream().cuda_stream
@@ -41,7 +41,7 @@ if (tr[:, 11] > 0).all():  # (one-off stamps of a hacked tuning build: slot list
 print("prologue done      ", pc(us(tr[:, 1])))
 prev = tr[:, 1]
 for i in range(11):
-    m = tr[:, 2 + i] > 0
+    m = (tr[:, 2 + i] > tr[:, 1]) & (tr[:, 2 + i] <= tr[:, 13])  # (a slot this launch did not stamp holds an older kernel's)
     if not m.any():
         break
     print(f"tile {i} done ({m.sum():4d})", pc(us(tr[m, 2 + i])), "  duration", pc((tr[m, 2 + i] - prev[m]) / 100.0))
@@ -52,7 +52,7 @@ print("exit               ", pc(us(tr[:, 15])), "  merge", pc((tr[:, 15] - tr[:,
 dur = np.zeros((len(tr), 11))
 prev = tr[:, 1]
 for i in range(11):
-    m = tr[:, 2 + i] > 0
+    m = (tr[:, 2 + i] > tr[:, 1]) & (tr[:, 2 + i] <= tr[:, 13])
     dur[m, i] = (tr[m, 2 + i] - prev[m]) / 100.0
     prev = np.where(m, tr[:, 2 + i], prev)
 slow = np.argwhere(dur > 7.5)
