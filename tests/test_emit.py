@@ -344,6 +344,50 @@ def test_symbol_stream_on_the_device(shape):
 
 
 @pytest.mark.gpu
+def test_symbol_stream_entry_points_reject_what_they_cannot_do():
+    """No stream order uploaded, a stream order that is no permutation of the Some nodes, strides that overlap: error codes, and the plan stays usable."""
+    import torch
+
+    import frave_amd
+
+    w, h, c = 160, 96, 3
+    ctx = frave_amd.Context(0)
+    P = frave_amd.Plan(ctx, w, h, c)
+    plane, n = P.num_cells * 512, P.num_some
+    img = _mixed_image(w, h, c, 3)
+    with pytest.raises(frave_amd.api.FriHipError):  # no order yet
+        P.encode_image_symbols(img)
+    order = emit.stream_order(P.centers(), P.valid_mask())
+    bad = order.copy()
+    bad[0] = bad[1]  # a node twice, another never
+    with pytest.raises(frave_amd.api.FriHipError):
+        P.set_stream_order(bad)
+    with pytest.raises(frave_amd.api.FriHipError):
+        P.set_stream_order(order[:-1])
+    P.set_stream_order(order)
+    d_px = torch.from_numpy(np.stack([img, img]).reshape(-1)).cuda()
+    d_co = torch.empty((2, c, plane), dtype=torch.int32, device="cuda")
+    d_w = torch.empty((2, c, plane), dtype=torch.uint16, device="cuda")
+    d_st = torch.empty((2, c, n), dtype=torch.uint16, device="cuda")
+    d_h = torch.empty((2, c, 10, 1024), dtype=torch.int32, device="cuda")
+    d_o = torch.empty((2, c), dtype=torch.int64, device="cuda")
+    d_par = torch.zeros((2, c, 2, 3, 6), dtype=torch.float32, device="cuda")
+    args = lambda **k: dict(dict(n_images=2, pixel_stride=P.pixel_bytes, coef_stride=c * plane, word_stride=c * plane, symbol_stride=c * n), **k)
+    def call(**k):
+        a = args(**k)
+        P.encode_symbols_batch_dev(a["n_images"], d_px.data_ptr(), a["pixel_stride"], None, True, d_par.data_ptr(), d_co.data_ptr(), a["coef_stride"], d_w.data_ptr(), a["word_stride"],
+                                   d_st.data_ptr(), a["symbol_stride"], d_h.data_ptr(), d_o.data_ptr())
+    for wrong in (dict(n_images=0), dict(symbol_stride=c * n - 1), dict(word_stride=c * plane - 512), dict(pixel_stride=P.pixel_bytes - 1), dict(coef_stride=c * plane + 512)):
+        with pytest.raises(frave_amd.api.FriHipError):
+            call(**wrong)
+    call()  # and the plan still works
+    torch.cuda.synchronize()
+    sym, vp, wp, hist, oob = P.encode_image_symbols(img)
+    assert np.array_equal(d_st[0].cpu().numpy(), sym) and np.array_equal(d_st[1].cpu().numpy(), sym) and int(oob.sum()) == 0
+    P.close()
+
+
+@pytest.mark.gpu
 def test_emit_from_device_arrays():
     import frave_amd
 
