@@ -28,6 +28,7 @@ SYMBOLS = [
     "fri_hip_fit_params_batch_dev", "fri_hip_encode_image_batch_dev", "fri_hip_fit_value_params_batch_dev", "fri_hip_fit_width_params_batch_dev",
     "fri_hip_plan_assume_forward_coefficients", "fri_hip_encode_image_batch", "fri_hip_multi_encode_image",
     "fri_hip_plan_set_stream_order", "fri_hip_symbol_stream_batch_dev", "fri_hip_encode_image_symbols", "fri_hip_encode_symbols_batch_dev",
+    "fri_hip_plan_set_dequantiser",
 ]
 
 
@@ -141,6 +142,7 @@ def load_library():
     L.fri_hip_predict_image_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.fri_hip_fit_params_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp, vp]
     L.fri_hip_plan_assume_forward_coefficients.argtypes = [vp, i32]
+    L.fri_hip_plan_set_dequantiser.argtypes = [vp, i32]
     L.fri_hip_plan_set_stream_order.argtypes = [vp, vp, C.c_uint64]
     L.fri_hip_symbol_stream_batch_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, vp, sz, vp]
     L.fri_hip_encode_image_symbols.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
@@ -352,6 +354,10 @@ class Plan:
         q = _q(qmatrix)
         _check(load_library().fri_hip_encode_symbols_batch_dev(self._h, n_images, d_pixels, pixel_stride, _p(q), 1 if fit else 0, d_params, d_coefs, coef_stride, d_node_words,
                                                                word_stride, d_symbols, symbol_stride, d_hist, d_oob, d_fit_range, stream), "fri_hip_encode_symbols_batch_dev", self.ctx)
+
+    def set_dequantiser(self, multiply):
+        """fri_hip_plan_set_dequantiser: False = the reference's dividing quantization::decode (default), True = coefficient x qmatrix[layer]."""
+        _check(load_library().fri_hip_plan_set_dequantiser(self._h, 1 if multiply else 0), "fri_hip_plan_set_dequantiser")
 
     def assume_forward_coefficients(self, on=True):
         """fri_hip_plan_assume_forward_coefficients: the predict entry points then skip the exact-kernel guard launch."""

@@ -585,6 +585,12 @@ int fri_hip_plan_assume_forward_coefficients(fri_hip_plan *p, int on) {
     return FRI_HIP_OK;
 }
 
+int fri_hip_plan_set_dequantiser(fri_hip_plan *p, int mode) {
+    if (!p || (mode != FRI_HIP_DEQUANT_REFERENCE && mode != FRI_HIP_DEQUANT_MULTIPLY)) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    p->dev.k3_multiply = mode == FRI_HIP_DEQUANT_MULTIPLY;
+    return FRI_HIP_OK;
+}
+
 int fri_hip_plan_centers(const fri_hip_plan *p, int32_t *centers) {
     if (!p || !centers) return FRI_HIP_ERR_INVALID_ARGUMENT;
     std::memcpy(centers, p->geo.centers.data(), p->geo.centers.size() * sizeof(Int2));

@@ -34,6 +34,7 @@ struct InvArgs {
     int32_t queue_bytes; // LDS rim queue per wave
     int32_t max_wg_tiles;
     int32_t q_identity;
+    int32_t q_multiply; // 0: the reference's quantization::decode, which divides (quantization.rs:37); 1: the inverse of the quantiser (wrapping multiply)
     int32_t ablate; // timing experiments only (FRI_HIP_K3_ABLATE): 1 = no global stores, 2 = no LDS scatter
     unsigned long long *trace; // diagnostic timeline, null in production
     // static write-out lists (geometry.hpp: InvTileLists), used by inverse_transform_lists_kernel
@@ -47,6 +48,7 @@ struct InvArgs {
 __device__ __forceinline__ int dequant_ref(int v, int heap_index, const InvArgs &a) {
     // quantization::decode divides like encode (quantization.rs:37); reproduced bit for bit.
     if (a.q_identity || v == kNone) return v;
+    if (a.q_multiply) return (int)((unsigned)v * (unsigned)a.q.q[quant_layer(heap_index)]); // fri_hip_plan_set_dequantiser(plan, FRI_HIP_DEQUANT_MULTIPLY)
     return v / a.q.q[quant_layer(heap_index)];
 }
 
@@ -471,6 +473,7 @@ hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, cons
     a.q = q;
     a.q_identity = 1;
     for (int i = 0; i <= 9; i++) a.q_identity &= (q.q[i] == 1);
+    a.q_multiply = p.k3_multiply ? 1 : 0;
     a.queue_bytes = (int32_t)inv_queue_bytes(p);
     const int items_per_wave = (p.max_tile_cells * p.channels + kInvWaves - 1) / kInvWaves;
     if (items_per_wave > kInvMaxItemsPerWave || p.inv_max_wg_tiles > kInvThreads || p.lds_rows > 256 || p.lds_pitch / 16 > 256) return hipErrorInvalidConfiguration;

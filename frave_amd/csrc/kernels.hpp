@@ -50,6 +50,7 @@ struct DevicePlan {
     bool k1_batch_shares = true; // FRI_HIP_K1_BATCH_SHARES=0 disables the merged shares (A/B)
     int32_t k1_ablate = 0; // timing-only ablation flags, see FwdArgs::ablate
     int32_t k2_ablate = 0; // the same for K2, see PredArgs::ablate
+    bool k3_multiply = false; // fri_hip_plan_set_dequantiser: the inverse kernel multiplies by the quantiser instead of reproducing the reference's division
     bool k4_value3 = false; // tuning (FRI_HIP_K4_VALUE3=1): the fit's value pass as fit_value_kernel3, the experiment on K2's skeleton (k2_predict.hip) - exact, 4 us slower
     unsigned long long *trace = nullptr; // [n_wg][16] diagnostic timeline (FRI_HIP_TRACE=1), else null
     // K3's static write-out lists (null = not built: the kernel scans the rectangle)

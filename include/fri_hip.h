@@ -323,6 +323,13 @@ int fri_hip_encode_image_symbols(fri_hip_plan *plan, const uint8_t *pixels, cons
  * (bit-exact, and the identity for today's all-ones matrix). Pixels not covered by any Some
  * coefficient are written 0 like the reference's zero-initialised raster. */
 int fri_hip_inverse_transform(fri_hip_plan *plan, const int32_t *coefs, const int32_t qmatrix[32], uint8_t *pixels);
+/* Which dequantiser the inverse entry points of this plan apply. FRI_HIP_DEQUANT_REFERENCE (default): quantization::decode as the reference has it
+ * (stages/quantization.rs:27-45), which DIVIDES by the matrix entry like the encoder does - bit for bit the reference's decoder, and a defect of the
+ * reference as soon as the matrix is not all ones. FRI_HIP_DEQUANT_MULTIPLY: the inverse of the quantiser, coefficient x
+ * qmatrix[layer] in wrapping 32-bit arithmetic - what a lossy round trip needs. With today's all-ones matrix the two are the same kernel instance. */
+#define FRI_HIP_DEQUANT_REFERENCE 0
+#define FRI_HIP_DEQUANT_MULTIPLY 1
+int fri_hip_plan_set_dequantiser(fri_hip_plan *plan, int mode);
 int fri_hip_inverse_transform_dev(fri_hip_plan *plan, const int32_t *d_coefs, const int32_t qmatrix[32], uint8_t *d_pixels,
                                   void *stream);
 /* n independent images in one launch: image k at d_coefs + k * coef_stride (int32 elements), d_pixels + k * pixel_stride (bytes). */

@@ -487,3 +487,35 @@ def test_histogram_hand_over_when_all_workgroups_finish_together(ctx):
     torch.cuda.synchronize()
     assert bool((d_h.sum(dim=(1, 2)) + d_o == P.num_some).all())
     assert bool((d_h == d_h[0]).all()) and bool((d_g == d_g[0]).all())
+
+
+@pytest.mark.gpu
+def test_multiplying_dequantiser(ctx):
+    """fri_hip_plan_set_dequantiser(MULTIPLY): the inverse of the quantiser instead of the reference's dividing quantization::decode. Equal to the reference
+    mode run on coefficients that were multiplied beforehand (same kernel arithmetic, any matrix), a lossy round trip that is close to the image where the
+    reference's decode is not, and the same thing as the reference mode for the all-ones matrix."""
+    import frave_amd
+
+    w, h, c = 300, 200, 3
+    img = gen_image("smooth", w, h, c, 17)
+    P = frave_amd.Plan(ctx, w, h, c)
+    q = np.ones(32, np.int32)
+    q[:10] = [1, 1, 1, 2, 2, 3, 3, 4, 6, 8]
+    co = P.transform_quant(img, q)
+    reference = P.inverse_transform(co, q)
+    P.set_dequantiser(True)
+    multiplied = P.inverse_transform(co, q)
+    # the same arithmetic as: multiply on the host, decode with the identity matrix
+    layer = np.floor(np.log2(np.arange(512) + 1)).astype(np.int64)
+    pre = np.where(co == np.iinfo(np.int32).min, co, (co.astype(np.int64) * q[layer][None, None, :]).astype(np.int32))
+    assert np.array_equal(multiplied, P.inverse_transform(pre, np.ones(32, np.int32)))
+    err_mul = np.abs(multiplied.astype(np.int32) - img.reshape(-1).astype(np.int32)).mean()
+    err_ref = np.abs(reference.astype(np.int32) - img.reshape(-1).astype(np.int32)).mean()
+    print("mean absolute error: multiply", err_mul, "reference (divides again)", err_ref)
+    assert err_mul < 0.7 * err_ref and err_mul < 4, (err_mul, err_ref)  # measured: 1.5 against 2.9
+    ones = np.ones(32, np.int32)
+    co1 = P.transform_quant(img, ones)
+    a = P.inverse_transform(co1, ones)
+    P.set_dequantiser(False)
+    assert np.array_equal(a, P.inverse_transform(co1, ones)) and np.array_equal(a, img.reshape(-1))
+    P.close()
