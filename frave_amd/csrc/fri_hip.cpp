@@ -72,7 +72,8 @@ struct fri_hip_plan {
         hipStream_t stream = nullptr;
         bool used = false;
         hipEvent_t handed_over = nullptr;
-        uint32_t *pred_acc = nullptr;           // [planes][kPredShards][kPredAccWords], grown on demand, all zero between launches
+        uint32_t *pred_acc = nullptr;           // [planes][kPredAccWords]: K2's hand-over bookkeeping (kernels.hpp), grown on demand, zero when allocated
+        uint32_t pred_serial = 0;               // launches of K2 on this accumulator so far: every launch publishes and polls for its own number
         unsigned long long *fit_acc = nullptr;  // [planes][kFitShards][kFitAccWords]
         // scratch of the device-side fit (fit_chain): the sums of a launch's planes on their way to the solve kernels, their out-of-range
         // counts, and parameter sets for callers that keep theirs on the host. Per stream like the accumulators: chains of several streams
@@ -185,7 +186,7 @@ int acquire_acc(fri_hip_plan *p, hipStream_t stream, uint32_t n_planes = 1) {
     if (p->acc_dirty) { // rare: a previous launch failed part-way; nothing may be in flight on the accumulators when they are cleared
         HIP_TRY(c, hipDeviceSynchronize());
         for (auto &a : p->acc_slots) {
-            if (a.pred_acc) HIP_TRY(c, hipMemset(a.pred_acc, 0, (size_t)a.planes * kPredShards * kPredAccWords * sizeof(uint32_t)));
+            if (a.pred_acc) HIP_TRY(c, hipMemset(a.pred_acc, 0, (size_t)a.planes * kPredAccWords * sizeof(uint32_t)));
             if (a.fit_acc) HIP_TRY(c, hipMemset(a.fit_acc, 0, (size_t)a.planes * kFitShards * kFitAccWords * sizeof(unsigned long long)));
         }
         HIP_TRY(c, hipDeviceSynchronize()); // (the memsets ran on the null stream: done before any stream launches on the accumulators again)
@@ -221,7 +222,7 @@ int acquire_acc(fri_hip_plan *p, hipStream_t stream, uint32_t n_planes = 1) {
     if (a.planes < n_planes) { // grow: the old buffers may still be in use by queued launches, so they are retired, not freed
         const uint32_t planes = n_planes < 4 ? 4 : n_planes;
         void *pa = nullptr, *fa = nullptr, *si = nullptr, *sd = nullptr, *rg = nullptr, *pr = nullptr;
-        const size_t pb = (size_t)planes * kPredShards * kPredAccWords * sizeof(uint32_t), fb = (size_t)planes * kFitShards * kFitAccWords * sizeof(unsigned long long);
+        const size_t pb = (size_t)planes * kPredAccWords * sizeof(uint32_t), fb = (size_t)planes * kFitShards * kFitAccWords * sizeof(unsigned long long);
         hipError_t e = hipMalloc(&pa, pb);
         if (e == hipSuccess) e = hipMalloc(&fa, fb);
         if (e == hipSuccess) e = hipMalloc(&si, (size_t)planes * 3 * 28 * sizeof(unsigned long long));
@@ -372,6 +373,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
     tp.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
     tp.cells_per_wg = env_int("FRI_HIP_CELLS_PER_WG");
     tp.batch_share_tiles = env_int("FRI_HIP_BATCH_SHARE_TILES");
+    tp.strided_shares = env_int("FRI_HIP_STRIDED_SHARES") > 0;
     // LDS budget of one forward tile buffer: 4 chunks of 16 bytes per thread for planes (the tuned variant), 6 for RGB
     tp.tile_buffer_bytes = (channels == 1 ? 4 : 6) * 256 * 16;
     if (env_int("FRI_HIP_TILE_BYTES") > 0) tp.tile_buffer_bytes = env_int("FRI_HIP_TILE_BYTES");
@@ -504,12 +506,10 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             p->owned.push_back(j);
             d.junk = static_cast<uint8_t *>(j);
         }
-        d.k2_previous = env_int("FRI_HIP_K2_PREVIOUS") > 0;
         d.k4_previous = env_int("FRI_HIP_K4_PREVIOUS") > 0;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
         d.k2_ablate = env_int("FRI_HIP_K2_ABLATE");
-        if (const char *v3 = env_str("FRI_HIP_K4_VALUE3")) d.k4_value3 = std::atoi(v3) != 0;
         if (const char *e = env_str("FRI_HIP_K1_BATCH_SHARES")) d.k1_batch_shares = std::atoi(e) != 0;
         d.k3_ablate = env_int("FRI_HIP_K3_ABLATE");
         d.k4_ablate = env_int("FRI_HIP_K4_ABLATE");
@@ -776,7 +776,9 @@ static int predict_launch(fri_hip_plan *p, const PredBatch &b, uint8_t *d_bucket
                           hipStream_t stream) {
     const int slot = acquire_acc(p, stream, b.n_planes);
     if (slot < 0) return slot;
-    if (hipError_t e = launch_predict_histogram(p->dev, p->acc_slots[slot].pred_acc, b, d_bucket, d_prediction, d_hist, (unsigned long long *)d_oob, trust, stream)) {
+    auto &acc = p->acc_slots[slot];
+    if (++acc.pred_serial == 0) acc.pred_serial = 1; // 0 is what a fresh accumulator holds
+    if (hipError_t e = launch_predict_histogram(p->dev, acc.pred_acc, acc.pred_serial, b, d_bucket, d_prediction, d_hist, (unsigned long long *)d_oob, trust, stream)) {
         p->acc_dirty = true;
         return fail_hip(p->ctx, e, "launch_predict_histogram");
     }
@@ -787,9 +789,7 @@ static int fit_launch(fri_hip_plan *p, int mode, const PredBatch &b, int64_t *d_
                       const FitSolve *solve = nullptr) {
     const int slot = acquire_acc(p, stream, b.n_planes);
     if (slot < 0) return slot;
-    const hipError_t e = mode == 0 && p->dev.k4_value3 && !p->dev.k4_previous
-                             ? launch_fit_value3(p->dev, p->acc_slots[slot].fit_acc, b, (unsigned long long *)d_int, d_range, stream, solve)
-                             : launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream, solve);
+    const hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream, solve);
     if (e != hipSuccess) {
         p->acc_dirty = true;
         return fail_hip(p->ctx, e, "launch_fit_accumulate");

@@ -444,6 +444,46 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
             g.max_wg_tiles = std::max(g.max_wg_tiles, g.wg_tiles[sh + 1] - g.wg_tiles[sh]);
         }
     }
+    if (tp.strided_shares && n_wg > 1) {
+        // Interleaved shares: the tiles are dealt to the shares like cards, round after round in share order, instead of giving every share one contiguous
+        // run. At any moment of a one-round launch the resident workgroups then work on ONE window of consecutive tiles that slides over the image - the
+        // pixel rows they read and the coefficient range they write are a compact, moving region of memory, not n_wg fronts spread over all of it - and
+        // neighbouring tiles still run side by side on one XCD (consecutive shares belong to one XCD: xcd_contiguous_share). A share's tiles and cells stay
+        // contiguous in the arrays (the kernels walk [wg_tiles[sh], wg_tiles[sh + 1]) and load a share's cell records as one range): the arrays are permuted.
+        std::vector<std::vector<int32_t>> dealt(n_wg);
+        size_t next = 0;
+        for (bool any = true; any && next < T;) {
+            any = false;
+            for (size_t sh = 0; sh < n_wg && next < T; sh++)
+                if (dealt[sh].size() < (size_t)(g.wg_tiles[sh + 1] - g.wg_tiles[sh])) {
+                    dealt[sh].push_back((int32_t)next++);
+                    any = true;
+                }
+        }
+        std::vector<Tile> tiles2;
+        std::vector<TileCell> meta2;
+        std::vector<int32_t> cells2;
+        tiles2.reserve(T), meta2.reserve(F), cells2.reserve(F);
+        g.max_wg_cells = 0;
+        for (size_t sh = 0; sh < n_wg; sh++) {
+            int32_t share_cells = 0;
+            for (int32_t t_old : dealt[sh]) {
+                Tile t = g.tiles[t_old];
+                const int32_t begin = (int32_t)meta2.size();
+                for (int32_t k = 0; k < t.cell_count; k++) {
+                    meta2.push_back(g.tile_meta[t.cell_begin + k]);
+                    cells2.push_back(g.tile_cells[t.cell_begin + k]);
+                }
+                t.cell_begin = begin;
+                share_cells += t.cell_count;
+                tiles2.push_back(t);
+            }
+            g.max_wg_cells = std::max(g.max_wg_cells, share_cells);
+        }
+        g.tiles.swap(tiles2);
+        g.tile_meta.swap(meta2);
+        g.tile_cells.swap(cells2);
+    }
     {
         const size_t cells_target = (size_t)(tp.batch_share_tiles > 0 ? tp.batch_share_tiles : 4) * cells_per_tile;
         size_t merge = 1;

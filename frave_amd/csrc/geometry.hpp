@@ -119,6 +119,7 @@ struct TilingParams {
     // instead of sizing every buffer for them. 0 = no cap.
     int tile_buffer_bytes = 0;
     int batch_share_tiles = 0; // tiles' worth of cells per merged batch share (0 = 4)
+    bool strided_shares = false; // deal the tiles to the shares round-robin (the resident set works on one sliding window of the image) instead of one contiguous run each
 };
 
 // Returns "" on success, else an error string.

@@ -1,7 +1,6 @@
 // k2_predict.hip -- K2 predict_histogram: 6-neighbour gather + context bucket + prediction + ANS symbol histogram for one
 // channel plane (context_modeling.rs:25-77; stages/prediction.rs:86-207, 237-298).
 #include "gather_common.hpp"
-#include "solve6.hpp"
 
 #include <algorithm>
 #include <vector>
@@ -66,7 +65,8 @@ struct PredArgs {
     unsigned long long *n_oob;
     uint8_t *junk;             // plan scratch, kPredJunkBytes per wave of the pipelined K2: output lines of block slots without a cell
     unsigned long long *trace; // diagnostic timeline, null in production
-    uint32_t *acc;             // plan scratch, all zero between launches: [kHistBins] counts, then kAccOob (u64), kAccTicket
+    uint32_t *acc;             // plan scratch, kPredAccWords per plane: the clearing workgroups' flags (serial numbers), the CHECK kernels' ticket, the inexact flag
+    uint32_t serial;           // this launch's number on this accumulator (never 0): what the clearing workgroups publish and everybody polls for
     uint32_t n_tiles;
     uint16_t *words;      // predict_histogram_kernel3<., true>: bucket << 10 | symbol per node, [n_planes] planes out_stride apart, INSTEAD of bucket / prediction
     int32_t trusted;      // the caller vouches for |coefficient| <= 256 (this library's forward kernel wrote them) and enqueues no exact kernel: a plane that
@@ -75,308 +75,73 @@ struct PredArgs {
     PredictParams pp3[3]; // plane k < 3 of a launch without a params array
 };
 
-// Histogram hand-over without a memset in front of the kernel (two fill kernels cost ~6 us per call): every workgroup adds
-// its LDS table into the plan's accumulator, then takes a ticket; the workgroup that draws the last ticket moves the totals to
-// the caller's arrays with atomic exchanges, which leaves the accumulator zero for the next launch.
-constexpr int kAccOob = kHistBins, kAccTicket = kHistBins + 2, kAccInexact = kHistBins + 4; // + the exact kernel's ticket at kAccInexact + 1
-static_assert(kHistBins + 8 == (int)kPredAccWords, "accumulator layout");
-__device__ __forceinline__ void pred_hand_over(const PredArgs &a, const uint32_t *s_hist, uint32_t *s_flag, int tid, int n_threads) {
-    // (the counts go to one of kPredShards copies of the accumulator: all workgroups of a launch adding into the same hot bins serialise at ~12 ns
-    // per add and address at the memory side; the last workgroup sums the copies. Copy 0 also holds the counters behind the bins.)
-    uint32_t *const acc_s = a.acc + (size_t)(blockIdx.x % kPredShards) * kPredAccWords;
+// Histogram hand-over (round 4). No memset in front of the kernel, no plan-side copy of the table, no copy-out behind it:
+//  * the first min(gridDim.x, 10) workgroups of a plane clear the caller's hist[10][1024] (and workgroup 0 *n_oob) in their prologue - atomic exchanges,
+//    i.e. read-modify-writes performed at the same coherence point as the adds that follow - and each then publishes the launch's serial number in its
+//    own flag word of the plane's accumulator (pred_clear_outputs);
+//  * at its end every workgroup polls those flags (they were raised tens of microseconds earlier: one round trip, hidden behind the last tile's stores) and
+//    then adds its LDS table straight into hist / *n_oob with fire-and-forget device-scope atomics. A workgroup only ever waits for workgroups with a LOWER
+//    block index of its own plane, which the dispatcher started before it and which wait for nobody in their prologue: the poll terminates whatever the grid,
+//    whatever else shares the device. The serial number (one per launch on this accumulator, host-side counter) makes a reset of the flags unnecessary.
+//  * CHECK = false (the chain's own coefficients): that is all - the end of the kernel completes the adds. Rounds 1-3 added into a plan accumulator and let the
+//    workgroup with the last ticket copy the totals out and re-zero: adds -> their acknowledgement -> ticket -> 10 loads -> 20 stores per thread, 6-7 us on the
+//    critical path of the workgroup that was last anyway.
+//  * CHECK = true keeps a ticket: a plane whose values the LDS image cannot hold (`inexact`) must end with an all-zero histogram (the exact kernel behind it
+//    adds the real one) or, for a caller who vouched for the coefficients, with n_oob = ~0: the workgroup with the last ticket does that, after every add.
+constexpr int kAccZeroFlag = 0, kAccTicket = 12, kAccInexact = 14; // + the exact kernel's ticket at kAccInexact + 1
+constexpr uint32_t kPredZeroBlocks = 10;                           // hist chunks of 1024 counters, one per clearing workgroup
+static_assert(kAccInexact + 2 == (int)kPredAccWords && kAccZeroFlag + (int)kPredZeroBlocks <= kAccTicket, "accumulator layout");
+// (issue only: the exchanges fly while the prologue makes its own round trips; pred_clear_publish raises the flag behind the prologue's first barrier, whose
+// wait covers them - the clearing workgroups walk the longest tile sequences of the launch, a round trip of their own in front would be the launch's)
+__device__ __forceinline__ void pred_clear_issue(const PredArgs &a, int tid, int n_threads) {
+    const uint32_t nz = min(gridDim.x, kPredZeroBlocks);
+    if (blockIdx.x >= nz) return; // (uniform)
+    for (uint32_t c = blockIdx.x; c < 10u; c += nz)
+        for (uint32_t j = (uint32_t)tid; j < 1024u; j += (uint32_t)n_threads) (void)__hip_atomic_exchange(a.hist + c * 1024u + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && tid == 0) (void)__hip_atomic_exchange(a.n_oob, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Behind a wait_for_own_memory_ops_then_barrier() of the whole workgroup: every clearing exchange has been performed, the flag may go up.
+__device__ __forceinline__ void pred_clear_publish(const PredArgs &a, int tid) {
+    if (blockIdx.x < min(gridDim.x, kPredZeroBlocks) && tid == 0)
+        (void)__hip_atomic_exchange(a.acc + kAccZeroFlag + blockIdx.x, a.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One poll of the plane's flags (lane z < number of clearing workgroups reads flag z; the other lanes read as "cleared")
+__device__ __forceinline__ uint32_t pred_clear_poll(const PredArgs &a, int lane) {
+    return (uint32_t)lane < min(gridDim.x, kPredZeroBlocks) ? __hip_atomic_load(a.acc + kAccZeroFlag + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.serial;
+}
+template <bool CHECK>
+__device__ __forceinline__ void pred_hand_over(const PredArgs &a, const uint32_t *s_hist, uint32_t *s_flag, int tid, int n_threads, uint32_t early_poll) {
+    // (the caller's LDS barrier behind the tile loop has made s_hist complete; the output stores of the last tile are still in flight - nothing here waits for them)
+    // early_poll: this wave's poll from the end of its prologue (the flags go up ~3 us into the launch): almost always the answer, and its round trip is long over
+    if (!__all(early_poll == a.serial)) {
+        const int lane = tid & 63;
+        while (!__all(pred_clear_poll(a, lane) == a.serial)) __builtin_amdgcn_s_sleep(2); // every wave for itself: no barrier between the poll and the adds
+    }
+    asm volatile("" ::: "memory"); // the adds below stay behind the poll
     for (int i = tid; i < kHistBins; i += n_threads) {
         const uint32_t c = s_hist[i];
-        if (c) __hip_atomic_fetch_add(acc_s + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c) (void)__hip_atomic_fetch_add(a.hist + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid == 0 && s_hist[kHistBins])
-        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.acc + kAccOob), (unsigned long long)s_hist[kHistBins], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // Order without fences: an agent-scope fence on this multi-XCD part writes back and invalidates the whole L2 (measured:
-    // +80 us per launch). The adds above are device-scope atomics, executed at the coherence point and acknowledged through
-    // vmcnt: every wave waits for its own vmcnt(0) - explicitly, see wait_for_own_memory_ops_then_barrier - so all of this workgroup's
-    // adds are performed before thread 0 draws the ticket. The last workgroup then reads with device-scope loads, which do not hit a
-    // stale L2 line.
+    if (tid == 0 && s_hist[kHistBins]) (void)__hip_atomic_fetch_add(a.n_oob, (unsigned long long)s_hist[kHistBins], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!CHECK) return;
+    // Order without fences (an agent-scope fence on this multi-XCD part writes back and invalidates the whole L2: +80 us per launch): the adds are device-scope
+    // atomics, executed at the coherence point and acknowledged through vmcnt; every wave waits for its own vmcnt(0) - explicitly, see
+    // wait_for_own_memory_ops_then_barrier - so all of this workgroup's adds are performed before thread 0 draws the ticket.
     wait_for_own_memory_ops_then_barrier();
     if (tid == 0) *s_flag = __hip_atomic_fetch_add(a.acc + kAccTicket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (*s_flag == 0) return;
-    // all other workgroups have finished (their adds precede their tickets): plain coherent loads, all in flight together
-    // (an atomic exchange per bin, one after the other, took 30-60 us), then the zeros for the next launch
-    static_assert(kHistBins % 512 == 0, "unrolled by 512-thread strides");
-    // (a plane kernel3 could not represent - a.inexact raised - hands over an all-zero histogram: the exact kernel behind it adds the real one)
-    const bool inexact = a.inexact && __hip_atomic_load(a.inexact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    if (n_threads == 1024) {
-        uint32_t v[kHistBins / 1024][kPredShards];
-#pragma unroll
-        for (int k = 0; k < kHistBins / 1024; k++)
-#pragma unroll
-            for (uint32_t sh = 0; sh < kPredShards; sh++) v[k][sh] = __hip_atomic_load(a.acc + sh * kPredAccWords + tid + 1024 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int k = 0; k < kHistBins / 1024; k++) {
-            uint32_t sum = 0;
-#pragma unroll
-            for (uint32_t sh = 0; sh < kPredShards; sh++) {
-                sum += v[k][sh];
-                __hip_atomic_store(a.acc + sh * kPredAccWords + tid + 1024 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            a.hist[tid + 1024 * k] = inexact ? 0u : sum;
-        }
-    } else { // (the 512-thread kernel of round 1, tuning builds only: it adds into copy blockIdx % kPredShards like everyone else)
-        for (int k = 0; k < kHistBins / 512; k++) {
-            uint32_t sum = 0;
-            for (uint32_t sh = 0; sh < kPredShards; sh++) {
-                sum += __hip_atomic_load(a.acc + sh * kPredAccWords + tid + 512 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.acc + sh * kPredAccWords + tid + 512 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            a.hist[tid + 512 * k] = sum;
+    // all other workgroups of the plane have finished (their adds precede their tickets)
+    const bool inexact = __hip_atomic_load(a.inexact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (inexact) {
+        for (int i = tid; i < kHistBins; i += n_threads) (void)__hip_atomic_exchange(a.hist + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            (void)__hip_atomic_exchange(a.n_oob, a.trusted ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.trusted) __hip_atomic_store(a.inexact, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // no exact kernel follows to lower it
         }
     }
-    if (tid == 0) {
-        const unsigned long long oob = __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(a.acc + kAccOob), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *a.n_oob = inexact ? (a.trusted ? ~0ull : 0ull) : oob;
-        if (inexact && a.trusted) __hip_atomic_store(a.inexact, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // no exact kernel follows to lower it
-        __hip_atomic_store(a.acc + kAccTicket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid == 0) __hip_atomic_store(a.acc + kAccTicket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-// K2, pipelined form. One 1024-thread workgroup per CU (16 waves = the 16 block cells of a tile), two LDS cell images:
-// while tile i is gathered / predicted out of one image, the 36 cells of tile i + 1 are in flight from HBM/L2 into registers
-// (2-3 cells per wave) and are committed to the other image at the end of the iteration, so a tile costs one barrier and
-// the staging latency overlaps the arithmetic (the single-buffered kernel above leaves the VALU idle 44 % of the time).
-// The slot lists (which cell sits in which LDS slot) run two tiles ahead through a three-entry ring. Bucket and prediction
-// are written once and never read here: nontemporal stores.
-constexpr int kPred2Threads = 1024;
-constexpr int kPred2Waves = kPred2Threads / 64;
-constexpr int kPred2Stage = (kPredSlots + kPred2Waves - 1) / kPred2Waves; // cells staged per wave
-constexpr int kPredCellsBytes = kPredSlots * kSlotStride;
-static_assert(kPred2Threads / 64 == (int)kPredJunkWaves && 512 + 2048 == (int)kPredJunkBytes, "junk layout");
-constexpr int kPredHistBytes = ((kHistBins + 2) * 4 + 15) & ~15;
-constexpr int kPredMaskWords = kPredSlots * 16; // Some/None masks of the staged cells, per image
-constexpr int kPred2LdsBytes = kPredHistBytes + 2 * kPredCellsBytes + 3 * kPredSlots * 4 + 32 * 2 + 2 * kPredMaskWords * 4;
-static_assert(kPred2Waves == kPredBlock * kPredBlock, "one wave per block cell");
-
-template <int I, bool INTERIOR>
-__device__ __forceinline__ void predict_node2(const uint8_t *own, int lane, uint32_t o01, uint32_t o23, uint32_t o45, bool some, const PredictParams &pp,
-                                              uint32_t *s_hist, const uint16_t *s_bkt, uint8_t *bucket_dst, int32_t *pred_dst) {
-    constexpr int g = I >= 4 ? 0 : I >= 2 ? 1 : 2;
-    const float *wp = pp.width[g], *vp = pp.value[g];
-    const int value = *reinterpret_cast<const short *>(own + 2 * (lane + 64 * I));
-    const int o[6] = {(int)(short)(o01 & 0xFFFFu), (int)o01 >> 16, (int)(short)(o23 & 0xFFFFu), (int)o23 >> 16, (int)(short)(o45 & 0xFFFFu), (int)o45 >> 16};
-    float f[6];
-    int v[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        v[k] = *reinterpret_cast<const short *>(own + 2 * o[k]);
-        f[k] = (float)v[k];
-    }
-    // get_hf_context_bucket, prediction.rs:165-206 (see predict_node)
-    float width = wp[0];
-    width = __fadd_rn(width, __fmul_rn(wp[1], fabsf(__fsub_rn(f[0], f[3]))));
-    width = __fadd_rn(width, __fmul_rn(wp[2], fabsf(__fsub_rn(f[1], f[2]))));
-    width = __fadd_rn(width, __fmul_rn(wp[3], fabsf(__fsub_rn(f[4], f[5]))));
-    width = __fadd_rn(width, __fmul_rn(wp[4], fabsf(__fsub_rn(f[1], f[5]))));
-    width = __fadd_rn(width, __fmul_rn(wp[5], fabsf(__fsub_rn(f[2], f[4]))));
-    // assign_bucket (prediction.rs:55-68) as a 32-entry LDS table of bucket << 10: the kernel is bound by instruction issue and
-    // the LDS pipe has room (one ds_read_u16 instead of nine VALU instructions)
-    uint32_t b10 = s_bkt[min(f32_as_u32(width), 31u)];
-    float pf = __fmul_rn(f[0], vp[0]);
-    pf = __fadd_rn(pf, __fmul_rn(f[1], vp[1]));
-    pf = __fadd_rn(pf, __fmul_rn(f[2], vp[2]));
-    pf = __fadd_rn(pf, __fmul_rn(f[3], vp[3]));
-    pf = __fadd_rn(pf, __fmul_rn(f[4], vp[4]));
-    pf = __fadd_rn(pf, __fmul_rn(f[5], vp[5]));
-    int prediction = f32_as_i32(pf);
-    if (I == 0) { // heap index 0 (DC) and 1 (root) live in lanes 0, 1: get_lf_context_bucket, prediction.rs:134-144
-        const uint32_t w = (uint32_t)iabs_w(sub_w(v[0], v[2]));
-        const int mx = max(v[0], v[2]), mn = min(v[0], v[2]);
-        const int lf_pred = v[1] >= mx ? mx : v[1] <= mn ? mn : sub_w(add_w(v[0], v[2]), v[1]);
-        const bool lf = lane < 2;
-        b10 = lf ? bucket_of_rt(w) << 10 : b10;
-        prediction = lf ? lf_pred : prediction;
-    }
-    const uint32_t sym = pack_signed(sub_w(value, prediction));
-    uint32_t bin = sym < 1024u ? b10 + sym : (uint32_t)kHistBins;
-    uint32_t bucket = b10 >> 10;
-    if (!INTERIOR) { // a None node is not counted and stays (0, 0) in the outputs (wavelet_transform.rs:60-64). Skipped under the
-                     // exec mask, not sent to a trash bin: 64 lanes adding to ONE LDS address take ~0.7 us per instruction (measured)
-        bucket = some ? bucket : 0u;
-        prediction = some ? prediction : 0;
-        if (some) atomicAdd(&s_hist[bin], 1u);
-    } else {
-        atomicAdd(&s_hist[bin], 1u); // bump_freq, entropy_coding.rs:98-100
-    }
-    __builtin_nontemporal_store((uint8_t)bucket, bucket_dst + 64 * I);
-    __builtin_nontemporal_store(prediction, pred_dst + 64 * I);
-}
-
-__global__ void __launch_bounds__(kPred2Threads) predict_histogram_kernel2(const PredArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint32_t *s_hist = reinterpret_cast<uint32_t *>(lds); // 10 x 1024 + out-of-alphabet counter + trash bin
-    uint8_t *s_cells = lds + kPredHistBytes;              // [2][kPredCellsBytes]
-    int32_t *s_ring = reinterpret_cast<int32_t *>(s_cells + 2 * kPredCellsBytes); // [3][kPredSlots]
-    uint16_t *s_bkt = reinterpret_cast<uint16_t *>(s_ring + 3 * kPredSlots);       // [32] bucket_of(w) << 10
-    uint32_t *s_masks = reinterpret_cast<uint32_t *>(s_bkt + 32);                  // [2][kPredSlots][16]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    trace_stamp(a.trace, blockIdx.x, 0, tid);
-    for (int i = tid; i < kHistBins + 2; i += kPred2Threads) s_hist[i] = 0;
-    if (tid < 32) s_bkt[tid] = (uint16_t)(bucket_of((uint32_t)tid) << 10);
-
-    uint32_t off[8][3]; // neighbour halfword offsets relative to the own slot, loop invariant
-#pragma unroll
-    for (int i = 0; i < 8; i++) { // precomputed at plan creation (build_pred_offsets): 8 loads, no arithmetic
-        const u32x4 o = reinterpret_cast<const u32x4 *>(a.pred_off)[lane + 64 * i];
-        off[i][0] = o.x, off[i][1] = o.y, off[i][2] = o.z;
-    }
-
-    const PredTileWalk walk(a.n_tiles);
-    if (walk.first < walk.end) { // (a workgroup without a tile still takes part in the hand-over below)
-    const uint32_t last = walk.first + ((walk.end - 1 - walk.first) / walk.step) * walk.step; // this workgroup's last tile
-    const int slot_lane = tid % kPredSlots;
-    if (tid < kPredSlots) {
-        s_ring[tid] = a.pred_slots[(size_t)walk.first * kPredSlots + tid];
-        s_ring[kPredSlots + tid] = a.pred_slots[(size_t)min(walk.first + walk.step, last) * kPredSlots + tid];
-    }
-    __syncthreads();
-    // stage tile 0 straight into image 0: all of a wave's (up to three) cells are requested before the first is converted - one
-    // global round trip instead of three in a row (the prologue took 4.7 us of the kernel's 54)
-    {
-        int cell0[kPred2Stage];
-        i32x4 lo0[kPred2Stage], hi0[kPred2Stage];
-        uint32_t mask0[kPred2Stage];
-#pragma unroll
-        for (int j0 = 0; j0 < kPred2Stage; j0++) {
-            const int sl = min(wave + kPred2Waves * j0, kPredSlots - 1);
-            cell0[j0] = pred_slot_cell(__builtin_amdgcn_readfirstlane(s_ring[sl]));
-            const i32x4 *src = reinterpret_cast<const i32x4 *>(a.coefs + (size_t)max(cell0[j0], 0) * kCell + 8 * lane);
-            lo0[j0] = src[0], hi0[j0] = src[1];
-            mask0[j0] = a.valid_mask[(size_t)max(cell0[j0], 0) * 16 + (lane & 15)];
-        }
-#pragma unroll
-        for (int j0 = 0; j0 < kPred2Stage; j0++) {
-            const int sl = wave + kPred2Waves * j0;
-            if (sl < kPredSlots) {
-                i32x4 lo = lo0[j0], hi = hi0[j0];
-                if (lane < 16) s_masks[sl * 16 + lane] = mask0[j0];
-                if (cell0[j0] < 0) {
-                    lo = hi = i32x4{0, 0, 0, 0};
-                } else if (pred_is_block_slot(sl)) {
-                    const int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    const uint32_t n = pred_count_outliers(v);
-                    if (n) atomicAdd(&s_hist[kHistBins], n);
-                }
-                uint8_t *dst = s_cells + sl * kSlotStride;
-                *reinterpret_cast<u32x4 *>(dst + 16 * lane) = u32x4{__builtin_amdgcn_perm((uint32_t)lo.y, (uint32_t)lo.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)lo.w, (uint32_t)lo.z, 0x05040100u),
-                                                                    __builtin_amdgcn_perm((uint32_t)hi.y, (uint32_t)hi.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)hi.w, (uint32_t)hi.z, 0x05040100u)};
-                if (lane == 0) *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{0u, 0u, 0u, 0u};
-            }
-        }
-    }
-    __syncthreads();
-    trace_stamp(a.trace, blockIdx.x, 1, tid);
-
-    int it = 0;
-    for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step, it++) {
-        const bool more = tile + walk.step < walk.end;
-        const int32_t *cur_slots = s_ring + (it % 3) * kPredSlots, *nxt_slots = s_ring + ((it + 1) % 3) * kPredSlots;
-        const uint8_t *cur = s_cells + (it & 1) * kPredCellsBytes;
-        uint8_t *nxt = s_cells + ((it & 1) ^ 1) * kPredCellsBytes;
-        const uint32_t *cur_masks = s_masks + (it & 1) * kPredMaskWords;
-        uint32_t *nxt_masks = s_masks + ((it & 1) ^ 1) * kPredMaskWords;
-        // in flight across the arithmetic below: the slot list of tile i + 2 and the cells of tile i + 1
-        const int32_t slot_pre = a.pred_slots[(size_t)min(tile + 2 * walk.step, last) * kPredSlots + slot_lane];
-        i32x4 st_lo[kPred2Stage], st_hi[kPred2Stage];
-        int st_cell[kPred2Stage];
-        uint32_t st_mask[kPred2Stage];
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < kPred2Stage; j++) {
-                const int sl = wave + kPred2Waves * j;
-                if (sl < kPredSlots) {
-                    st_cell[j] = pred_slot_cell(__builtin_amdgcn_readfirstlane(nxt_slots[sl]));
-                    const i32x4 *src = reinterpret_cast<const i32x4 *>(a.coefs + (size_t)max(st_cell[j], 0) * kCell + 8 * lane);
-                    st_lo[j] = src[0], st_hi[j] = src[1];
-                    st_mask[j] = a.valid_mask[(size_t)max(st_cell[j], 0) * 16 + (lane & 15)]; // the cell's Some/None bits travel with it
-                }
-            }
-        }
-
-        { // One block cell per wave. Every path issues exactly 16 stores (a wave without a retained cell at its block slot
-          // writes zeros to the plan's junk lines), so the compiler can count them: the commit below waits for the staging
-          // loads with vmcnt(16) instead of vmcnt(0) and does not sit out the acknowledgement of the stores just issued.
-            const int slot = (1 + wave / kPredBlock) * kPredSide + 1 + (wave % kPredBlock);
-            const int raw = __builtin_amdgcn_readfirstlane(cur_slots[slot]); // everything this phase needs is in LDS: a global load here
-            const int cell = pred_slot_cell(raw);                            // would have to wait for the staging loads just issued
-            const bool has = cell >= 0;
-            const uint8_t *own = cur + slot * kSlotStride;
-            // (junk lines are private to the wave: one shared line would be a write hot spot for every edge tile of the image)
-            const size_t junk = ((size_t)blockIdx.x * kPred2Waves + wave) * kPredJunkBytes;
-            uint8_t *bd = (has ? a.bucket + (size_t)cell * kCell : a.junk + junk) + lane;
-            int32_t *pd = (has ? a.prediction + (size_t)cell * kCell : reinterpret_cast<int32_t *>(a.junk + junk + 512)) + lane;
-            if (pred_slot_interior(raw)) {
-                predict_node2<0, true>(own, lane, off[0][0], off[0][1], off[0][2], true, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<1, true>(own, lane, off[1][0], off[1][1], off[1][2], true, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<2, true>(own, lane, off[2][0], off[2][1], off[2][2], true, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<3, true>(own, lane, off[3][0], off[3][1], off[3][2], true, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<4, true>(own, lane, off[4][0], off[4][1], off[4][2], true, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<5, true>(own, lane, off[5][0], off[5][1], off[5][2], true, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<6, true>(own, lane, off[6][0], off[6][1], off[6][2], true, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<7, true>(own, lane, off[7][0], off[7][1], off[7][2], true, a.pp, s_hist, s_bkt, bd, pd);
-            } else if (!has) { // no retained cell at this block slot (image edge): only the fixed number of stores, to the wave's junk lines
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    __builtin_nontemporal_store((uint8_t)0, bd + 64 * i);
-                    __builtin_nontemporal_store(0, pd + 64 * i);
-                }
-            } else { // boundary cell: Some/None of node lane + 64 i is bit (lane & 31) of mask word 2 i + (lane >> 5)
-                uint32_t some_bits = 0;
-                {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) some_bits |= ((cur_masks[slot * 16 + 2 * i + (lane >> 5)] >> (lane & 31)) & 1u) << i;
-                }
-                predict_node2<0, false>(own, lane, off[0][0], off[0][1], off[0][2], some_bits & 1u, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<1, false>(own, lane, off[1][0], off[1][1], off[1][2], some_bits & 2u, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<2, false>(own, lane, off[2][0], off[2][1], off[2][2], some_bits & 4u, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<3, false>(own, lane, off[3][0], off[3][1], off[3][2], some_bits & 8u, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<4, false>(own, lane, off[4][0], off[4][1], off[4][2], some_bits & 16u, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<5, false>(own, lane, off[5][0], off[5][1], off[5][2], some_bits & 32u, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<6, false>(own, lane, off[6][0], off[6][1], off[6][2], some_bits & 64u, a.pp, s_hist, s_bkt, bd, pd);
-                predict_node2<7, false>(own, lane, off[7][0], off[7][1], off[7][2], some_bits & 128u, a.pp, s_hist, s_bkt, bd, pd);
-            }
-        }
-
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < kPred2Stage; j++) {
-                const int sl = wave + kPred2Waves * j;
-                if (sl < kPredSlots) {
-                    i32x4 lo = st_lo[j], hi = st_hi[j];
-                    if (st_cell[j] < 0) {
-                        lo = hi = i32x4{0, 0, 0, 0}; // no retained cell at this slot: the reference reads 0 there
-                    } else if (pred_is_block_slot(sl)) {
-                        const int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                        const uint32_t n = pred_count_outliers(v);
-                        if (n) atomicAdd(&s_hist[kHistBins], n);
-                    }
-                    uint8_t *dst = nxt + sl * kSlotStride;
-                    if (lane < 16) nxt_masks[sl * 16 + lane] = st_mask[j];
-                    *reinterpret_cast<u32x4 *>(dst + 16 * lane) = u32x4{__builtin_amdgcn_perm((uint32_t)lo.y, (uint32_t)lo.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)lo.w, (uint32_t)lo.z, 0x05040100u),
-                                                                        __builtin_amdgcn_perm((uint32_t)hi.y, (uint32_t)hi.x, 0x05040100u), __builtin_amdgcn_perm((uint32_t)hi.w, (uint32_t)hi.z, 0x05040100u)};
-                    if (lane == 0) *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{0u, 0u, 0u, 0u};
-                }
-            }
-        }
-        if (tid < kPredSlots) s_ring[((it + 2) % 3) * kPredSlots + tid] = slot_pre;
-        lds_barrier();
-        trace_stamp(a.trace, blockIdx.x, 2 + it, tid);
-    }
-    }
-    __syncthreads();
-    trace_stamp(a.trace, blockIdx.x, 13, tid);
-    pred_hand_over(a, s_hist, reinterpret_cast<uint32_t *>(s_ring), tid, kPred2Threads);
-    trace_exit(a.trace, blockIdx.x, tid);
-}
-
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // K2, third form: the kernel the product launches. What the counters and microbenchmarks of round 2 said about the pipelined
@@ -715,7 +480,7 @@ __global__ void __launch_bounds__(kCell) exact_predict_kernel(const ExactArgs a0
         if (a.prediction) a.prediction += plane * a0.out_stride;
         a.hist += (size_t)plane * kHistBins;
         a.n_oob += plane;
-        a.acc += (size_t)plane * kPredShards * kPredAccWords;
+        a.acc += (size_t)plane * kPredAccWords;
     }
     // this plane's parameters as scalars (static indices only: a dynamic index into the argument struct would keep all of it in scratch memory);
     // a thread then picks its layer group's set with selects
@@ -964,7 +729,7 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
 }
 
 template <int ROLE, bool CHECK, bool WORDS>
-__device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, int lane, int wave) {
+__device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, int lane, int wave, uint32_t &early_poll) {
     uint8_t *s_cells = lds.cells[0];
     int32_t *s_ring = &lds.ring[0][0];
     uint32_t *s_masks = &lds.masks[0][0][0];
@@ -995,7 +760,11 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
     i32x4 own_a[2] = {i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}}, own_b[2] = {i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
 
     const PredTileWalk walk(a.n_tiles);
-    if (walk.first >= walk.end) return; // (a workgroup without a tile still takes part in the hand-over)
+    if (walk.first >= walk.end) { // (a workgroup without a tile still takes part in the hand-over - and clears its part of the histogram if it is one of the first ten)
+        wait_for_own_memory_ops_then_barrier();
+        pred_clear_publish(a, tid);
+        return;
+    }
     const uint32_t last = walk.first + ((walk.end - 1 - walk.first) / walk.step) * walk.step; // this workgroup's last tile
     // Heap nodes 0 and 1 of every block cell of this workgroup's tiles (p3_lf_*), by the level-8 waves only (role 0 holds two parameter groups
     // in scalar registers and has none to spare: with this code in its prologue its tile loop spilled 68 scalars instead of 4): thread t of the
@@ -1009,7 +778,8 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
         s_ring[tid] = a.pred_slots[(size_t)walk.first * kPredSlots + tid];
         s_ring[kPredSlots + tid] = a.pred_slots[(size_t)min(walk.first + walk.step, last) * kPredSlots + tid];
     }
-    __syncthreads();
+    wait_for_own_memory_ops_then_barrier(); // (also the clearing workgroups' exchanges: pred_clear_issue)
+    pred_clear_publish(a, tid);
     { // tile 0 straight into image 0: everything a wave stages is requested before the first value is converted
         uint32_t st_own_mask[2] = {0, 0};
         int raw_own[2];
@@ -1048,6 +818,7 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
     // tile's data has landed" and "prologue done" by the time stamps, most of it that wait.
     lds_barrier();
     trace_stamp(a.trace, blockIdx.x, 1, tid);
+    early_poll = pred_clear_poll(a, lane); // consumed by pred_hand_over, a whole tile loop later
 
     int it = 0;
     for (uint32_t tile = walk.first; tile < walk.end;) { // unrolled by two: the LDS image a tile lives in is a compile-time constant
@@ -1067,7 +838,7 @@ __device__ __forceinline__ PredArgs pred_plane_view(const PredArgs &a0, uint32_t
     if (a.words) a.words += plane * a0.out_stride;
     a.hist += (size_t)plane * kHistBins;
     a.n_oob += plane;
-    a.acc += (size_t)plane * kPredShards * kPredAccWords;
+    a.acc += (size_t)plane * kPredAccWords;
     a.inexact = a.acc + kAccInexact;
     // two branches with their own loads (caller's array / argument segment): a select between the two sources would be a select between
     // address spaces, and the copy behind it would go through scratch memory
@@ -1098,419 +869,24 @@ __global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const Pr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     trace_stamp(a.trace, blockIdx.x, 0, tid);
+    pred_clear_issue(a, tid, kP3Threads); // the first ten workgroups of the plane: the caller's histogram starts at zero (see pred_hand_over)
     for (int i = tid; i < kHistBins + 4; i += kP3Threads) s_hist[i] = 0;
     if (tid < 32) s_bkt[tid] = (uint16_t)(bucket_of((uint32_t)tid) << 12);
     for (int i = tid; i < 2 * (kP3ImageBytes - kP3ZeroOff) / 4; i += kP3Threads) // the zero words behind the cells of both images
         reinterpret_cast<uint32_t *>(s_cells + (i / ((kP3ImageBytes - kP3ZeroOff) / 4)) * kP3ImageBytes + kP3ZeroOff)[i % ((kP3ImageBytes - kP3ZeroOff) / 4)] = 0;
+    uint32_t early_poll = 0;
     if (wave & 1)
-        p3_run<1, CHECK, WORDS>(a, lds, tid, lane, wave);
+        p3_run<1, CHECK, WORDS>(a, lds, tid, lane, wave, early_poll);
     else
-        p3_run<0, CHECK, WORDS>(a, lds, tid, lane, wave);
-    __syncthreads();
+        p3_run<0, CHECK, WORDS>(a, lds, tid, lane, wave, early_poll);
+    lds_barrier(); // the table is complete; nobody waits here for the last tile's output stores
     trace_stamp(a.trace, blockIdx.x, 13, tid);
-    pred_hand_over(a, s_hist, reinterpret_cast<uint32_t *>(s_ring), tid, kP3Threads);
+    pred_hand_over<CHECK>(a, s_hist, reinterpret_cast<uint32_t *>(s_ring), tid, kP3Threads, early_poll);
     trace_exit(a.trace, blockIdx.x, tid);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// K4, value pass, on THIS kernel's skeleton (round 3): fit_value_kernel3. The sums of optimize_value_prediction (context_modeling.rs:175-202) are
-// the Gram matrix of u = [v0..v5, value] per layer group - the same six gathers per node as the predictor plus the node itself. fit_accumulate_kernel2
-// (k4_fit.hip: 512 threads, int16 cell images, v_dot2 on packed pairs, gathers the compiler schedules) spends a fifth of its time on those products and
-// the rest waiting; here the values arrive as f32 through the hand-pipelined ds_read_u16_d16_hi blocks of K2 (seven per node: the node's own value is a
-// seventh gather instead of a register) and a product-sum is one v_fma_f32. Everything is an integer of magnitude <= 65 536 = 256^2 in f32, exact while a
-// lane's sum stays below 2^24: a lane sees eight rows per tile, so the sums are flushed (as integers) every 16 tiles. One layer group per wave, and
-// every wave works on ONE pair of a lane's nodes in the FOUR block cells of its block row (slots 1 KiB apart, like K2's two): role-0 waves take 2 lane,
-// 2 lane + 1 (levels 0..6, group 2; even wave pairs) or 128 + 2 lane, + 1 (level 7, group 1; odd pairs), role-1 waves 256 + 4 lane + {0, 1} or + {2, 3}
-// (level 8, group 0) - fourteen addresses per lane where K2's four nodes need twenty-four. The roles differ in what they STAGE of the wave pair's two cells: K2's split.
-// Staging, images, slot ring and tile walk are K2's; hand-over, accumulator and the solve in the tail are fit_accumulate_kernel2's.
-// STATUS: an experiment, NOT the product path (DevicePlan::k4_value3, FRI_HIP_K4_VALUE3=1 under FRI_HIP_TUNING=1; tests/test_gpu_fit.py checks it bit for bit
-// against the product kernel). It is exact and it is slower: 41.7 us against 37.5 us for a 4096^2 plane. What the time stamps say: a tile takes 3.2-3.4 us here
-// too - K2's figure, with a third of K2's arithmetic, with one or two gather sets, with the staging loads one or two tiles ahead - and the wave sums of sixteen
-// waves cost ~4 us at the end. One 1024-thread workgroup per CU with a barrier per tile does not keep the CU busy; fit_accumulate_kernel2's two independent
-// 512-thread workgroups per CU cover each other's stalls (28 us for its tiles against 33.5 us here). The skeleton to carry over is that one, not K2's.
-// ---------------------------------------------------------------------------------------------------------------------
-struct Fit3Args {
-    const int32_t *coefs;
-    size_t coef_stride;
-    const int32_t *pred_slots;
-    const uint32_t *gather_off; // [512][4] byte offsets of the six neighbours in the permuted 1 KiB layout (build_gather_tables)
-    const uint16_t *pair_pos;
-    const uint32_t *halo_list;
-    const uint32_t *valid_mask;
-    uint32_t n_tiles;
-    unsigned long long *acc;       // per plane: kFitShards copies of kFitAccWords words, zero between launches (the layout of k4_fit.hip)
-    unsigned long long *gram;      // [n_planes][3][28]
-    unsigned long long *out_range; // [n_planes] or NULL
-    float *solve_params;           // as FitArgs (k4_fit.hip): NULL = sums only
-    float *host_params;
-    unsigned long long *host_range;
-    unsigned long long *trace;
-};
-constexpr int kF3AccInt = 3 * 28, kF3AccTicket = kF3AccInt + 18, kF3AccRange = kF3AccTicket + 1; // = kFitAcc* of k4_fit.hip
-static_assert(kF3AccRange + 1 == (int)kFitAccWords, "fit accumulator layout");
-
-// "never a node" entries read the zero words behind an image's cells at the cell's distance from the wave's first cell: up to 3 KiB for role 0's four cells
-// (K2's two cells: 1 KiB), so this kernel's images carry 4 KiB + 64 bytes of zeros
-constexpr int kF3ImageBytes = kP3ZeroOff + 4 * kP3SlotBytes + 64;
-struct F3Lds {
-    uint8_t cells[2][kF3ImageBytes];
-    int32_t ring[4][kPredSlots]; // slot lists of tiles i .. i + 3: the loads of tile i + 2 are issued during tile i
-    uint32_t masks[2][kPredSlots][16];
-    unsigned long long s_int[3][28];
-    uint32_t flag, range;
-    Solve6Work work[3];
-};
-static_assert(sizeof(F3Lds) <= 160 * 1024 && kF3ImageBytes + 3 * kP3SlotBytes < 65536, "LDS budget / image + cell offset must fit a DS instruction's 16-bit offset field");
-
-template <int OFFSET>
-__device__ __forceinline__ void f3_issue(float (&g)[7], const uint32_t (&a)[7]) {
-    asm volatile("ds_read_u16_d16_hi %0, %7 offset:%14\n\t"
-                 "ds_read_u16_d16_hi %1, %8 offset:%14\n\t"
-                 "ds_read_u16_d16_hi %2, %9 offset:%14\n\t"
-                 "ds_read_u16_d16_hi %3, %10 offset:%14\n\t"
-                 "ds_read_u16_d16_hi %4, %11 offset:%14\n\t"
-                 "ds_read_u16_d16_hi %5, %12 offset:%14\n\t"
-                 "ds_read_u16_d16_hi %6, %13 offset:%14"
-                 : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6])
-                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "n"(OFFSET));
-}
-template <int OFFSET>
-__device__ __forceinline__ void f3_issue_wait(float (&nxt)[7], const uint32_t (&a)[7], float (&cur)[7]) {
-    asm volatile("ds_read_u16_d16_hi %0, %14 offset:%21\n\t"
-                 "ds_read_u16_d16_hi %1, %15 offset:%21\n\t"
-                 "ds_read_u16_d16_hi %2, %16 offset:%21\n\t"
-                 "ds_read_u16_d16_hi %3, %17 offset:%21\n\t"
-                 "ds_read_u16_d16_hi %4, %18 offset:%21\n\t"
-                 "ds_read_u16_d16_hi %5, %19 offset:%21\n\t"
-                 "ds_read_u16_d16_hi %6, %20 offset:%21\n\t"
-                 "s_waitcnt lgkmcnt(7)"
-                 : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]), "+v"(nxt[5]), "+v"(nxt[6]), "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]),
-                   "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6])
-                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "n"(OFFSET));
-}
-__device__ __forceinline__ void f3_wait(float (&cur)[7]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]));
-}
-// one row: acc += upper triangle of u u^T, u = [v0..v5, value]; MASKED: the row counts only when m = 1 (a None node / an LF node is no row of the fit)
-template <bool MASKED>
-__device__ __forceinline__ void f3_row(const float (&u)[7], float m, float (&acc)[28]) {
-    float mu[7];
-#pragma unroll
-    for (int i = 0; i < 7; i++) mu[i] = MASKED ? __fmul_rn(m, u[i]) : u[i];
-    int n = 0;
-#pragma unroll
-    for (int i = 0; i < 7; i++)
-#pragma unroll
-        for (int j = i; j < 7; j++, n++) acc[n] = __builtin_fmaf(mu[i], u[j], acc[n]);
-}
-// one pair of a lane's nodes in the four block cells of the wave's block row: eight rows in one pipeline. MASKED: m says which of them are rows
-// (the staged Some/None masks; heap nodes 0 and 1); without it all four cells are interior cells and every node is a row.
-template <int IMG, bool MASKED>
-__device__ __forceinline__ void f3_row_of_cells(const uint32_t (&addr)[2][7], uint32_t rows, float (&acc)[28]) {
-    constexpr int kOff = IMG * kF3ImageBytes;
-    // the two gather sets live inside this function (low halves zero: a d16_hi load writes bits 31:16): carried from tile to tile like K2's, they crossed the
-    // interior / boundary branch of the caller and cost fourteen registers there plus copies at its merge
-    float g[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // ONE gather set: issue, wait, 28 multiply-adds - the other three waves of the SIMD cover the wait. (Two alternating sets, as in K2, are fourteen registers
-    // this kernel spends on the second staging set instead: it spilled with both.)
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        if ((t >> 1) == 0) f3_issue<kOff>(g, addr[t & 1]);
-        if ((t >> 1) == 1) f3_issue<kOff + kP3SlotBytes>(g, addr[t & 1]);
-        if ((t >> 1) == 2) f3_issue<kOff + 2 * kP3SlotBytes>(g, addr[t & 1]);
-        if ((t >> 1) == 3) f3_issue<kOff + 3 * kP3SlotBytes>(g, addr[t & 1]);
-        f3_wait(g);
-        f3_row<MASKED>(g, (rows >> t) & 1u ? 1.f : 0.f, acc);
-    }
-}
-// A wave's 28 sums, exact integers in f32, into the workgroup's table. A lane's sum is below 2^24, so the wave's is below 2^30: the whole reduction stays in
-// 32 bits - four butterfly steps inside the rows of 16, then row_bcast:15 / row_bcast:31 carry the row totals into lane 63, which adds the total to LDS
-// (fit2_wave_sums of k4_fit.hip, whose 32-bit bound holds per row only, reads four row totals through readlane into 64-bit scalar adds: four times the instructions).
-__device__ __forceinline__ void f3_wave_sums(float (&acc)[28], int group, int lane, F3Lds &lds) {
-#pragma unroll
-    for (int k = 0; k < 28; k++) {
-        int v = (int)acc[k];
-        acc[k] = 0.f;
-        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
-        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
-        if (lane == 63) atomicAdd(&lds.s_int[group][k], (unsigned long long)(long long)v);
-    }
-}
-// staging of one of the wave's own block cells, K2's (p3_commit4) plus the fit's range rule: a Some coefficient outside [-256, 255] is reported
-template <bool CHECK>
-__device__ __forceinline__ void f3_commit4(int raw, i32x4 v, uint8_t *dst, uint32_t pos0, uint32_t pos1, int lane, uint32_t *range_counter) {
-    if (CHECK && raw >= 0) { // a None is 0x80000000: it is not an outlier
-        const int w[4] = {v.x, v.y, v.z, v.w};
-        uint32_t m = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) m |= w[j] == kNone ? 0u : ((uint32_t)w[j] + 256u) & 0xFFFFFE00u;
-        if (__any(m != 0) && lane == 0) atomicAdd(range_counter, 1u);
-    }
-    (void)p3_commit4<false>(raw, v, dst, pos0, pos1);
-}
-template <bool CHECK>
-__device__ __forceinline__ void f3_commit_halo(const P3Halo &h, uint8_t *image, uint32_t lds_off, int lane, uint32_t *range_counter) {
-    if (CHECK) {
-        const uint32_t m = (h.raw < 0 || h.v == kNone) ? 0u : ((uint32_t)h.v + 256u) & 0xFFFFFE00u;
-        if (__any(m != 0) && lane == 0) atomicAdd(range_counter, 1u);
-    }
-    (void)p3_commit_halo<false>(h, image, lds_off);
-}
-
-struct F3Lane {
-    uint32_t addr[2][7]; // the six neighbours and the node itself, for the lane's two nodes (first cell of the block row)
-    uint32_t opos[2], halo_ring, halo_heap, halo_lds;
-};
-
-// What a wave stages of one tile: its half of its two block cells, their Some/None masks (role 1), one halo value per lane.
-struct F3Stage {
-    i32x4 own[2];
-    uint32_t mask[2];
-    P3Halo halo;
-    int raw[2];
-};
-template <int ROLE>
-__device__ __forceinline__ void f3_stage_issue(const Fit3Args &a, const int32_t *plane, const int32_t *slots, int slot_a, int lane, const F3Lane &L, F3Stage &st) {
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        st.raw[c] = __builtin_amdgcn_readfirstlane(slots[slot_a + c]);
-        const int cell = max(pred_slot_cell(st.raw[c]), 0);
-        st.own[c] = p3_load_own<ROLE>(plane + (size_t)cell * kCell, (uint32_t)lane);
-        if (ROLE == 1) st.mask[c] = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u];
-    }
-    p3_issue_halo(plane, slots, L.halo_ring, L.halo_heap, st.halo);
-}
-template <int ROLE, bool CHECK>
-__device__ __forceinline__ void f3_stage_commit(F3Lds &lds, uint32_t img, int slot_a, int lane, const F3Lane &L, const F3Stage &st) {
-    asm volatile("" : "+s"(img)); // (as in p3_tile: keeps the write addresses from being hoisted out of the loop into registers it does not have)
-    uint8_t *image = lds.cells[0] + img * kF3ImageBytes;
-    uint32_t *masks = &lds.masks[0][0][0] + img * (kPredSlots * 16);
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        f3_commit4<CHECK>(st.raw[c], st.own[c], image + (slot_a + c) * kP3SlotBytes, L.opos[0], L.opos[1], lane, &lds.range);
-        if (ROLE == 1 && lane < 16) masks[(slot_a + c) * 16 + lane] = st.mask[c];
-    }
-    f3_commit_halo<CHECK>(st.halo, image, L.halo_lds, lane, &lds.range);
-}
-
-// One tile out of image IMG. The loads of tile i + 2 are issued here, into `issue`; `commit` holds tile i + 1, requested a tile ago, and goes into the other
-// image behind this tile's sums: a staging load has two tile times to arrive. (With K2's one-tile window the tile time of this kernel was the latency of
-// those loads - 3.2 us, K2's figure, with a third of K2's arithmetic.)
-template <int IMG, int ROLE, bool CHECK>
-__device__ __forceinline__ void f3_tile(const Fit3Args &a, const int32_t *plane, F3Lds &lds, int it, bool more1, bool more2, uint32_t next3_tile, int tid, int lane, int slot_a,
-                                        int slot_row, uint32_t mask_word, uint32_t mask_shift, bool lf_lane, bool lf_wave, const F3Lane &L, F3Stage &issue, const F3Stage &commit,
-                                        float (&acc)[28]) {
-    const int32_t *cur_slots = lds.ring[it & 3];
-    const int32_t slot_pre = a.pred_slots[(size_t)next3_tile * kPredSlots + tid % kPredSlots];
-    if (more2) f3_stage_issue<ROLE>(a, plane, lds.ring[(it + 2) & 3], slot_a, lane, L, issue);
-    {
-        // all four cells interior and no LF lane in the wave: every node is a row (wave-uniform; decided before the first gather is issued)
-        int all_interior = lf_wave ? 0 : 1;
-#pragma unroll
-        for (int c = 0; c < 4; c++) all_interior &= pred_slot_interior(__builtin_amdgcn_readfirstlane(cur_slots[slot_row + c])) ? 1 : 0;
-        if (all_interior) {
-            f3_row_of_cells<IMG, false>(L.addr, 255u, acc);
-        } else {
-            // the pair's Some bits in the four cells, read before the first gather is issued. A slot without a cell has no rows at all (its own values are
-            // zeros, but its gathers would see the neighbouring cells).
-            uint32_t rows = 0; // bit 2 c + n: node n of the pair in cell c is a row
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const bool absent = __builtin_amdgcn_readfirstlane(cur_slots[slot_row + c]) < 0;
-                const uint32_t bits = (lf_lane || absent) ? 0u : lds.masks[IMG][slot_row + c][mask_word] >> mask_shift;
-                rows |= (bits & 3u) << (2 * c);
-            }
-            asm volatile("" : "+v"(rows)); // (complete now: no LDS wait of the compiler's between the blocks below)
-            f3_row_of_cells<IMG, true>(L.addr, rows, acc);
-        }
-    }
-    if (more1) f3_stage_commit<ROLE, CHECK>(lds, IMG ^ 1, slot_a, lane, L, commit);
-    if (tid < kPredSlots) lds.ring[(it + 3) & 3][tid] = slot_pre;
-    lds_barrier();
-    trace_stamp(a.trace, blockIdx.x, 2 + it, tid);
-}
-
-template <int ROLE, bool CHECK>
-__device__ __forceinline__ void f3_run(const Fit3Args &a, const int32_t *plane, F3Lds &lds, int tid, int lane, int wave) {
-    uint8_t *s_cells = lds.cells[0];
-    int32_t *s_ring = &lds.ring[0][0];
-    const int pair = wave >> 1;
-    const int slot_a = (1 + (pair >> 1)) * kPredSide + 1 + 2 * (pair & 1); // the wave's two block cells (staging; role 1 also works on them)
-    const int slot_row = (1 + (pair >> 1)) * kPredSide + 1;               // role 0 works on the four cells of its block row
-    const int group = ROLE ? 0 : (pair & 1) ? 1 : 2;
-    const int node0 = ROLE ? 256 + 4 * lane + 2 * (pair & 1) : (pair & 1) ? 128 + 2 * lane : 2 * lane;
-    const bool lf_wave = ROLE == 0 && !(pair & 1), lf_lane = lf_wave && lane == 0; // heap nodes 0 and 1 are the LF predictor's: no rows of the fit
-    const uint32_t mask_word = (uint32_t)node0 >> 5, mask_shift = (uint32_t)node0 & 31u;
-
-    F3Lane L;
-    const uint32_t cells_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_cells;
-    const int base_slot = slot_row;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int node = node0 + j;
-        const u32x4 o = reinterpret_cast<const u32x4 *>(a.gather_off)[node];
-        const uint32_t rel[3] = {o.x, o.y, o.z};
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int r = (int)(short)((rel[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
-            // "never a node": the image's zero words; the further cells of the wave read them up to 3 KiB further on - zeros too (see the kernel)
-            L.addr[j][k] = r == 0x7FFF ? cells_lds + kP3ZeroOff : cells_lds + (uint32_t)(base_slot * kP3SlotBytes + r);
-        }
-        L.addr[j][6] = cells_lds + (uint32_t)(base_slot * kP3SlotBytes) + 2u * (2u * a.pair_pos[node >> 1] + (uint32_t)(node & 1)); // the node itself
-    }
-    L.opos[0] = 4u * a.pair_pos[ROLE ? 128 + 2 * lane : lane];
-    L.opos[1] = 4u * a.pair_pos[ROLE ? 129 + 2 * lane : 64 + lane];
-    {
-        const uint32_t e = a.halo_list[tid];
-        L.halo_ring = 4u * (e & 63u), L.halo_heap = 4u * ((e >> 8) & 511u), L.halo_lds = (e & 63u) * (uint32_t)kP3SlotBytes + (e >> 20);
-    }
-    float acc[28];
-#pragma unroll
-    for (int k = 0; k < 28; k++) acc[k] = 0.f;
-
-    const PredTileWalk walk(a.n_tiles);
-    if (walk.first >= walk.end) return;
-    const uint32_t last = walk.first + ((walk.end - 1 - walk.first) / walk.step) * walk.step;
-    if (tid < kPredSlots) {
-        s_ring[tid] = a.pred_slots[(size_t)walk.first * kPredSlots + tid];
-        s_ring[kPredSlots + tid] = a.pred_slots[(size_t)min(walk.first + walk.step, last) * kPredSlots + tid];
-        s_ring[2 * kPredSlots + tid] = a.pred_slots[(size_t)min(walk.first + 2 * walk.step, last) * kPredSlots + tid];
-    }
-    __syncthreads();
-    F3Stage st_a, st_b; // tiles of even / odd index
-    f3_stage_issue<ROLE>(a, plane, s_ring, slot_a, lane, L, st_a);
-    if (walk.first + walk.step < walk.end) f3_stage_issue<ROLE>(a, plane, s_ring + kPredSlots, slot_a, lane, L, st_b); // tile 1: in flight through tile 0
-    f3_stage_commit<ROLE, CHECK>(lds, 0u, slot_a, lane, L, st_a);                                                       // tile 0 straight into image 0
-    lds_barrier();
-    trace_stamp(a.trace, blockIdx.x, 1, tid);
-
-    int it = 0, since_flush = 0;
-    for (uint32_t tile = walk.first; tile < walk.end;) { // unrolled by two: the LDS image a tile lives in is a compile-time constant
-        f3_tile<0, ROLE, CHECK>(a, plane, lds, it, tile + walk.step < walk.end, tile + 2 * walk.step < walk.end, min(tile + 3 * walk.step, last), tid, lane, slot_a, slot_row, mask_word,
-                                mask_shift, lf_lane, lf_wave, L, st_a, st_b, acc);
-        tile += walk.step, it++;
-        if (tile < walk.end) {
-            f3_tile<1, ROLE, CHECK>(a, plane, lds, it, tile + walk.step < walk.end, tile + 2 * walk.step < walk.end, min(tile + 3 * walk.step, last), tid, lane, slot_a, slot_row,
-                                    mask_word, mask_shift, lf_lane, lf_wave, L, st_b, st_a, acc);
-            tile += walk.step, it++;
-        }
-        since_flush += 2;
-        if (since_flush >= 16) { // eight rows per tile and lane, each product <= 2^16: sixteen tiles stay below 2^24 - exact in f32
-            f3_wave_sums(acc, group, lane, lds);
-            since_flush = 0;
-        }
-    }
-    f3_wave_sums(acc, group, lane, lds);
-}
-
-// the three solves at the end of the kernel (as fit2_tail_solve of k4_fit.hip: not inlined, so that its f64 temporaries stay out of the tile loop's budget)
-__device__ __attribute__((noinline)) void f3_tail_solve(const long long *sums_int, Solve6Work *w, float *params, float *host_params) {
-    float out[6];
-    fit_value_group(sums_int, out, *w);
-#pragma unroll
-    for (int k = 0; k < 6; k++) params[k] = out[k];
-    if (host_params) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) host_params[k] = out[k];
-    }
-}
-
-template <bool CHECK>
-__global__ void __launch_bounds__(kP3Threads) fit_value_kernel3(const Fit3Args a) {
-    const uint32_t plane_i = blockIdx.y;
-    const int32_t *const plane = a.coefs + plane_i * a.coef_stride;
-    unsigned long long *const accp = a.acc + (size_t)plane_i * kFitShards * kFitAccWords;
-    unsigned long long *const accs = accp + (size_t)(blockIdx.x % kFitShards) * kFitAccWords;
-    __shared__ __attribute__((aligned(16))) F3Lds lds;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    trace_stamp(a.trace, blockIdx.x, 0, tid);
-    if (tid < 3 * 28) (&lds.s_int[0][0])[tid] = 0;
-    if (tid == 0) lds.range = 0;
-    for (int i = tid; i < 2 * (kF3ImageBytes - kP3ZeroOff) / 4; i += kP3Threads) // the zero words behind the cells of both images
-        reinterpret_cast<uint32_t *>(lds.cells[0] + (i / ((kF3ImageBytes - kP3ZeroOff) / 4)) * kF3ImageBytes + kP3ZeroOff)[i % ((kF3ImageBytes - kP3ZeroOff) / 4)] = 0;
-    if (wave & 1)
-        f3_run<1, CHECK>(a, plane, lds, tid, lane, wave);
-    else
-        f3_run<0, CHECK>(a, plane, lds, tid, lane, wave);
-    __syncthreads();
-    trace_stamp(a.trace, blockIdx.x, 13, tid);
-    // hand-over as in fit_accumulate_kernel2: adds into this workgroup's copy of the plane's accumulator, a ticket, the last workgroup sums the copies
-    if (tid < kF3AccInt) __hip_atomic_fetch_add(accs + tid, (&lds.s_int[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 0 && lds.range) __hip_atomic_fetch_add(accp + kF3AccRange, (unsigned long long)lds.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    wait_for_own_memory_ops_then_barrier();
-    if (tid == 0) lds.flag = __hip_atomic_fetch_add(accp + kF3AccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    trace_exit(a.trace, blockIdx.x, tid);
-    if (lds.flag == 0 || tid >= 64) return;
-    unsigned long long *const out_int = a.gram + (size_t)plane_i * kF3AccInt;
-    for (int i = tid; i < kF3AccInt; i += 64) {
-        unsigned long long part[kFitShards], sum = 0;
-#pragma unroll
-        for (uint32_t sh = 0; sh < kFitShards; sh++) part[sh] = __hip_atomic_load(accp + sh * kFitAccWords + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (uint32_t sh = 0; sh < kFitShards; sh++) {
-            sum += part[sh];
-            __hip_atomic_store(accp + sh * kFitAccWords + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        out_int[i] = sum;
-        (&lds.s_int[0][0])[i] = sum;
-    }
-    if (tid == 0) {
-        const unsigned long long r = __hip_atomic_exchange(accp + kF3AccRange, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.out_range) a.out_range[plane_i] = r;
-        if (a.host_range) a.host_range[plane_i] = r;
-        __hip_atomic_store(accp + kF3AccTicket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (!a.solve_params) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (tid < 3) {
-        const size_t at = (size_t)plane_i * (sizeof(PredictParams) / sizeof(float)) + tid * 6;
-        f3_tail_solve(reinterpret_cast<const long long *>(lds.s_int[tid]), &lds.work[tid], a.solve_params + at, a.host_params ? a.host_params + at : nullptr);
-    }
 }
 
 } // namespace
 
-hipError_t launch_fit_value3(const DevicePlan &p, unsigned long long *acc, const PredBatch &b, unsigned long long *sums_int, unsigned long long *out_of_range, hipStream_t stream,
-                             const FitSolve *solve) {
-    if (!acc || !sums_int || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
-    Fit3Args a{};
-    a.coefs = b.coefs;
-    a.coef_stride = b.coef_stride;
-    a.pred_slots = p.pred_slots;
-    a.gather_off = p.gather_off;
-    a.pair_pos = p.pair_pos;
-    a.halo_list = p.halo_list;
-    a.valid_mask = p.valid_mask;
-    a.n_tiles = p.n_pred_tiles;
-    a.acc = acc;
-    a.gram = sums_int;
-    a.out_range = out_of_range;
-    a.trace = p.trace;
-    if (solve) {
-        if (!solve->params) return hipErrorInvalidValue;
-        a.solve_params = solve->params, a.host_params = solve->host_params, a.host_range = solve->host_range;
-    }
-    // the grid of launch_predict_histogram: one plane = a workgroup per CU; many planes = an eighth of the machine each, eight side by side
-    uint32_t blocks = p.n_pred_tiles < p.pred_blocks ? p.n_pred_tiles : p.pred_blocks;
-    if (b.n_planes > 1) {
-        const uint32_t share = (p.n_pred_tiles + 7) / 8, eighth = p.pred_blocks / 8 ? p.pred_blocks / 8 : 1;
-        blocks = share < eighth ? eighth : share;
-        if (blocks > p.pred_blocks) blocks = p.pred_blocks;
-        if (blocks > p.n_pred_tiles) blocks = p.n_pred_tiles;
-    }
-    if (!blocks) blocks = 1;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((fit_value_kernel3<true>), dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
-    return hipGetLastError();
-}
 
 void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out) {
     for (int p = 0; p < kCell; p++) {
@@ -1580,12 +956,13 @@ void build_halo_list(const uint16_t *nbr_table, const uint16_t *pair_pos, uint32
     }
 }
 
-hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const PredBatch &b, uint8_t *bucket, int32_t *prediction, uint32_t *hist, unsigned long long *n_oob,
-                                    int trust, hipStream_t stream) {
-    if (!acc || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
+hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, uint32_t serial, const PredBatch &b, uint8_t *bucket, int32_t *prediction, uint32_t *hist,
+                                    unsigned long long *n_oob, int trust, hipStream_t stream) {
+    if (!acc || !serial || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     PredArgs a{};
     a.acc = acc;
+    a.serial = serial;
     a.coefs = b.coefs;
     a.coef_stride = b.coef_stride;
     a.out_stride = b.out_stride;
@@ -1603,7 +980,7 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const Pr
     a.n_tiles = p.n_pred_tiles;
     a.trusted = trust != kPredAnyInt32 ? 1 : 0;
     a.words = b.words;
-    if (b.words && (trust != kPredForwardOutput || p.k2_previous)) return hipErrorInvalidValue; // the halfword form exists for the chain's own coefficients only
+    if (b.words && trust != kPredForwardOutput) return hipErrorInvalidValue; // the halfword form exists for the chain's own coefficients only
     // One plane: a workgroup per CU. Many planes: a plane keeps an eighth of the machine busy (at least ~8 tiles per workgroup, so that
     // the start-up and the hand-over are paid once per 8 tiles) and eight planes run side by side.
     uint32_t blocks = p.n_pred_tiles < p.pred_blocks ? p.n_pred_tiles : p.pred_blocks;
@@ -1616,14 +993,6 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const Pr
     if (!blocks) blocks = 1;
     a.junk = p.junk;
     a.trace = p.trace;
-    if (p.k2_previous) { // FRI_HIP_TUNING=1 FRI_HIP_K2_PREVIOUS=1: the pipelined kernel of round 1 (A/B on one box); one plane, both outputs
-        if (!bucket || !prediction || b.n_planes != 1) return hipErrorInvalidValue;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(predict_histogram_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, kPred2LdsBytes);
-        if (e != hipSuccess) return e;
-        (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
-        hipLaunchKernelGGL(predict_histogram_kernel2, dim3(blocks), dim3(kPred2Threads), kPred2LdsBytes, stream, a);
-        return hipGetLastError();
-    }
     a.pred_off = p.gather_off;
     a.pair_pos = p.pair_pos;
     a.heap_of_pos = p.heap_of_pos;

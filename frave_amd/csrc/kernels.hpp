@@ -41,7 +41,6 @@ struct DevicePlan {
     uint32_t hist_blocks = 0;
     uint8_t *junk = nullptr;              // [pred_blocks][kPredJunkWaves][kPredJunkBytes]: output lines of block slots without a cell (pipelined K2)
     uint32_t pred_blocks = 0;             // workgroups of the pipelined K2: one 1024-thread workgroup per CU
-    bool k2_previous = false;             // tuning: round 1's pipelined K2 (A/B)
     bool k4_previous = false;             // tuning: round 1's fit kernel (A/B)
     uint32_t n_tiles = 0;
     uint32_t F = 0;
@@ -51,7 +50,6 @@ struct DevicePlan {
     int32_t k1_ablate = 0; // timing-only ablation flags, see FwdArgs::ablate
     int32_t k2_ablate = 0; // the same for K2, see PredArgs::ablate
     bool k3_multiply = false; // fri_hip_plan_set_dequantiser: the inverse kernel multiplies by the quantiser instead of reproducing the reference's division
-    bool k4_value3 = false; // tuning (FRI_HIP_K4_VALUE3=1): the fit's value pass as fit_value_kernel3, the experiment on K2's skeleton (k2_predict.hip) - exact, 4 us slower
     unsigned long long *trace = nullptr; // [n_wg][16] diagnostic timeline (FRI_HIP_TRACE=1), else null
     // K3's static write-out lists (null = not built: the kernel scans the rectangle)
     const InvTileLists *inv_lists = nullptr;
@@ -70,10 +68,8 @@ constexpr uint32_t kFitAccWords = 3 * 28 + 18 + 2; // integer sums, f64 sums, ti
 // word were 5-6 us of every launch (per-workgroup time stamps: "loop done" -> "ticket drawn"). The accumulator of a plane is therefore kept in
 // kFitShards copies, workgroup b adds into copy b % kFitShards, and the workgroup that draws the last ticket (copy 0 holds it) sums the copies.
 constexpr uint32_t kFitShards = 16;
-// (K2's accumulator is NOT sharded like the fit kernel's: tried with 4 copies - the last workgroup's copy-out, 40 loads and 40 stores per thread instead
-// of 10, cost more than the contention on the hot bins: K2 47.2 -> 49.3 us in an A/B on one box)
-constexpr uint32_t kPredShards = 1;
-constexpr uint32_t kPredAccRing = 8, kPredAccWords = 10 * 1024 + 8; // per plane: counts, out-of-alphabet count (u64), ticket, pad, "inexact" flag, the exact kernel's ticket, pad
+// K2 adds its counts straight into the caller's histogram (k2_predict.hip, pred_hand_over): its accumulator is only the bookkeeping of that hand-over
+constexpr uint32_t kPredAccRing = 8, kPredAccWords = 16; // per plane: ten "cleared" flags, pad, ticket, pad, "inexact" flag, the exact kernel's ticket
 
 struct QMatrix {
     int32_t q[32];
@@ -99,14 +95,15 @@ struct PredBatch {
     PredictParams pp[3] = {}; // used when params is NULL: plane k takes pp[min(k, 2)] (one image's channels travel as kernel arguments)
     uint16_t *words = nullptr; // K2 only, with kPredForwardOutput only: write bucket << 10 | symbol per node ([n_planes] planes, out_stride apart) and neither bucket nor prediction
 };
-// K2. acc: n_planes accumulators of kPredShards x kPredAccWords words, all zero between launches. hist [n_planes][10][1024], n_oob [n_planes].
+// K2. acc: n_planes x kPredAccWords words of hand-over bookkeeping, zero when allocated; serial: the number of this launch on `acc` (1, 2, ...: the caller counts; never 0).
+// hist [n_planes][10][1024] and n_oob [n_planes] are device memory the kernel clears itself and then adds into with device-scope atomics.
 // trust: what is known about the coefficients. kPredAnyInt32: nothing - the fast kernel checks what it stages and the exact int32 kernel behind it
 // redoes a plane whose values its LDS image cannot hold. kPredPromised: the caller promises the forward kernel's output (magnitudes <= 255,
 // fri_hip_plan_assume_forward_coefficients): still checked, no exact kernel, a broken promise comes back as n_oob = ~0. kPredForwardOutput: this
 // library's forward kernel wrote them earlier in the same call: not checked.
 constexpr int kPredAnyInt32 = 0, kPredPromised = 1, kPredForwardOutput = 2;
-hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, const PredBatch &b, uint8_t *bucket, int32_t *prediction, uint32_t *hist, unsigned long long *n_oob,
-                                    int trust, hipStream_t stream);
+hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, uint32_t serial, const PredBatch &b, uint8_t *bucket, int32_t *prediction, uint32_t *hist,
+                                    unsigned long long *n_oob, int trust, hipStream_t stream);
 // Fit accumulators: mode 0 = value fit (sums_int[n_planes][3][28]), mode 1 = width fit (sums_int[n_planes][3][21], sums_dbl[n_planes][3][6]).
 // acc: n_planes accumulators of kFitShards x kFitAccWords words, all zero between launches.
 // out_of_range (may be NULL): per plane, the number of waves that staged a Some coefficient outside [-256, 255] - the sums are then not to be trusted.
@@ -120,9 +117,6 @@ struct FitSolve {
 };
 hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
                                  unsigned long long *out_of_range, hipStream_t stream, const FitSolve *solve = nullptr);
-// The value pass (mode 0 above) on K2's skeleton: fit_value_kernel3 (k2_predict.hip). Same accumulator, same sums, same solve in the tail.
-hipError_t launch_fit_value3(const DevicePlan &p, unsigned long long *acc, const PredBatch &b, unsigned long long *sums_int, unsigned long long *out_of_range, hipStream_t stream,
-                             const FitSolve *solve = nullptr);
 // The fit's 6 x 6 solves on the device: sums of a launch_fit_accumulate (mode 0: sums_int[n_planes][3][28]; mode 1: sums_int[n_planes][3][21],
 // sums_dbl[n_planes][3][6], rows[3] = heights of the reference's matrices) -> params[n_planes] (PredictParams: mode 0 writes .value, mode 1 .width).
 // host_params / host_range (device-visible pointers into mapped host memory, or NULL): the solving threads also leave the parameters - and the
