@@ -2,9 +2,10 @@
 """bench.py -- Mpixels/s of libfri's encode hot path (transform + quantisation) at 4096x4096 on MI355X.
 
 A "step" is one pass of K1 (address map + residue transform + quantiser) over one synthetic 8-bit
-4096x4096 plane per GPU, input already resident in HBM. Steps rotate over enough distinct image/coefficient
-slots to exceed the 256 MiB Infinity Cache, so the timed traffic really goes to HBM. Ranks hold independent
-images (one process per GPU, no data-path collective): weak scaling.
+4096x4096 plane per GPU, input already resident in HBM. Steps rotate over 24 distinct image/coefficient slots
+(403 MB of pixels, 2 GB with the coefficients): with 8 slots (rounds 1-3) the 134 MB of pixels stayed in the 256 MiB
+Infinity Cache and the launch period was 16.5 us; from 24 slots on it is flat at the HBM-bound figure (tools/k1_slots.py,
+DESIGN.md section 7). Ranks hold independent images (one process per GPU, no data-path collective): weak scaling.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -31,7 +32,7 @@ def measured_traffic():
     """HBM bytes per K1 launch from the committed rocprofv3 PMC pass (profiles/), or None. bench.py cannot collect
     hardware counters itself; the number is tied to the kernel named in the file."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_k1_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_k1_traffic.json")) as f:
             return int(json.load(f)["hbm_bytes_per_launch"])
     except Exception:
         return None
@@ -121,20 +122,24 @@ def cpu_baseline(seconds_budget=12.0):
     }
 
 
-def extras(plan, ctx, torch, np, px0, co0, pstride, cstride, slots, alg_bytes, stream, full=False):
+def extras(plan, ctx, torch, np, d_px, d_co, slots, alg_bytes, stream, full=False):
     """Event-timed figures for the kernels beside K1 and for the chain (see the call site). {us, frac}: microseconds per launch (or per chain /
-    per image) and algorithmic bytes / us / 8 TB/s."""
+    per image) and algorithmic bytes / us / 8 TB/s. Like the headline, every figure rotates over the bench's image / coefficient slots, so that its
+    input comes from HBM (a kernel re-reading ONE 68 MB plane finds it in the 256 MiB Infinity Cache: K2 42 instead of 47 us, K3 26.5 instead of 29.6)."""
     import frave_amd
 
     F = plan.num_cells
+    pstride, cstride = plan.pixel_bytes, plan.coef_count
+    px0, co0 = d_px.data_ptr(), d_co.data_ptr()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def timed(fn, reps=20):
-        fn()
+    def timed(fn, reps=None):
+        reps = reps or slots  # one pass over the slots (a second pass re-reads slot 0 only after 2 GB of other traffic)
+        fn(slots - 1)
         torch.cuda.synchronize()
         ev0.record()
-        for _ in range(reps):
-            fn()
+        for i in range(reps):
+            fn(i % slots)
         ev1.record()
         torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) / reps * 1e3
@@ -142,6 +147,8 @@ def extras(plan, ctx, torch, np, px0, co0, pstride, cstride, slots, alg_bytes, s
     def entry(us, nbytes):
         return {"us": round(us, 2), "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
 
+    px = lambda k: px0 + k * pstride
+    co = lambda k: co0 + k * cstride * 4
     plane = F * 512
     k2_bytes = plane * (4 + 1 + 4) + 10 * 1024 * 4  # coefficient read + bucket + prediction write + histogram
     k4_bytes = plane * 4
@@ -155,23 +162,25 @@ def extras(plan, ctx, torch, np, px0, co0, pstride, cstride, slots, alg_bytes, s
     d_g = torch.empty(3 * 28, dtype=torch.int64, device="cuda")
     d_w = torch.empty(18, dtype=torch.float64, device="cuda")
     d_par = torch.zeros(36, dtype=torch.float32, device="cuda")
-    res = {"note": "HIP events around 20 back-to-back launches each, one 4096x4096 plane unless said otherwise; frac = algorithmic bytes (SURVEY.md 8d) / us / 8 TB/s"}
+    res = {"note": f"HIP events around {slots} back-to-back launches each, rotating over the {slots} image / coefficient slots (inputs from HBM), one 4096x4096 plane unless said "
+                   "otherwise; frac = algorithmic bytes (SURVEY.md 8d) / us / 8 TB/s"}
     # K2 alone: the coefficients are K1's, so the plan may skip the exact-int32 guard launch (fri_hip_plan_assume_forward_coefficients)
     plan.assume_forward_coefficients(True)
-    res["k2_predict_histogram"] = entry(timed(lambda: plan.predict_histogram_dev(co0, 0, vp, wp, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=stream)), k2_bytes)
+    res["k2_predict_histogram"] = entry(timed(lambda k: plan.predict_histogram_dev(co(k), 0, vp, wp, d_b.data_ptr(), d_p.data_ptr(), d_h.data_ptr(), d_o.data_ptr(), stream=stream)), k2_bytes)
     plan.assume_forward_coefficients(False)
     assert int(d_h.sum()) + int(d_o) == plan.num_some
-    res["k3_inverse"] = entry(timed(lambda: plan.inverse_transform_dev(co0, d_back.data_ptr(), stream=stream)), alg_bytes)
-    res["k4_fit_value_sums"] = entry(timed(lambda: plan.fit_value_sums_dev(co0, 0, d_g.data_ptr(), stream=stream)), k4_bytes)
-    res["k4_fit_width_sums"] = entry(timed(lambda: plan.fit_width_sums_dev(co0, 0, vp, d_g.data_ptr(), d_w.data_ptr(), stream=stream)), k4_bytes)
+    res["k3_inverse"] = entry(timed(lambda k: plan.inverse_transform_dev(co(k), d_back.data_ptr(), stream=stream)), alg_bytes)
+    assert torch.equal(d_back, d_px[(slots - 1) % slots]), "K3(K1(x)) != x"  # the last launch inverted slot slots - 1: the lossless round trip
+    res["k4_fit_value_sums"] = entry(timed(lambda k: plan.fit_value_sums_dev(co(k), 0, d_g.data_ptr(), stream=stream)), k4_bytes)
+    res["k4_fit_width_sums"] = entry(timed(lambda k: plan.fit_width_sums_dev(co(k), 0, vp, d_g.data_ptr(), d_w.data_ptr(), stream=stream)), k4_bytes)
     # the device part of FRIEncoder::encode for one image, everything in HBM, nothing but enqueues (fri_hip_encode_image_batch_dev): with the
     # parameters given (K1 -> K2) and with the fit (K1 -> value sums + solves -> width sums + solves -> K2: four launches, each sums kernel solves in its tail)
     d_par.copy_(torch.from_numpy(np.stack([vp, wp]).reshape(-1)))
-    given = timed(lambda: plan.encode_image_batch_dev(1, px0, pstride, d_par.data_ptr(), co0, cstride, d_b.data_ptr(), d_p.data_ptr(), plane, d_h.data_ptr(), d_o.data_ptr(),
-                                                      fit=False, stream=stream))
+    given = timed(lambda k: plan.encode_image_batch_dev(1, px(k), pstride, d_par.data_ptr(), co(k), cstride, d_b.data_ptr(), d_p.data_ptr(), plane, d_h.data_ptr(), d_o.data_ptr(),
+                                                        fit=False, stream=stream))
     res["chain_k1_k2_given_params"] = entry(given, alg_bytes + k2_bytes)
-    fit = timed(lambda: plan.encode_image_batch_dev(1, px0, pstride, d_par.data_ptr(), co0, cstride, d_b.data_ptr(), d_p.data_ptr(), plane, d_h.data_ptr(), d_o.data_ptr(),
-                                                    fit=True, stream=stream))
+    fit = timed(lambda k: plan.encode_image_batch_dev(1, px(k), pstride, d_par.data_ptr(), co(k), cstride, d_b.data_ptr(), d_p.data_ptr(), plane, d_h.data_ptr(), d_o.data_ptr(),
+                                                      fit=True, stream=stream))
     res["chain_with_fit"] = entry(fit, alg_bytes + k2_bytes + 2 * k4_bytes)
     # ... and all the way to the emitter's input (fri_hip_encode_symbols_batch_dev): the scan writes one halfword per node instead of bucket + prediction,
     # the gather kernel (K5) puts them in the reference's stream order: 2 bytes per symbol is all that has to leave the device
@@ -181,41 +190,28 @@ def extras(plan, ctx, torch, np, px0, co0, pstride, cstride, slots, alg_bytes, s
     d_sym = torch.empty(n_sym, dtype=torch.uint16, device="cuda")
     k2w_bytes = plane * (4 + 2) + 10 * 1024 * 4
     k5_bytes = n_sym * (4 + 2 + 2)  # order + halfword gathered + halfword written
-    sym = timed(lambda: plan.encode_symbols_batch_dev(1, px0, pstride, None, False, d_par.data_ptr(), co0, cstride, d_words.data_ptr(), plane, d_sym.data_ptr(), n_sym,
-                                                      d_h.data_ptr(), d_o.data_ptr(), stream=stream))
+    d_par.copy_(torch.from_numpy(np.stack([vp, wp]).reshape(-1)))
+    sym = timed(lambda k: plan.encode_symbols_batch_dev(1, px(k), pstride, None, False, d_par.data_ptr(), co(k), cstride, d_words.data_ptr(), plane, d_sym.data_ptr(), n_sym,
+                                                        d_h.data_ptr(), d_o.data_ptr(), stream=stream))
     res["chain_to_symbol_stream_given_params"] = entry(sym, alg_bytes + k2w_bytes + k5_bytes)
     res["k5_symbol_gather"] = entry(sym - given, k5_bytes)
     res["k5_symbol_gather"]["note"] = "difference of the two chains above (the scan's halfword form is ~1.5 us faster than its array form, so this slightly understates K5)"
     del d_words, d_sym
     # K1 on RGB, the colour space libfri really encodes (wavelet_transform.rs:191, 415-416)
     plan3 = frave_amd.Plan(ctx, W, H, 3)
-    n3 = 6  # rotating slots: 300 MB of pixels, more than the 256 MiB Infinity Cache holds (two slots would be re-read from it: 51.7 instead of ~54 us)
+    n3 = 12  # rotating slots: 604 MB of pixels (6 slots: 302 MB, part of which still came out of the 256 MiB Infinity Cache: 52.8 against 53.7 us)
     d_px3 = torch.randint(0, 256, (n3, plan3.pixel_bytes), dtype=torch.uint8, device="cuda")
     d_co3 = torch.empty((n3, plan3.coef_count), dtype=torch.int32, device="cuda")
-    it = [0]
-
-    def k1_rgb():
-        k = it[0] % n3
-        it[0] += 1
-        plan3.transform_quant_dev(d_px3[k].data_ptr(), d_co3[k].data_ptr(), stream=stream)
-
-    for _ in range(60):  # this plan's first launches: tables and buffers are cold, and 30 launches alone measured 58 us where the steady state is 54
-        k1_rgb()
-    res["k1_rgb"] = entry(timed(k1_rgb, reps=120), plan3.pixel_bytes + plan3.coef_count * 4)
+    # through the native loop like the headline (a Python call per launch leaves host gaps between 50-us kernels: 57.5-59.2 against 55.3 us in round 3)
+    rgb = lambda n: plan3.time_transform_quant_dev(n3, d_px3.data_ptr(), plan3.pixel_bytes, d_co3.data_ptr(), plan3.coef_count, n, stream=stream)
+    rgb(5 * n3)  # this plan's first launches: tables and buffers are cold
+    res["k1_rgb"] = entry(rgb(10 * n3), plan3.pixel_bytes + plan3.coef_count * 4)
     del d_px3, d_co3
     plan3.close()
-    # K1 with many images per launch (the batch entry point; BASELINE config 4 runs like this). Two figures that must not be confused: a launch
-    # over the bench's own 8 slots re-reads the same 134 MB of pixels every repetition - they stay in the 256 MiB Infinity Cache, so its rate is
-    # cache-assisted - and a launch over 32 DISTINCT images (2.7 GB: every byte comes from and goes to HBM), which is the HBM-bound batch figure.
-    us8 = timed(lambda: plan.transform_quant_dev(px0, co0, stream=stream, n_images=slots, pixel_stride=pstride, coef_stride=cstride)) / slots
-    n32 = 32
-    d_px32 = torch.randint(0, 256, (n32, plan.pixel_bytes), dtype=torch.uint8, device="cuda")
-    d_co32 = torch.empty((n32, plan.coef_count), dtype=torch.int32, device="cuda")
-    us32 = timed(lambda: plan.transform_quant_dev(d_px32.data_ptr(), d_co32.data_ptr(), stream=stream, n_images=n32, pixel_stride=plan.pixel_bytes, coef_stride=plan.coef_count),
-                 reps=6) / n32
-    del d_px32, d_co32
-    res["k1_batch_launch"] = {"per_image_32_distinct_images": entry(us32, alg_bytes), "per_image_8_resident_slots": entry(us8, alg_bytes),
-                              "note": "32 distinct images per launch = HBM-bound; the 8-slot figure re-reads pixels that stay in the Infinity Cache and is NOT an HBM fraction"}
+    # K1 with many images per launch (the batch entry point; BASELINE config 4 runs like this), over the same slots: distinct images, every byte from and to HBM
+    nb = min(slots, 32)
+    usb = timed(lambda k: plan.transform_quant_dev(px0, co0, stream=stream, n_images=nb, pixel_stride=pstride, coef_stride=cstride), reps=4) / nb
+    res["k1_batch_launch"] = {f"per_image_{nb}_distinct_images": entry(usb, alg_bytes), "note": f"one launch over {nb} distinct images ({nb * alg_bytes / 1e9:.1f} GB): HBM-bound like the headline"}
     if full:
         res["encode_pcie_bytes_per_image"] = {"host_to_device": plan.pixel_bytes, "device_to_host": plane * (4 + 1 + 4) + 10 * 1024 * 4 + 8}
     return res
@@ -226,7 +222,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)  # on top of the untimed spin-up, see SPIN_UP_LAUNCHES
-    ap.add_argument("--slots", type=int, default=8, help="distinct image/coefficient buffer pairs the steps rotate over")
+    ap.add_argument("--slots", type=int, default=24, help="distinct image/coefficient buffer pairs the steps rotate over (>= 24: neither pixels nor coefficients can come from the 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="leave the event-timed figures of K2 / K3 / K4 / K1-RGB / the chain out of the line")
     ap.add_argument("--extras", action="store_true", help="(kept for older command lines: the extras are in the default line now; adds the PCIe byte counts)")
@@ -354,7 +350,7 @@ def main():
     # period of back-to-back launches between two HIP events on the launch stream, with its fraction of the 8 TB/s roofline for the
     # algorithmic bytes of SURVEY.md section 8d. ~40 ms of GPU time behind the timed region (rank 0 only); never part of `value`.
     if rank == 0 and not args.no_extras:
-        out["extras"] = extras(plan, ctx, torch, np, px0, co0, pstride, cstride, args.slots, alg_bytes, stream, full=args.extras)
+        out["extras"] = extras(plan, ctx, torch, np, d_px, d_co, args.slots, alg_bytes, stream, full=args.extras)
 
     if rank == 0:
         if cpu is not None:

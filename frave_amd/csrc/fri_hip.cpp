@@ -53,6 +53,13 @@ struct fri_hip_plan {
     fri_hip_ctx *ctx = nullptr;
     Geometry geo;
     DevicePlan dev;
+    // The inverse kernel walks tiles of its own (round 4): what suits the forward kernel's loads and stores (bands of 16 rows) is not what suits the inverse's
+    // write-out (bands of 32 for planes). geo_inv holds only the tiling (tiles, cell records, shares, write-out lists); dev_inv is dev with those swapped in.
+    // Host-only plans and plans created with FRI_HIP_INV_SHARED=1 (tuning) keep one tiling: inv_geo() == geo.
+    Geometry geo_inv;
+    bool own_inverse_tiling = false;
+    DevicePlan dev_inv;
+    const Geometry &inv_geo() const { return own_inverse_tiling ? geo_inv : geo; }
     std::vector<void *> owned; // device allocations backing dev.*
     // staging for the host-pointer entry points (lazy)
     uint8_t *d_pixels = nullptr;
@@ -373,7 +380,17 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
     tp.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
     tp.cells_per_wg = env_int("FRI_HIP_CELLS_PER_WG");
     tp.batch_share_tiles = env_int("FRI_HIP_BATCH_SHARE_TILES");
-    tp.strided_shares = env_int("FRI_HIP_STRIDED_SHARES") > 0;
+    // Interleaved shares (geometry.cpp): the resident workgroups work on one window sliding over the image. Default since round 4 (4096^2 from HBM: planes
+    // 20.3 -> 19.1 us, RGB 55.5 -> 51.9 us, the inverse 29.6 -> 27.8 / 86 -> 72 us); FRI_HIP_STRIDED_SHARES=0 (tuning) restores one contiguous run per share.
+    // Up to ~200 000 cells, that is: at 12000^2 and 16384^2 (282 K / 526 K cells, many short shares dispatched in order: the resident set slides already) the
+    // interleaving costs 6 % (150 -> 160 us, 270 -> 285 us), at 8192^2 (131 K) it still gains 7 % (80 -> 74 us).
+    const bool strided_env = env_str("FRI_HIP_STRIDED_SHARES") != nullptr;
+    tp.strided_shares = strided_env ? env_int("FRI_HIP_STRIDED_SHARES") > 0 : ctx != nullptr;
+    constexpr size_t kStridedMaxCells = 200000, kOwnInverseMaxCells = 400000;
+    if (!strided_env && (size_t)width * height / kCell >= kStridedMaxCells) tp.strided_shares = false; // (a cell per 512 pixels: spares the large plan a geometry pass)
+    // Band height of the forward tiles: 16 rows for planes and RGB (planes were 32 through round 3 - tuned while the bench's pixels came out of the Infinity
+    // Cache; from HBM 16 with interleaved shares is 3-5 % faster at 4096^2 and 15 % at 6000 x 4000). The inverse kernel keeps 32 for planes (below).
+    if (tp.band_rows <= 0 && ctx) tp.band_rows = 16;
     // LDS budget of one forward tile buffer: 4 chunks of 16 bytes per thread for planes (the tuned variant), 6 for RGB
     tp.tile_buffer_bytes = (channels == 1 ? 4 : 6) * 256 * 16;
     if (env_int("FRI_HIP_TILE_BYTES") > 0) tp.tile_buffer_bytes = env_int("FRI_HIP_TILE_BYTES");
@@ -383,7 +400,8 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
     // RGB tiles need ~47 KB, so three. One share per resident workgroup, sized by dispatch rank.
     auto set_ranks = [&](int ranks) {
         tp.ranks = ranks;
-        static const float w4[4] = {1.3f, 1.1f, 0.9f, 0.7f}, w3[4] = {1.3f, 1.1f, 0.6f, 0.f}, w2[4] = {1.15f, 0.85f, 0.f, 0.f}, w1[4] = {1.f, 0.f, 0.f, 0.f};
+        // (three ranks = RGB: 1.3 / 1.1 / 0.6 through round 3; with interleaved shares and all bytes from HBM 1.2 / 1.0 / 0.8 is 2 % faster: 51.9 -> 50.6 us)
+        static const float w4[4] = {1.3f, 1.1f, 0.9f, 0.7f}, w3[4] = {1.2f, 1.0f, 0.8f, 0.f}, w2[4] = {1.15f, 0.85f, 0.f, 0.f}, w1[4] = {1.f, 0.f, 0.f, 0.f};
         const float *w = ranks >= 4 ? w4 : ranks == 3 ? w3 : ranks == 2 ? w2 : w1;
         for (int i = 0; i < 4; i++) tp.rank_weight[i] = ctx ? w[i] : 0.f;
         if (const char *e = env_str("FRI_HIP_RANK_WEIGHTS")) { // "w0,w1,w2,w3" (tuning; "1,1,1,1" = equal shares)
@@ -413,6 +431,10 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         probe.max_tile_cells = p->geo.max_tile_cells;
         probe.max_wg_tiles = std::max(p->geo.max_wg_tiles, p->geo.max_wg_tiles_batch);
         if (fwd_plan_fits(probe)) {
+            if (ctx && !strided_env && tp.strided_shares && p->geo.centers.size() >= kStridedMaxCells) { // large image: contiguous shares (see above)
+                tp.strided_shares = false;
+                continue;
+            }
             const int resident = (int)std::min<size_t>(4, (160 * 1024) / fwd_lds_bytes(probe));
             if (ctx && env_int("FRI_HIP_RANKS") <= 0 && resident >= 1 && resident < tp.ranks) { // e.g. RGB: three workgroups per CU
                 set_ranks(resident);
@@ -443,7 +465,42 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             }
         }
     }
-    build_inverse_lists(p->geo, (size_t)256 << 20); // 6 MB at 4096^2; beyond 256 MB the inverse kernel scans the rectangle instead
+    // (from ~400 000 cells on - 16384^2 - the inverse kernel is fastest on groups of the forward plan's short shares, as in round 3: 386 against 408 us)
+    if (ctx && (env_str("FRI_HIP_INV_SHARED") ? env_int("FRI_HIP_INV_SHARED") <= 0 : p->geo.centers.size() < kOwnInverseMaxCells)) {
+        // the inverse kernel's own tiling: one share per resident workgroup (it prefers that at every size), dispatch-rank weights, interleaved, bands of
+        // 32 rows for planes / 16 for RGB (FRI_HIP_INV_BAND_ROWS); shrunk like the forward tiles until the (shared) LDS rectangle budget holds
+        set_ranks(tp.ranks); // (the forward plan is built: tp is free; this restores the dispatch-rank weights a many-shares forward plan had flattened)
+        TilingParams ti = tp;
+        ti.band_rows = env_int("FRI_HIP_INV_BAND_ROWS") > 0 ? env_int("FRI_HIP_INV_BAND_ROWS") : (channels == 1 ? 32 : 16);
+        ti.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
+        ti.cells_per_wg = 0;
+        ti.target_wgs = ctx_wgs(ctx, tp.ranks);
+        ti.strided_shares = env_str("FRI_HIP_INV_STRIDED_SHARES") ? env_int("FRI_HIP_INV_STRIDED_SHARES") > 0 : (strided_env ? tp.strided_shares : true); // interleaved at every size it is built for
+        bool ok = false;
+        for (int guard = 0; guard < 64; guard++) {
+            if (!build_geometry(width, height, channels, ti, p->geo_inv).empty()) break;
+            DevicePlan probe;
+            probe.channels = (int32_t)channels;
+            probe.lds_pitch = p->geo_inv.lds_pitch;
+            probe.lds_rows = p->geo_inv.lds_rows;
+            probe.max_tile_cells = p->geo_inv.max_tile_cells;
+            probe.max_wg_tiles = std::max(p->geo_inv.max_wg_tiles, p->geo_inv.max_wg_tiles_batch);
+            if (fwd_plan_fits(probe)) {
+                ok = true;
+                break;
+            }
+            ti.band_rows = p->geo_inv.band_rows;
+            ti.cells_per_tile = p->geo_inv.cells_per_tile - 1;
+            if (ti.cells_per_tile < 1) {
+                ti.cells_per_tile = 1;
+                ti.band_rows = p->geo_inv.band_rows / 2;
+                if (ti.band_rows < 1) break;
+            }
+        }
+        p->own_inverse_tiling = ok;
+        if (!ok) p->geo_inv = Geometry{};
+    }
+    build_inverse_lists(p->own_inverse_tiling ? p->geo_inv : p->geo, (size_t)256 << 20); // 6 MB at 4096^2; beyond 256 MB the inverse kernel scans the rectangle instead
     if (ctx) {
         if (hipSetDevice(ctx->device) != hipSuccess) {
             delete p;
@@ -515,16 +572,19 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.k4_ablate = env_int("FRI_HIP_K4_ABLATE");
         if (const char *e = env_str("FRI_HIP_K4_OLDER_EIGHTHS")) d.k4_older_eighths = std::atoi(e);
         d.k3_scan = env_int("FRI_HIP_K3_SCAN") > 0;
-        if (!g.inv_lists.empty()) {
-            if ((rc = upload(p, g.inv_lists, d.inv_lists)) || (rc = upload(p, g.inv_quads, d.inv_quads)) || (rc = upload(p, g.inv_dwords, d.inv_dwords)) ||
-                (rc = upload(p, g.inv_parts, d.inv_parts))) {
-                fri_hip_plan_destroy(p);
-                return rc;
+        {
+            const Geometry &gi = p->inv_geo();
+            if (!gi.inv_lists.empty()) {
+                if ((rc = upload(p, gi.inv_lists, d.inv_lists)) || (rc = upload(p, gi.inv_quads, d.inv_quads)) || (rc = upload(p, gi.inv_dwords, d.inv_dwords)) ||
+                    (rc = upload(p, gi.inv_parts, d.inv_parts))) {
+                    fri_hip_plan_destroy(p);
+                    return rc;
+                }
+                d.inv_rect_bytes = gi.inv_rect_bytes;
             }
-            d.inv_rect_bytes = g.inv_rect_bytes;
         }
         if (env_int("FRI_HIP_TRACE") > 0) {
-            const size_t bytes = (size_t)d.n_wg * 16 * sizeof(unsigned long long);
+            const size_t bytes = (size_t)std::max<size_t>(d.n_wg, p->own_inverse_tiling ? p->geo_inv.wg_tiles.size() : 0) * 16 * sizeof(unsigned long long);
             void *t = nullptr;
             if (hipMalloc(&t, bytes) != hipSuccess || hipMemset(t, 0, bytes) != hipSuccess) {
                 fri_hip_plan_destroy(p);
@@ -538,6 +598,25 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         if (hipEventCreate(&p->ev_begin) != hipSuccess || hipEventCreate(&p->ev_end) != hipSuccess) {
             fri_hip_plan_destroy(p);
             return FRI_HIP_ERR_HIP;
+        }
+        // the inverse kernel's view of the plan: everything of `dev`, with its own tiles, cell records and shares swapped in
+        p->dev_inv = d;
+        if (p->own_inverse_tiling) {
+            Geometry &gi = p->geo_inv;
+            DevicePlan &di = p->dev_inv;
+            if ((rc = upload(p, gi.tiles, di.tiles)) || (rc = upload(p, gi.tile_cells, di.tile_cells)) || (rc = upload(p, gi.tile_meta, di.tile_meta)) || (rc = upload(p, gi.wg_tiles, di.wg_tiles))) {
+                fri_hip_plan_destroy(p);
+                return rc;
+            }
+            di.wg_tiles_batch = nullptr, di.n_wg_batch = 0;
+            di.n_tiles = (uint32_t)gi.tiles.size();
+            di.n_wg = (uint32_t)gi.wg_tiles.size() - 1;
+            di.lds_pitch = gi.lds_pitch, di.lds_rows = gi.lds_rows, di.cells_per_tile = gi.cells_per_tile, di.max_tile_cells = gi.max_tile_cells;
+            di.max_wg_tiles = gi.max_wg_tiles, di.max_wg_cells = gi.max_wg_cells;
+            di.inv_group = 1, di.inv_max_wg_tiles = gi.max_wg_tiles, di.inv_max_wg_cells = gi.max_wg_cells;
+            // what the plan keeps of geo_inv on the host: the tiling (fri_hip_plan_inverse_lists reads the list sizes); the lattice arrays are geo's
+            for (auto *v : {&gi.valid_mask}) std::vector<uint32_t>().swap(*v);
+            std::vector<int32_t>().swap(gi.nbr_cells), std::vector<int32_t>().swap(gi.pred_slots);
         }
     }
     *out = p;
@@ -587,7 +666,7 @@ int fri_hip_plan_assume_forward_coefficients(fri_hip_plan *p, int on) {
 
 int fri_hip_plan_set_dequantiser(fri_hip_plan *p, int mode) {
     if (!p || (mode != FRI_HIP_DEQUANT_REFERENCE && mode != FRI_HIP_DEQUANT_MULTIPLY)) return FRI_HIP_ERR_INVALID_ARGUMENT;
-    p->dev.k3_multiply = mode == FRI_HIP_DEQUANT_MULTIPLY;
+    p->dev.k3_multiply = p->dev_inv.k3_multiply = mode == FRI_HIP_DEQUANT_MULTIPLY;
     return FRI_HIP_OK;
 }
 
@@ -615,7 +694,7 @@ int fri_hip_plan_tiling(const fri_hip_plan *p, int32_t out[8]) {
 }
 int fri_hip_plan_inverse_lists(const fri_hip_plan *p, uint64_t out[5]) {
     if (!p || !out) return FRI_HIP_ERR_INVALID_ARGUMENT;
-    const Geometry &g = p->geo;
+    const Geometry &g = p->inv_geo();
     uint64_t bits = 0;
     for (uint32_t e : g.inv_parts) bits += (uint64_t)__builtin_popcount(e & 15u);
     out[0] = g.inv_lists.empty() ? 0 : 1;
@@ -1355,7 +1434,7 @@ int fri_hip_inverse_transform_batch_dev(fri_hip_plan *p, uint32_t n_images, cons
     if (n_images > 1 && (pixel_stride < fri_hip_plan_pixel_bytes(p) || coef_stride < fri_hip_plan_coef_count(p))) return FRI_HIP_ERR_INVALID_ARGUMENT;
     QMatrix q;
     if (int rc = check_q(qmatrix, q)) return rc;
-    HIP_TRY(p->ctx, launch_inverse_transform(p->dev, n_images, d_coefs, coef_stride, q, d_pixels, pixel_stride, (hipStream_t)stream));
+    HIP_TRY(p->ctx, launch_inverse_transform(p->dev_inv, n_images, d_coefs, coef_stride, q, d_pixels, pixel_stride, (hipStream_t)stream));
     return FRI_HIP_OK;
 }
 
