@@ -14,6 +14,13 @@
 
 #include "kernels.hpp"
 
+// The hand-written waits of these kernels (s_waitcnt vmcnt(0) in front of a hand-over ticket, counted lgkmcnt(6) behind d16 LDS gathers) rely on gfx9-class
+// counters - vmcnt covers stores and atomics without a return value, d16 loads write whole registers - and on gfx950's instruction set. Another target must
+// not compile them silently (the Makefile's ARCH can be overridden).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "frave_amd's kernels are written for gfx950 (MI355X): the hand-counted s_waitcnt sequences and DPP / permlane forms do not carry over to other targets"
+#endif
+
 namespace fri {
 namespace {
 

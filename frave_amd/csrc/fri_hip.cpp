@@ -563,7 +563,6 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             p->owned.push_back(j);
             d.junk = static_cast<uint8_t *>(j);
         }
-        d.k4_previous = env_int("FRI_HIP_K4_PREVIOUS") > 0;
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
         d.k2_ablate = env_int("FRI_HIP_K2_ABLATE");
@@ -1272,8 +1271,6 @@ int fri_hip_encode_image(fri_hip_plan *p, const uint8_t *pixels, const int32_t q
     if (prediction) HIP_TRY(c, hipMemcpy(prediction, p->d_prediction_all, C * plane * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(hist, p->d_hist_all, C * 10 * 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(n_out_of_alphabet, p->d_oob_all, C * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    for (size_t ch = 0; ch < C; ch++) // the scan met a coefficient its LDS image cannot hold although the forward kernel wrote them (unreachable for |q| >= 1; see the header)
-        if (n_out_of_alphabet[ch] == ~0ull) return FRI_HIP_ERR_OUT_OF_RANGE;
     return FRI_HIP_OK;
 }
 
@@ -1303,7 +1300,7 @@ int fri_hip_encode_image_batch(fri_hip_plan *p, uint32_t n_images, const uint8_t
         std::memcpy(n_out_of_alphabet[i], s.h_oob, C * sizeof(uint64_t));
         if (fit) std::memcpy(params[i], s.h_params, C * sizeof(PredictParams));
         for (size_t ch = 0; ch < C; ch++)
-            if ((fit && s.h_oob[C + ch]) || s.h_oob[ch] == ~0ull) first_error = first_error ? first_error : FRI_HIP_ERR_OUT_OF_RANGE;
+            if (fit && s.h_oob[C + ch]) first_error = first_error ? first_error : FRI_HIP_ERR_OUT_OF_RANGE; // (the fit's range count; the scan does not check what the forward kernel wrote)
         return FRI_HIP_OK;
     };
     for (Slot &s : p->slots) s.pending = -1;
@@ -1421,8 +1418,6 @@ int fri_hip_encode_image_symbols(fri_hip_plan *p, const uint8_t *pixels, const i
     HIP_TRY(c, hipMemcpy(symbols, p->d_symbols, C * n * sizeof(uint16_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(hist, p->d_hist_all, C * 10 * 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(n_out_of_alphabet, p->d_oob_all, C * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    for (size_t ch = 0; ch < C; ch++)
-        if (n_out_of_alphabet[ch] == ~0ull) return FRI_HIP_ERR_OUT_OF_RANGE;
     return FRI_HIP_OK;
 }
 

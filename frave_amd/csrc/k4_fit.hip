@@ -5,6 +5,12 @@
 namespace fri {
 namespace {
 
+__device__ __forceinline__ uint32_t f32_to_u32_sat(float x) { // Rust-style `as u32`: truncation toward zero, saturating, NaN -> 0 (what v_cvt_u32_f32 does)
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fit accumulators: the sums behind ContextModeler::optimize_parameters
 // (context_modeling.rs:79-213), so that the host solves two 6 x 6 systems per layer group instead of running an SVD over
@@ -31,7 +37,7 @@ struct FitArgs {
     unsigned long long *wtw;  // [3][21]   (MODE 1)
     double *wtr;              // [3][6]    (MODE 1)
     unsigned long long *out_range; // [n_planes] or NULL: waves that staged a Some coefficient outside [-256, 255] (the sums are then not to be trusted)
-    unsigned long long *acc;  // plan scratch, all zero between launches: [kFitAccInt] integer sums, [18] f64 bit patterns, then the ticket
+    unsigned long long *acc;  // plan scratch, all zero between launches: [kFitAccInt] integer sums, [18] fixed-point sums (W^T r), then the ticket
     // planes of a batch (grid.y): plane k reads coefs + k * coef_stride, takes its parameters from params[k] (NULL: pp), hands over through
     // acc + k * kFitAccWords and writes gram / wtw + k * 3 * NI, wtr + k * 18
     size_t coef_stride;
@@ -49,232 +55,6 @@ struct FitArgs {
 };
 constexpr int kFitAccInt = 3 * 28, kFitAccDbl = kFitAccInt, kFitAccTicket = kFitAccInt + 18, kFitAccRange = kFitAccTicket + 1;
 static_assert(kFitAccRange + 1 == (int)kFitAccWords, "fit accumulator layout");
-
-template <int MODE>
-__global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel(const FitArgs a0) {
-    constexpr int NI = MODE == 0 ? 28 : 21;
-    // This plane of the batch (grid.y). The view is a struct of scalars and ONE parameter set: a copy of the whole argument struct with
-    // its three parameter sets would be indexed dynamically and therefore live in scratch memory, and every argument access with it.
-    struct {
-        const int32_t *coefs;
-        unsigned long long *acc, *gram, *wtw, *out_range;
-        double *wtr;
-        const int32_t *pred_slots;
-        const uint32_t *pred_off, *valid_mask;
-        uint32_t n_tiles;
-        PredictParams pp;
-    } a;
-    {
-        const uint32_t plane = blockIdx.y;
-        a.coefs = a0.coefs + plane * a0.coef_stride;
-        a.acc = a0.acc + (size_t)plane * kFitShards * kFitAccWords; // (this kernel uses the first of the plane's copies only)
-        a.gram = a0.gram ? a0.gram + (size_t)plane * 3 * NI : nullptr;
-        a.wtw = a0.wtw ? a0.wtw + (size_t)plane * 3 * NI : nullptr;
-        a.wtr = a0.wtr ? a0.wtr + (size_t)plane * 18 : nullptr;
-        a.out_range = a0.out_range ? a0.out_range + plane : nullptr;
-        a.pred_slots = a0.pred_slots, a.pred_off = a0.pred_off, a.valid_mask = a0.valid_mask, a.n_tiles = a0.n_tiles;
-        // static indices only: a dynamic index into the argument struct would keep all of it in scratch memory
-        if (a0.params)
-            a.pp = a0.params[plane];
-        else if (plane == 0)
-            a.pp = a0.pp3[0];
-        else if (plane == 1)
-            a.pp = a0.pp3[1];
-        else
-            a.pp = a0.pp3[2];
-    }
-    __shared__ __attribute__((aligned(16))) uint8_t s_cells[kPredSlots * kSlotStride];
-    __shared__ int32_t s_slot_cell[kPredSlots];
-    __shared__ int32_t s_slot_interior[kPredSlots];
-    __shared__ uint32_t s_flag, s_range;
-    __shared__ unsigned long long s_int[3][28];
-    __shared__ double s_dbl[3][6];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: slot, cell and the own-slot address become wave-uniform
-    if (tid < 3 * 28) (&s_int[0][0])[tid] = 0;
-    if (tid < 18) (&s_dbl[0][0])[tid] = 0.0;
-    if (tid == 0) s_range = 0;
-
-    const int g = lane < 32 ? 0 : lane < 48 ? 1 : 2;
-    const int p0 = lane < 32 ? 256 + lane : lane < 48 ? 128 + (lane - 32) : lane - 48;
-    const int pstep = lane < 32 ? 32 : 16;
-    // The neighbour offsets of a lane's 8 nodes live in LDS here (not in registers as in K2): together with 21-28 accumulators
-    // they would not fit 128 VGPRs, and this kernel is not on the critical path. The map is per lane, identical in all waves.
-    __shared__ uint32_t s_off[8][64][3];
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const u32x4 o = reinterpret_cast<const u32x4 *>(a.pred_off)[p0 + pstep * i];
-            s_off[i][lane][0] = o.x;
-            s_off[i][lane][1] = o.y;
-            s_off[i][lane][2] = o.z;
-        }
-    }
-    float vp[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) vp[k] = g == 0 ? a.pp.value[0][k] : g == 1 ? a.pp.value[1][k] : a.pp.value[2][k]; // selects, not a dynamic index
-
-    int acc[NI];
-    double dacc[6];
-#pragma unroll
-    for (int k = 0; k < NI; k++) acc[k] = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) dacc[k] = 0.0;
-    int cells_since_flush = 0;
-    auto flush = [&]() { // per-lane int32 sums -> workgroup int64 sums (sign-extended two's complement adds)
-#pragma unroll
-        for (int k = 0; k < NI; k++) {
-            atomicAdd(&s_int[g][k], (unsigned long long)(long long)acc[k]);
-            acc[k] = 0;
-        }
-        cells_since_flush = 0;
-    };
-
-    const PredTileWalk walk(a.n_tiles);
-    for (uint32_t tile = walk.first; tile < walk.end; tile += walk.step) {
-        __syncthreads();
-        if (tid < kPredSlots) {
-            const int raw = a.pred_slots[(size_t)tile * kPredSlots + tid];
-            s_slot_cell[tid] = pred_slot_cell(raw);
-            s_slot_interior[tid] = pred_slot_interior(raw) ? 1 : 0;
-        }
-        __syncthreads();
-        pred_stage_tile(a.coefs, s_slot_cell, s_cells, lane, wave, &s_range);
-        __syncthreads();
-        for (int r = wave; r < kPredBlock * kPredBlock; r += kPredWaves) {
-            const int slot = (1 + r / kPredBlock) * kPredSide + 1 + (r % kPredBlock);
-            const int cell = __builtin_amdgcn_readfirstlane(s_slot_cell[slot]);
-            if (cell < 0) continue;
-            const uint8_t *own = s_cells + slot * kSlotStride;
-            const bool boundary = __builtin_amdgcn_readfirstlane(s_slot_interior[slot]) == 0;
-#pragma unroll 1
-            for (int ip = 0; ip < 4; ip++) { // two nodes of the lane per step, packed as int16 pairs: one v_dot2 = two multiply-adds
-                const int pa = p0 + pstep * (2 * ip), pb = pa + pstep;
-                bool use_a = pa >= 2, use_b = true; // heap index 0 and 1 are coded by the LF predictor and are not rows of the fit
-                if (boundary) {
-                    use_a = use_a && ((a.valid_mask[(size_t)cell * 16 + (pa >> 5)] >> (pa & 31)) & 1u);
-                    use_b = ((a.valid_mask[(size_t)cell * 16 + (pb >> 5)] >> (pb & 31)) & 1u) != 0;
-                }
-                const uint32_t mask = (use_a ? 0x0000FFFFu : 0u) | (use_b ? 0xFFFF0000u : 0u); // a None row is all zeros in the reference (:109-134)
-                const uint32_t offa[3] = {s_off[2 * ip][lane][0], s_off[2 * ip][lane][1], s_off[2 * ip][lane][2]};
-                const uint32_t offb[3] = {s_off[2 * ip + 1][lane][0], s_off[2 * ip + 1][lane][1], s_off[2 * ip + 1][lane][2]};
-                int va[6], vb[6];
-                pred_gather(own, offa, va);
-                pred_gather(own, offb, vb);
-                const int value_a = *reinterpret_cast<const short *>(own + 2 * pa), value_b = *reinterpret_cast<const short *>(own + 2 * pb);
-                auto pack = [](int lo, int hi) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u)); };
-                auto masked = [&](s16x2 x) { return __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, x) & mask); };
-                if (MODE == 0) {
-                    s16x2 u[7];
-#pragma unroll
-                    for (int k = 0; k < 6; k++) u[k] = masked(pack(va[k], vb[k]));
-                    u[6] = masked(pack(value_a, value_b));
-                    int n = 0;
-#pragma unroll
-                    for (int r0 = 0; r0 < 7; r0++)
-#pragma unroll
-                        for (int c0 = r0; c0 < 7; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(u[r0], u[c0], acc[n], false);
-                } else {
-                    auto residual = [&](const int (&v)[6], int value) {
-                        float pf = __fmul_rn((float)v[0], vp[0]);
-#pragma unroll
-                        for (int k = 1; k < 6; k++) pf = __fadd_rn(pf, __fmul_rn((float)v[k], vp[k]));
-                        return (double)fabsf(__fsub_rn((float)value, pf));
-                    };
-                    const double rda = residual(va, value_a), rdb = residual(vb, value_b);
-                    auto absdiff = [&](int k0, int k1) { // |v[k0] - v[k1]| of both nodes: every Some coefficient is within [-255, 255]
-                        const s16x2 d = pack(va[k0], vb[k0]) - pack(va[k1], vb[k1]);
-                        return masked(__builtin_elementwise_max(d, -d));
-                    };
-                    const s16x2 w[6] = {masked(s16x2{1, 1}), absdiff(0, 3), absdiff(1, 2), absdiff(4, 5), absdiff(1, 5), absdiff(2, 4)};
-                    int n = 0;
-#pragma unroll
-                    for (int r0 = 0; r0 < 6; r0++)
-#pragma unroll
-                        for (int c0 = r0; c0 < 6; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(w[r0], w[c0], acc[n], false);
-#pragma unroll
-                    for (int k = 0; k < 6; k++) dacc[k] += (double)w[k].x * rda, dacc[k] += (double)w[k].y * rdb;
-                }
-            }
-            if (++cells_since_flush >= 1024) flush(); // 8 nodes x 255^2 x 1024 cells < 2^31
-        }
-    }
-    // Final reduction through LDS scratch instead of atomics: all 32 (16) lanes of a layer group would add to ONE LDS address,
-    // which costs ~0.7 us per instruction (see K2), 28 + 6 times per wave. The cell image is free now: every lane parks its sums
-    // at its own address, then one thread per (wave, sum, group) adds a group's lanes up - in a fixed order, so the f64 sums of
-    // MODE 1 no longer depend on the arrival order of atomics.
-    __syncthreads();
-    {
-        constexpr int NS = NI + (MODE == 1 ? 12 : 0); // int sums + 6 doubles as 12 words
-        int32_t *scr = reinterpret_cast<int32_t *>(s_cells); // [4 waves][NS][64] words at a time: the 36-slot image holds 37 440 B
-        static_assert(4 * NS * 64 * 4 <= kPredSlots * kSlotStride, "scratch fits the cell image");
-        for (int half = 0; half < 2; half++) {
-            const bool mine = (wave >> 2) == half;
-            const int w4 = wave & 3;
-            if (mine) {
-#pragma unroll
-                for (int k = 0; k < NI; k++) scr[(w4 * NS + k) * 64 + lane] = acc[k];
-                if (MODE == 1) {
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        const unsigned long long u = __builtin_bit_cast(unsigned long long, dacc[k]);
-                        scr[(w4 * NS + NI + 2 * k) * 64 + lane] = (int32_t)(uint32_t)u;
-                        scr[(w4 * NS + NI + 2 * k + 1) * 64 + lane] = (int32_t)(uint32_t)(u >> 32);
-                    }
-                }
-            }
-            __syncthreads();
-            for (int t = tid; t < 4 * NI * 3; t += kPredThreads) { // integer sums: (wave of this half, k, group)
-                const int ww = t / (NI * 3), k = (t / 3) % NI, gg = t % 3;
-                const int l0 = gg == 0 ? 0 : gg == 1 ? 32 : 48, l1 = gg == 0 ? 32 : gg == 1 ? 48 : 64;
-                long long sum = 0;
-                for (int l = l0; l < l1; l++) sum += scr[(ww * NS + k) * 64 + l];
-                atomicAdd(&s_int[gg][k], (unsigned long long)sum); // <= 8 adds per address in the whole kernel
-            }
-            if (MODE == 1) {
-                for (int t = tid; t < 4 * 6 * 3; t += kPredThreads) {
-                    const int ww = t / 18, k = (t / 3) % 6, gg = t % 3;
-                    const int l0 = gg == 0 ? 0 : gg == 1 ? 32 : 48, l1 = gg == 0 ? 32 : gg == 1 ? 48 : 64;
-                    double sum = 0.0;
-                    for (int l = l0; l < l1; l++) {
-                        const unsigned long long u = (unsigned long long)(uint32_t)scr[(ww * NS + NI + 2 * k) * 64 + l] |
-                                                     (unsigned long long)(uint32_t)scr[(ww * NS + NI + 2 * k + 1) * 64 + l] << 32;
-                        sum += __builtin_bit_cast(double, u);
-                    }
-                    atomicAdd(&s_dbl[gg][k], sum);
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // Hand-over like K2's: add into the plan accumulator, draw a ticket, the last workgroup moves the totals out and re-zeroes.
-    if (tid < 3 * NI) {
-        const int gg = tid / NI, k = tid % NI;
-        __hip_atomic_fetch_add(a.acc + tid, s_int[gg][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (MODE == 1 && tid < 18) __hip_atomic_fetch_add(reinterpret_cast<double *>(a.acc + kFitAccDbl) + tid, (&s_dbl[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 0 && s_range) __hip_atomic_fetch_add(a.acc + kFitAccRange, (unsigned long long)s_range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    wait_for_own_memory_ops_then_barrier(); // every wave has waited for its adds before the ticket is drawn
-    if (tid == 0) s_flag = __hip_atomic_fetch_add(a.acc + kFitAccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (s_flag == 0) return;
-    if (tid < 3 * NI) {
-        (MODE == 0 ? a.gram : a.wtw)[tid] = __hip_atomic_load(a.acc + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.acc + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (MODE == 1 && tid < 18) {
-        const unsigned long long u = __hip_atomic_load(a.acc + kFitAccDbl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.wtr[tid] = __builtin_bit_cast(double, u);
-        __hip_atomic_store(a.acc + kFitAccDbl + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (tid == 0) {
-        const unsigned long long r = __hip_atomic_exchange(a.acc + kFitAccRange, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.out_range) *a.out_range = r;
-        __hip_atomic_store(a.acc + kFitAccTicket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 2: the same sums with a third of the instructions. What the kernel above spends per pair of nodes: 14 sign-extending LDS
@@ -464,6 +244,20 @@ __device__ __forceinline__ void fit2_wave_sums(int (&acc)[28], int group, int la
     }
 }
 
+// W^T r (the width fit's right-hand side) is a sum of f32 values: per (tile, lane) the products feature x residual of the lane's sixteen nodes in that tile,
+// added in f32 in a fixed order - the reference's whole fit is f32 (context_modeling.rs:144-173). From there on the sum is INTEGER: every such f32 value
+// (>= 0, < 2^24: features <= 511, residuals of fitted parameters <= ~1024, sixteen of them) becomes a 64-bit fixed-point number with kFitFixBits fraction bits
+// by a function of the value alone (truncation below 2^-20: < 1e-6 per value), and integer adds commute. So the total does not depend on which workgroup walks which tile, on how many planes a launch
+// holds or on who finishes when: the same bits from every entry point and every run, hence the same f32 parameters, buckets and bytes. (Rounds 1-3 added
+// doubles in arrival order) A value of 2^24 or more - parameters from nowhere - saturates.
+constexpr int kFitFixBits = 20; // a plane's total stays below 2^63 up to sums of 8.8e12 (a 16384^2 noise plane: ~1.6e12)
+__device__ __forceinline__ unsigned long long fit_f32_to_fixed(float v) {
+    const float t = __builtin_truncf(v);                         // v >= 0
+    const uint32_t hi = f32_to_u32_sat(t);                       // saturating (v_cvt_u32_f32): NaN -> 0
+    const uint32_t lo = f32_to_u32_sat((v - t) * (float)(1u << kFitFixBits)); // exact difference, exact scaling, truncation below 2^-20 (only values < 16 have such bits)
+    return ((unsigned long long)hi << kFitFixBits) + lo;
+}
+
 // One layer group's solve at the end of the sums kernel. A function of its own, not inlined: as part of the kernel's body its ~90 registers' worth of f64
 // temporaries pushed the tile loop of the width pass (122 registers of 128) into spilling.
 template <int MODE>
@@ -503,12 +297,13 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     __shared__ int32_t s_slot_interior[2][kPredSlots];
     __shared__ uint32_t s_flag, s_range;
     __shared__ unsigned long long s_int[3][28];
-    __shared__ double s_dbl[3][6];
+    __shared__ unsigned long long s_fix[3][6]; // W^T r in fixed point (kFitFixBits fraction bits): integer adds commute, so the sums do not depend on who arrives when
+    __shared__ double s_dbl[3][6];              // (the totals, for the solve in the tail)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg = wave & 3, half = wave >> 2;
     if (tid < 3 * 28) (&s_int[0][0])[tid] = 0;
-    if (tid < 18) (&s_dbl[0][0])[tid] = 0.0;
+    if (tid < 18) (&s_fix[0][0])[tid] = 0ull;
     if (tid == 0) s_range = 0;
     trace_stamp(a0.trace, blockIdx.x, 0, tid);
 
@@ -537,11 +332,11 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
 #pragma unroll
     for (int k = 0; k < 6; k++) vp[k] = group == 0 ? pp.value[0][k] : group == 1 ? pp.value[1][k] : pp.value[2][k]; // selects, not a dynamic index
     int acc[28];
-    double dacc[6];
+    unsigned long long fx[6]; // W^T r of this lane, fixed point (kFitFixBits fraction bits)
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) dacc[k] = 0.0;
+    for (int k = 0; k < 6; k++) fx[k] = 0ull;
     int tiles_since_flush = 0, trace_it = 0;
     // the thread's two halo values per tile; entries >= 1024 - 122 of the list stage into the unused corner slot, where two of them may meet: harmless
     const uint32_t halo_e0 = a0.halo_list[tid], halo_e1 = a0.halo_list[tid + kPredThreads];
@@ -598,7 +393,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             fit2_halo_commit(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e1);                                                                     \
         }                                                                                                                                        \
         if (MODE == 1) {                                                                                                                         \
-            _Pragma("unroll") for (int k = 0; k < 6; k++) dacc[k] += (double)facc[k];                                                            \
+            _Pragma("unroll") for (int k = 0; k < 6; k++) fx[k] += fit_f32_to_fixed(facc[k]);                                                    \
         }                                                                                                                                        \
         if (++tiles_since_flush >= 16) { /* 16 nodes x 256^2 x 2 per tile and lane: a row of 16 lanes stays below 2^31 for 16 tiles */            \
             fit2_wave_sums<NI>(acc, group, lane, s_int);                                                                                         \
@@ -641,10 +436,10 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     if (MODE == 1) {
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            double v = dacc[k];
+            unsigned long long v = fx[k];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if (lane == 0) atomicAdd(&s_dbl[group][k], v);
+            if (lane == 0) atomicAdd(&s_fix[group][k], v);
         }
     }
     __syncthreads();
@@ -654,7 +449,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         const int gg = tid / NI, k = tid % NI;
         __hip_atomic_fetch_add(accs + tid, s_int[gg][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (MODE == 1 && tid < 18) __hip_atomic_fetch_add(reinterpret_cast<double *>(accs + kFitAccDbl) + tid, (&s_dbl[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (MODE == 1 && tid < 18) __hip_atomic_fetch_add(accs + kFitAccDbl + tid, (&s_fix[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0 && s_range) __hip_atomic_fetch_add(accp + kFitAccRange, (unsigned long long)s_range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wait_for_own_memory_ops_then_barrier(); // every wave has waited for its adds before the ticket is drawn
     if (tid == 0) s_flag = __hip_atomic_fetch_add(accp + kFitAccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
@@ -677,15 +472,15 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         s_int[i / NI][i % NI] = sum; // (for the solve below)
     }
     if (MODE == 1 && tid < 18) {
-        unsigned long long part[kFitShards];
-        double sum = 0.0;
+        unsigned long long part[kFitShards], total = 0;
 #pragma unroll
         for (uint32_t sh = 0; sh < kFitShards; sh++) part[sh] = __hip_atomic_load(accp + sh * kFitAccWords + kFitAccDbl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (uint32_t sh = 0; sh < kFitShards; sh++) {
-            sum += __builtin_bit_cast(double, part[sh]);
+            total += part[sh];
             __hip_atomic_store(accp + sh * kFitAccWords + kFitAccDbl + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        const double sum = (double)(long long)total * (1.0 / (double)(1ull << kFitFixBits));
         a0.wtr[(size_t)plane * 18 + tid] = sum;
         (&s_dbl[0][0])[tid] = sum;
     }
@@ -794,7 +589,7 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
     a.wtr = sums_dbl;
     a.out_range = out_of_range;
     if (solve) {
-        if (p.k4_previous || !solve->params) return hipErrorInvalidValue;
+        if (!solve->params) return hipErrorInvalidValue;
         a.solve_params = solve->params, a.host_params = solve->host_params, a.host_range = solve->host_range;
         for (int g = 0; g < 3; g++) a.rows[g] = solve->rows[g];
     }
@@ -809,14 +604,6 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
         if (blocks > p.n_pred_tiles) blocks = p.n_pred_tiles;
     }
     if (!blocks) blocks = 1;
-    if (p.k4_previous) { // FRI_HIP_TUNING=1 FRI_HIP_K4_PREVIOUS=1: round 1's kernel (A/B on one box)
-        (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
-        if (mode == 0)
-            hipLaunchKernelGGL(fit_accumulate_kernel<0>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
-        else
-            hipLaunchKernelGGL(fit_accumulate_kernel<1>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
-        return hipGetLastError();
-    }
     (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
     if (mode == 0)
         hipLaunchKernelGGL(fit_accumulate_kernel2<0>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);

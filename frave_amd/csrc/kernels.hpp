@@ -41,7 +41,6 @@ struct DevicePlan {
     uint32_t hist_blocks = 0;
     uint8_t *junk = nullptr;              // [pred_blocks][kPredJunkWaves][kPredJunkBytes]: output lines of block slots without a cell (pipelined K2)
     uint32_t pred_blocks = 0;             // workgroups of the pipelined K2: one 1024-thread workgroup per CU
-    bool k4_previous = false;             // tuning: round 1's fit kernel (A/B)
     uint32_t n_tiles = 0;
     uint32_t F = 0;
     int32_t width = 0, height = 0, channels = 0;
@@ -98,7 +97,7 @@ struct PredBatch {
 // K2. acc: n_planes x kPredAccWords words of hand-over bookkeeping, zero when allocated; serial: the number of this launch on `acc` (1, 2, ...: the caller counts; never 0).
 // hist [n_planes][10][1024] and n_oob [n_planes] are device memory the kernel clears itself and then adds into with device-scope atomics.
 // trust: what is known about the coefficients. kPredAnyInt32: nothing - the fast kernel checks what it stages and the exact int32 kernel behind it
-// redoes a plane whose values its LDS image cannot hold. kPredPromised: the caller promises the forward kernel's output (magnitudes <= 255,
+// redoes a plane whose values its LDS image cannot hold. kPredPromised: the caller promises the forward kernel's output (magnitudes <= 255 - the LDS image holds up to 256 -,
 // fri_hip_plan_assume_forward_coefficients): still checked, no exact kernel, a broken promise comes back as n_oob = ~0. kPredForwardOutput: this
 // library's forward kernel wrote them earlier in the same call: not checked.
 constexpr int kPredAnyInt32 = 0, kPredPromised = 1, kPredForwardOutput = 2;

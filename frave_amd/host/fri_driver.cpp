@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "libfri.hpp"
@@ -129,10 +130,24 @@ static bool has_suffix(const char *path, const char *suffix) {
     return n >= m && std::strcmp(path + n - m, suffix) == 0;
 }
 
+// `encode` / `encode-file`: the .frv comes from the symbol stream route (FRIEncoder::encode_bytes_streamed: the emitter's gather on the device, 2 bytes per symbol
+// over PCIe) - the default since round 4. Self-checks: the array route (stage functions one by one, 9 bytes per node over PCIe, gather on the host) must give
+// the same bytes - it does bit for bit since the fit's W^T r sums are fixed-point integers (k4_fit.hip): both routes fit the same parameters - ; the container
+// parses and every symbol decodes; FRIDecoder::decode returns the input.
 static int encode_image_to_file(std::vector<uint8_t> img, uint32_t w, uint32_t h, uint32_t c, const libfri::EncoderOpts &opts, const char *out_path) {
     const libfri::ColorSpace cs = c == 1 ? libfri::ColorSpace::Luma : libfri::ColorSpace::RGB;
-    libfri::FRIEncoder encoder(opts);
     auto t0 = std::chrono::steady_clock::now();
+    libfri::FRIEncoder streamed_encoder(opts);
+    auto streamed = streamed_encoder.encode_bytes_streamed(img, h, w, cs);
+    const double t_streamed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!streamed.ok) {
+        std::fprintf(stderr, "%s\n", streamed.error.c_str());
+        return 1;
+    }
+    const std::vector<uint8_t> &bytes = streamed.value;
+    // the array route
+    libfri::FRIEncoder encoder(opts);
+    t0 = std::chrono::steady_clock::now();
     auto st = encoder.encode(img, h, w, cs);
     if (!st.ok) {
         std::fprintf(stderr, "%s\n", st.error.c_str());
@@ -145,18 +160,13 @@ static int encode_image_to_file(std::vector<uint8_t> img, uint32_t w, uint32_t h
         std::fprintf(stderr, "%s\n", comp.error.c_str());
         return 1;
     }
-    const std::vector<uint8_t> bytes = libfri::stages::serialize::encode(comp.value);
+    const bool same = libfri::stages::serialize::encode(comp.value) == bytes;
     const double t_host = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    // once more: what every further image of this size costs (the symbol order is geometry and stays cached); the bytes must not change
-    t0 = std::chrono::steady_clock::now();
-    auto comp2 = libfri::stages::entropy_coding::encode(st.value.image, st.value.contexts, encoder.opts());
-    const bool same_again = comp2.ok && libfri::stages::serialize::encode(comp2.value) == bytes;
-    const double t_host2 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (!same_again) {
-        std::fprintf(stderr, "self-check failed: a second emit of the same image gives different bytes\n");
+    if (!same) {
+        std::fprintf(stderr, "self-check failed: the array route gives different bytes\n");
         return 1;
     }
-    // self-check: parse the container, rebuild the models from it, decode every symbol
+    // parse the container, rebuild the models from it, decode every symbol
     libfri::emit::ParsedImage parsed;
     std::string err = libfri::emit::deserialize(bytes, parsed);
     const size_t plane = (size_t)st.value.image.num_cells * 512;
@@ -174,15 +184,6 @@ static int encode_image_to_file(std::vector<uint8_t> img, uint32_t w, uint32_t h
         std::fprintf(stderr, "self-check failed: %s\n", err.c_str());
         return 1;
     }
-    // the symbol stream route (the emitter's gather on the device, 2 bytes per symbol over PCIe) must give the same file
-    t0 = std::chrono::steady_clock::now();
-    libfri::FRIEncoder streamed_encoder(opts);
-    auto streamed = streamed_encoder.encode_bytes_streamed(img, h, w, cs);
-    const double t_streamed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (!streamed.ok || streamed.value != bytes) {
-        std::fprintf(stderr, "self-check failed: %s\n", streamed.ok ? "the symbol stream route gives different bytes" : streamed.error.c_str());
-        return 1;
-    }
     // and the whole way back like FRIDecoder::decode (decoder.rs:47-59): every context recomputed from the symbols decoded so far
     t0 = std::chrono::steady_clock::now();
     auto back = libfri::FRIDecoder().decode(bytes, opts);
@@ -198,8 +199,8 @@ static int encode_image_to_file(std::vector<uint8_t> img, uint32_t w, uint32_t h
         std::fprintf(stderr, "cannot write %s\n", out_path);
         return 1;
     }
-    std::printf("%ux%ux%u: %zu bytes, %.3f bits per pixel; device stages (incl. plan + PCIe) %.3f s, host emit %.3f s (first image of this size: builds the symbol order), %.3f s (every further image); symbol stream route end to end (plan, stream order, chain, emit) %.3f s: same bytes; decoded back in %.3f s: lossless\n", w, h, c,
-                bytes.size(), 8.0 * bytes.size() / ((double)w * h), t_dev, t_host, t_host2, t_streamed, t_dec);
+    std::printf("%ux%ux%u: %zu bytes, %.3f bits per pixel; symbol stream route end to end (context, plan, stream order, chain, emit) %.3f s; self-checks: array route, device stages (incl. plan + PCIe) %.3f s + host emit %.3f s: same bytes; decoded back in %.3f s: lossless\n", w, h, c,
+                bytes.size(), 8.0 * bytes.size() / ((double)w * h), t_streamed, t_dev, t_host, t_dec);
     return 0;
 }
 
@@ -251,7 +252,7 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (argc < 5) {
-        std::fprintf(stderr, "usage: %s roundtrip|encode|batch <width> <height> <channels> [n_images | out.frv]\n       %s encode-file <in.pgm|in.ppm|in.bmp> <out.frv>\n       %s decode-file <in.frv> <out.pgm|out.ppm|out.bmp>\n", argv[0], argv[0], argv[0]);
+        std::fprintf(stderr, "usage: %s roundtrip|encode|batch|batch-frv <width> <height> <channels> [n_images | out.frv]\n       %s encode-file <in.pgm|in.ppm|in.bmp> <out.frv>\n       %s decode-file <in.frv> <out.pgm|out.ppm|out.bmp>\n", argv[0], argv[0], argv[0]);
         return 2;
     }
     const std::string cmd = argv[1];
@@ -295,6 +296,71 @@ int main(int argc, char **argv) {
             for (uint32_t x = 0; x < w / 2; x++)
                 for (uint32_t k = 0; k < c; k++) img[((size_t)y * w + x) * c + k] = (uint8_t)((((x + 2 * y) >> 3) + (img[((size_t)y * w + x) * c + k] & 7)) & 0xFF);
         return encode_image_to_file(std::move(img), w, h, c, opts, argv[5]);
+    }
+    if (cmd == "batch-frv") { // n images -> n .frv byte strings, device chains and host emits pipelined (libfri::encode_batch_bytes)
+        const uint32_t n = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 16;
+        uint32_t gpus = 1, emitters = std::max(1u, std::thread::hardware_concurrency() / 4);
+        bool same_device = false;
+        for (int i = 6; i < argc; i++) {
+            if (std::string(argv[i]) == "--gpus" && i + 1 < argc) gpus = (uint32_t)std::atoi(argv[i + 1]);
+            if (std::string(argv[i]) == "--emitters" && i + 1 < argc) emitters = (uint32_t)std::atoi(argv[i + 1]);
+            if (std::string(argv[i]) == "--same-device") same_device = true; // every "GPU" is device 0: the pipeline's threading on a one-GPU box
+        }
+        if (!n || !gpus || gpus > 64 || !emitters || emitters > 256) {
+            std::fprintf(stderr, "usage: %s batch-frv <width> <height> <channels> <n_images> [--gpus N] [--emitters T] [--same-device]\n", argv[0]);
+            return 2;
+        }
+        std::vector<int> devices(gpus);
+        for (uint32_t d = 0; d < gpus; d++) devices[d] = same_device ? 0 : (int)d;
+        const uint32_t distinct = n < 4 ? n : 4;
+        std::vector<std::vector<uint8_t>> in(distinct);
+        for (uint32_t i = 0; i < distinct; i++) { // left half smooth, right half noise, as `encode`: every context is populated
+            in[i] = noise_image(w, h, c, i);
+            for (uint32_t y = 0; y < h; y++)
+                for (uint32_t x = 0; x < w / 2; x++)
+                    for (uint32_t k = 0; k < c; k++) in[i][((size_t)y * w + x) * c + k] = (uint8_t)((((x + 2 * y + 5 * i) >> 3) + (in[i][((size_t)y * w + x) * c + k] & 7)) & 0xFF);
+        }
+        std::vector<const uint8_t *> pin(n);
+        for (uint32_t i = 0; i < n; i++) pin[i] = in[i % distinct].data();
+        libfri::EncoderOpts fit_opts; // parameters fitted per image on the device
+        {   // warm-up: contexts, plans, stream order, pinned staging, the emitter's cached symbol order
+            std::vector<const uint8_t *> few(pin.begin(), pin.begin() + std::min<size_t>(n, gpus));
+            auto warm = libfri::encode_batch_bytes(few, h, w, cs, fit_opts, devices, emitters);
+            if (!warm.ok) {
+                std::fprintf(stderr, "%s\n", warm.error.c_str());
+                return 1;
+            }
+        }
+        libfri::BatchStats stats;
+        auto out = libfri::encode_batch_bytes(pin, h, w, cs, fit_opts, devices, emitters, &stats);
+        if (!out.ok) {
+            std::fprintf(stderr, "%s\n", out.error.c_str());
+            return 1;
+        }
+        size_t total = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            total += out.value[i].size();
+            if (i >= distinct && out.value[i] != out.value[i % distinct]) {
+                std::fprintf(stderr, "image %u: bytes differ from image %u (same input)\n", i, i % distinct);
+                return 1;
+            }
+        }
+        // one image through the single-image API, and back: the batch's bytes are FRIEncoder's, and they decode to the input
+        auto single = libfri::FRIEncoder(fit_opts).encode_bytes_streamed(in[0], h, w, cs);
+        if (!single.ok || single.value != out.value[0]) {
+            std::fprintf(stderr, "self-check failed: image 0 of the batch differs from FRIEncoder::encode_bytes_streamed\n");
+            return 1;
+        }
+        auto back = libfri::FRIDecoder().decode(out.value[0], fit_opts);
+        if (!back.ok || back.value.data != in[0]) {
+            std::fprintf(stderr, "self-check failed: image 0 does not decode to its input\n");
+            return 1;
+        }
+        std::printf("batch-frv %u x %ux%ux%u on %u device thread(s)%s + %u emitter thread(s): %.3f s = %.1f images/s = %.1f Mpixels/s pixels-to-.frv (PCIe and host rANS inclusive); "
+                    "summed over images: device calls %.3f s, host emits %.3f s; %.3f bits per pixel; image 0 = the single-image API's bytes, decodes losslessly\n",
+                    n, w, h, c, gpus, same_device ? " (all on device 0)" : "", emitters, stats.seconds, n / stats.seconds, (double)n * w * h / stats.seconds / 1e6, stats.device_seconds,
+                    stats.emit_seconds, 8.0 * total / ((double)n * w * h));
+        return 0;
     }
     if (cmd == "batch") {
         const uint32_t n = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 16;

@@ -1,7 +1,13 @@
 // libfri.cpp -- see libfri.hpp. Host glue over the C ABI; no compute here.
 #include "libfri.hpp"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <utility>
 
 namespace libfri {
@@ -315,6 +321,39 @@ Result<RasterImage> FRIDecoder::decode(const std::vector<uint8_t> &data, const E
     return decode(w.value, opts); // quantization::decode + wavelet_transform::decode: one kernel (fri_hip_inverse_transform)
 }
 
+namespace {
+// what the device hands the emitter for one image
+struct StreamedImage {
+    size_t index = 0;
+    std::vector<uint16_t> symbols; // [C][num_some]
+    std::vector<uint32_t> hist;    // [C][10][1024]
+    float vp[3][3][6], wp[3][3][6];
+};
+std::string set_plan_stream_order(fri_hip_plan *plan, Device &dev) {
+    const uint32_t F = fri_hip_plan_num_cells(plan);
+    std::vector<int32_t> centers((size_t)F * 2);
+    std::vector<uint32_t> mask((size_t)F * 16);
+    int rc = fri_hip_plan_centers(plan, centers.data());
+    if (rc == FRI_HIP_OK) rc = fri_hip_plan_valid_mask(plan, mask.data());
+    if (rc != FRI_HIP_OK) return dev.describe(rc);
+    const std::vector<uint32_t> order = emit::stream_order(*emit::shared_symbol_order(centers.data(), F), mask.data());
+    rc = fri_hip_plan_set_stream_order(plan, order.data(), order.size());
+    return rc == FRI_HIP_OK ? std::string() : dev.describe(rc);
+}
+std::string emit_streamed(const StreamedImage &im, uint32_t c, uint64_t n, uint32_t height, uint32_t width, ColorSpace colorspace, std::vector<uint8_t> &out) {
+    std::vector<emit::ChannelStream> streams;
+    const std::string e = emit::encode_channels_from_streams(c, im.symbols.data(), (size_t)n, im.hist.data(), streams);
+    if (!e.empty()) return e;
+    std::vector<emit::ChannelParams> params(c);
+    for (uint32_t ch = 0; ch < c; ch++)
+        for (int g = 0; g < 3; g++)
+            for (int k = 0; k < 6; k++) params[ch].value[g][k] = im.vp[ch][g][k], params[ch].width[g][k] = im.wp[ch][g][k];
+    const emit::ColorSpaceCode cs = colorspace == ColorSpace::Luma ? emit::kLuma : colorspace == ColorSpace::RGB ? emit::kRGB : emit::kYCbCr;
+    out = emit::serialize(height, width, cs, streams, params);
+    return std::string();
+}
+} // namespace
+
 // FRIEncoder::encode (encoder.rs:87-109) end to end through the symbol stream route: the device runs the stage chain AND the emitter's gather
 // (sort_lattice order, entropy_coding.rs:285-336), the host receives 2 bytes per symbol and runs the rANS loop and the serializer. Byte for byte
 // the .frv of encode_bytes below (tests/test_emit.py); 34 MB instead of 153 MB come down per 4096 x 4096 plane.
@@ -331,18 +370,8 @@ Result<std::vector<uint8_t>> FRIEncoder::encode_bytes_streamed(std::vector<uint8
     std::string err;
     fri_hip_plan *plan = dev.plan(width, height, c, err);
     if (!plan) return fail(err);
-    const uint32_t F = fri_hip_plan_num_cells(plan);
     const uint64_t n = fri_hip_plan_num_some(plan);
-    {   // the stream order: geometry only, once per plan (the plan is new here: Device lives for this call, as in encode())
-        std::vector<int32_t> centers((size_t)F * 2);
-        std::vector<uint32_t> mask((size_t)F * 16);
-        int rc = fri_hip_plan_centers(plan, centers.data());
-        if (rc == FRI_HIP_OK) rc = fri_hip_plan_valid_mask(plan, mask.data());
-        if (rc != FRI_HIP_OK) return fail(dev.describe(rc));
-        const std::vector<uint32_t> order = emit::stream_order(*emit::shared_symbol_order(centers.data(), F), mask.data());
-        rc = fri_hip_plan_set_stream_order(plan, order.data(), order.size());
-        if (rc != FRI_HIP_OK) return fail(dev.describe(rc));
-    }
+    if (const std::string e = set_plan_stream_order(plan, dev); !e.empty()) return fail(e); // geometry only, once per plan (the plan is new here: Device lives for this call, as in encode())
     std::vector<uint16_t> symbols((size_t)c * n);
     std::vector<uint32_t> hist((size_t)c * CONTEXT_AMOUNT * ALPHABET_SIZE);
     float vp[3][3][6], wp[3][3][6];
@@ -362,6 +391,117 @@ Result<std::vector<uint8_t>> FRIEncoder::encode_bytes_streamed(std::vector<uint8
             for (int k = 0; k < 6; k++) params[ch].value[g][k] = vp[ch][g][k], params[ch].width[g][k] = wp[ch][g][k];
     const emit::ColorSpaceCode cs = colorspace == ColorSpace::Luma ? emit::kLuma : colorspace == ColorSpace::RGB ? emit::kRGB : emit::kYCbCr;
     r.value = emit::serialize(height, width, cs, streams, params);
+    r.ok = true;
+    return r;
+}
+
+Result<std::vector<std::vector<uint8_t>>> encode_batch_bytes(const std::vector<const uint8_t *> &images, uint32_t height, uint32_t width, ColorSpace colorspace,
+                                                             const EncoderOpts &opts, const std::vector<int> &devices, unsigned emit_threads, BatchStats *stats) {
+    Result<std::vector<std::vector<uint8_t>>> r;
+    const size_t n_images = images.size();
+    const uint32_t c = num_channels(colorspace);
+    const uint32_t n_dev = (uint32_t)devices.size();
+    if (!n_dev || !emit_threads) {
+        r.error = "encode_batch_bytes: no device / no emitter thread";
+        return r;
+    }
+    r.value.assign(n_images, {});
+    std::mutex mu;
+    std::condition_variable have_work, have_room;
+    std::deque<StreamedImage> queue; // bounded: the device side runs at most a few images ahead of the emitters (a 4096^2 RGB stream set is 100 MB)
+    const size_t max_queued = 2 * (size_t)emit_threads + n_dev;
+    uint32_t producers_left = n_dev;
+    std::string first_error;
+    std::atomic<long long> dev_ns{0}, emit_ns{0};
+    auto fail = [&](const std::string &msg) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (first_error.empty()) first_error = msg;
+        have_work.notify_all(), have_room.notify_all();
+    };
+    const auto t_begin = std::chrono::steady_clock::now();
+    uint64_t n_some = 0;
+    std::vector<std::thread> producers, emitters;
+    for (uint32_t d = 0; d < n_dev; d++)
+        producers.emplace_back([&, d]() {
+            Device dev(devices[d]);
+            std::string err;
+            fri_hip_plan *plan = dev.ok() ? dev.plan(width, height, c, err) : nullptr;
+            if (!plan) err = dev.ok() ? err : dev.error();
+            if (plan) err = set_plan_stream_order(plan, dev);
+            if (!err.empty()) fail(err);
+            const uint64_t n = plan ? fri_hip_plan_num_some(plan) : 0;
+            if (d == 0) {
+                std::lock_guard<std::mutex> lk(mu);
+                n_some = n;
+            }
+            for (size_t k = 0; err.empty() && k < fri_hip_shard_size(n_images, d, n_dev); k++) {
+                const size_t i = fri_hip_shard_image(k, d, n_dev); // image i -> device i mod n_dev: the library's partition
+                StreamedImage im;
+                im.index = i;
+                im.symbols.resize((size_t)c * n);
+                im.hist.resize((size_t)c * CONTEXT_AMOUNT * ALPHABET_SIZE);
+                EncoderOpts o = opts;
+                stages::prediction::params_to_flat(o, c, im.vp, im.wp);
+                uint64_t oob[3] = {0, 0, 0};
+                const auto t0 = std::chrono::steady_clock::now();
+                const int rc = fri_hip_encode_image_symbols(plan, images[i], o.quantization_matrix.data(), o.fit_parameters ? 1 : 0, &im.vp[0][0][0], &im.wp[0][0][0], im.symbols.data(),
+                                                            im.hist.data(), oob);
+                dev_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                if (rc != FRI_HIP_OK) {
+                    fail(dev.describe(rc));
+                    break;
+                }
+                if (oob[0] | oob[1] | oob[2]) {
+                    fail("symbol outside the 1024-entry alphabet"); // the reference panics: bump_freq, entropy_coding.rs:99
+                    break;
+                }
+                std::unique_lock<std::mutex> lk(mu);
+                have_room.wait(lk, [&] { return queue.size() < max_queued || !first_error.empty(); });
+                if (!first_error.empty()) break;
+                queue.push_back(std::move(im));
+                have_work.notify_one();
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (--producers_left == 0) have_work.notify_all();
+        });
+    for (unsigned t = 0; t < emit_threads; t++)
+        emitters.emplace_back([&]() {
+            for (;;) {
+                StreamedImage im;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    have_work.wait(lk, [&] { return !queue.empty() || producers_left == 0 || !first_error.empty(); });
+                    if (!first_error.empty() || queue.empty()) return;
+                    im = std::move(queue.front());
+                    queue.pop_front();
+                    have_room.notify_one();
+                }
+                const auto t0 = std::chrono::steady_clock::now();
+                uint64_t n;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    n = n_some;
+                }
+                if (!n) n = im.symbols.size() / c;
+                const std::string e = emit_streamed(im, c, n, height, width, colorspace, r.value[im.index]);
+                emit_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                if (!e.empty()) {
+                    fail(e);
+                    return;
+                }
+            }
+        });
+    for (auto &t : producers) t.join();
+    for (auto &t : emitters) t.join();
+    if (stats) {
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        stats->device_seconds = dev_ns.load() * 1e-9, stats->emit_seconds = emit_ns.load() * 1e-9;
+    }
+    if (!first_error.empty()) {
+        r.error = "Failed to decode: " + first_error; // sic, encoder.rs:106
+        r.value.clear();
+        return r;
+    }
     r.ok = true;
     return r;
 }

@@ -166,6 +166,16 @@ class FRIEncoder { // encoder.rs:66-109
     EncoderOpts opts_;
 };
 
+// A batch of images of one shape to .frv bytes - the loop of crates/fri-cli/src/commands/bench.rs:15-120 around FRIEncoder::encode - as a pipeline: one thread
+// per device runs the stage chain up to the emitter's input (fri_hip_encode_image_symbols: K1 -> fit -> K2 -> K5, 17 MB up and 34 MB down per 4096^2 plane),
+// image i on device i mod n_devices (fri_hip_shard_image), while `emit_threads` host threads turn the streams of the images before it into rANS bytes
+// (entropy_coding.rs:266-352) and containers (serialize.rs:48-117). The bytes are those of FRIEncoder::encode_bytes, image for image.
+struct BatchStats {
+    double seconds = 0, device_seconds = 0, emit_seconds = 0; // wall clock of the batch; summed over images: the device calls / the host emits
+};
+Result<std::vector<std::vector<uint8_t>>> encode_batch_bytes(const std::vector<const uint8_t *> &images, uint32_t height, uint32_t width, ColorSpace colorspace,
+                                                             const EncoderOpts &opts, const std::vector<int> &devices, unsigned emit_threads, BatchStats *stats = nullptr);
+
 class FRIDecoder { // decoder.rs:44-59
   public:
     // the whole pipeline of decoder.rs:16-40: EncodedImage -> EntropyDecoding -> Dequantization -> WaveletTransform -> RawImage.

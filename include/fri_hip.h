@@ -159,7 +159,7 @@ int fri_hip_predict_histogram(fri_hip_plan *plan, const int32_t *coefs, uint32_t
                               const float width_params[3][6], uint8_t *bucket, int32_t *prediction, uint32_t *hist,
                               uint64_t *n_out_of_alphabet);
 /* The caller's promise that the coefficient arrays it hands to fri_hip_predict_histogram_dev / _batch_dev on this plan are outputs of
- * fri_hip_transform_quant* (every magnitude <= 256) - the situation of the replacement stage bodies, where prediction::encode always receives
+ * fri_hip_transform_quant* (every magnitude <= 255; the image holds up to 256) - the situation of the replacement stage bodies, where prediction::encode always receives
  * what wavelet_transform::encode + quantization::encode produced: with on != 0 the exact int32 kernel behind the fast one is not enqueued
  * (one launch less, ~5 us). A broken promise is detected, not obeyed: the plane reports *n_out_of_alphabet == UINT64_MAX and an all-zero
  * histogram. Default: off (any int32 array accepted). */
@@ -197,9 +197,11 @@ int fri_hip_fit_value_sums_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint3
 /* Width fit (optimize_width_prediction, :144-173) for given value parameters x: residual r = |f32(value) - A x| in f32
  * (left to right like nalgebra's gemv), features w = [1, |v0-v3|, |v1-v2|, |v4-v5|, |v1-v5|, |v2-v4|].
  * wtw[g][21] = upper triangle of sum w w^T over the Some rows (exact), wtr[g][6] = sum w r: the products of the (at most 16) nodes a lane
- * holds of one tile are summed in f32, everything beyond that in f64 - relative error <= 2^-20 of sum |w r|, far inside the reference's own
- * fit, whose matrices and SVD are f32 throughout (context_modeling.rs:144-173); the summation order across workgroups is not fixed, so the
- * last bits may vary between runs. rows[g] = height of the reference's matrix (F*256, F*128, F*128): its
+ * holds of one tile are summed in f32 in a fixed order, each such partial sum becomes a 64-bit fixed-point number (20 fraction bits) and everything
+ * beyond that is integer addition - far inside the reference's own fit, whose matrices and SVD are f32 throughout (context_modeling.rs:144-173), and
+ * REPRODUCIBLE: integer adds commute, so the sums (hence the fitted parameters, the buckets and the encoder's bytes) are the same bits in every
+ * run, from every entry point and for any number of planes per launch (through round 3 they were f64 atomics in arrival order). Valid while a
+ * plane's sum stays below 8.8e12 (a 16384 x 16384 noise plane: ~1.6e12). rows[g] = height of the reference's matrix (F*256, F*128, F*128): its
  * all-zero rows still carry the constant feature 1 with residual 0, so add rows[g] - wtw[g][0] to entry (0,0). */
 int fri_hip_fit_width_sums(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, const float value_params[3][6], int64_t wtw[3][21],
                            double wtr[3][6], uint64_t rows[3]);
@@ -239,16 +241,17 @@ int fri_hip_fit_params_batch_dev(fri_hip_plan *plan, uint32_t n_planes, const in
 /* ---- the device part of FRIEncoder::encode in one call ---------------------------------------------- */
 /* Replaces the stage chain of FRIEncoder::encode (encoder.rs:19-48) up to EncoderStage::EntropyEncoding for one image, all channels:
  * wavelet_transform::encode + quantization::encode (one kernel), then per channel ContextModeler::optimize_parameters
- * (prediction.rs:232-235; the sums on the device, the 6 x 6 solves on the host) and the scan loop of prediction::encode
+ * (prediction.rs:232-235; the sums and the 6 x 6 solves on the device) and the scan loop of prediction::encode
  * (:237-298) - with the coefficients staying in device memory between the stages, as the reference threads ONE WaveletImage through them.
  * fit != 0: the parameters are fitted and returned in value_params / width_params (float[channels][3][6] each); fit == 0: they are inputs.
  * Outputs: coefs [C][F][512], bucket / prediction [C][F][512] (may be NULL), hist [C][10][1024], n_out_of_alphabet [C].
  * The host form uploads the pixels once and downloads each output once. The device form enqueues the whole chain on `stream` (the fit's
  * 6 x 6 solves run on the device too) and returns without synchronising when fit == 0; with fit != 0 it returns once the fitted parameters have
  * arrived in value_params / width_params - the scan kernel is queued behind them and still running. One thread / one stream per plan at a time
- * for the fit forms (the parameters travel through plan-owned buffers). FRI_HIP_ERR_OUT_OF_RANGE from the host forms: see the fit entry points;
- * the device form reports a plane whose coefficients the scan kernel could not represent although the forward kernel wrote them (cannot
- * happen for quantisers of magnitude >= 1) as n_out_of_alphabet == UINT64_MAX. */
+ * for the fit forms (the parameters travel through plan-owned buffers). FRI_HIP_ERR_OUT_OF_RANGE from the host forms: see the fit entry points.
+ * Inside these chains the scan kernel does not check what it stages: the forward kernel of the same call wrote the coefficients, differences of 8-bit pixels
+ * divided by a quantiser of magnitude >= 1, i.e. magnitudes <= 255, which its 16-bit staging holds exactly (the UINT64_MAX report of
+ * fri_hip_plan_assume_forward_coefficients exists for coefficients the CALLER vouches for, not here). */
 int fri_hip_encode_image(fri_hip_plan *plan, const uint8_t *pixels, const int32_t qmatrix[32], int fit, float *value_params, float *width_params, int32_t *coefs,
                          uint8_t *bucket, int32_t *prediction, uint32_t *hist, uint64_t *n_out_of_alphabet);
 int fri_hip_encode_image_dev(fri_hip_plan *plan, const uint8_t *d_pixels, const int32_t qmatrix[32], int fit, float *value_params, float *width_params, int32_t *d_coefs,

@@ -135,3 +135,51 @@ def test_shard_functions_cover_the_batch_once():
             seen += ids
         assert sorted(seen) == list(range(n_images))
     assert L.fri_hip_shard_size(10, 4, 4) == 0 and L.fri_hip_shard_size(10, 0, 0) == 0
+
+
+@pytest.mark.gpu
+def test_two_device_threads_on_one_gpu(oracle):
+    """Multi([0, 0], ...): the same device twice. A one-GPU box cannot run image i -> GPU i mod N on N > 1 GPUs, but it can run everything else the N > 1 path is made
+    of: two host threads, two contexts, two plans, two sets of streams, pinned pools and accumulators working CONCURRENTLY (against one GPU), the partition
+    i mod 2 dealing the images to them. Every image of both halves against the oracle - coefficients for the transform path; buckets, predictions and
+    histograms (with the parameters the chain fitted) for the sharded encode."""
+    import frave_amd as fa
+    from tests.common import gen_image
+
+    w, h, c = 640, 360, 3
+    M = fa.Multi([0, 0], w, h, c)
+    assert M.num_devices == 2
+    imgs = [gen_image("noise" if i % 3 else "smooth", w, h, c, 70 + i) for i in range(10)]
+    for rep in range(2):  # (the second pass reuses the pinned pools and streams of the first)
+        outs = M.transform_quant(imgs)
+        coefs, par, bucket, pred, hist, oob = M.encode_image(imgs, fit=True)
+    L = fa.load_library()
+    some = L.fri_hip_plan_num_some(L.fri_hip_multi_plan(M._h, 1))
+    for i in range(len(imgs)):
+        Wv = oracle.Wavelet(imgs[i], h, w, c)
+        assert np.array_equal(outs[i], Wv.coefficients()), i
+        assert np.array_equal(coefs[i], Wv.coefficients()), i
+        Wv.quantize(np.ones(32, np.int32))
+        for ch in range(c):
+            wb, wpred, whist, woob = Wv.predict(ch, par[i][ch, 0], par[i][ch, 1])
+            assert int(hist[i][ch].sum()) + int(oob[i][ch]) == some
+            assert np.array_equal(bucket[i][ch], wb) and np.array_equal(pred[i][ch], wpred) and np.array_equal(hist[i][ch], whist) and int(oob[i][ch]) == woob, (i, ch)
+        Wv.close()
+    M.close()
+
+
+@pytest.mark.gpu
+def test_driver_batch_to_frv_bytes():
+    """fri_driver batch-frv: n images -> n .frv byte strings with the device chains (to the emitter's input) and the host rANS emits pipelined
+    (libfri::encode_batch_bytes) - one device thread, and two device threads on the one GPU (--same-device: the N > 1 threading without N GPUs). The driver
+    itself checks that equal inputs give equal bytes, that image 0 equals FRIEncoder::encode_bytes_streamed's output and that it decodes to its input."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    driver = os.path.join(root, "frave_amd", "host", "fri_driver")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "frave_amd", "host")])
+    for extra in ([], ["--gpus", "2", "--same-device"]):
+        out = subprocess.run([driver, "batch-frv", "640", "360", "3", "12", "--emitters", "3"] + extra, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr + out.stdout
+        assert "decodes losslessly" in out.stdout

@@ -267,6 +267,36 @@ def test_stream_route_reproduces_the_golden_files(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(129, 65, 1), (700, 90, 1), (100, 37, 3), (512, 512, 3), (640, 360, 1)])
+def test_device_symbol_stream_is_the_references_walk(shape):
+    """The device route to the emitter's input (fri_hip_encode_image_symbols: K1 -> K2 halfwords -> K5) against the reference's own loop, restated literally
+    (oracle/emit_oracle.stream_symbols: entropy_coding::encode, entropy_coding.rs:285-336, walking sort_lattice / scan_level, wavelet_transform.rs:505-705) over
+    the ORACLE's coefficients, buckets and predictions: symbol for symbol, bucket for bucket, in stream order. (test_symbol_stream_on_the_device checks the
+    device's stream against a gather of the device's own arrays; the order against the literal walk is otherwise a CPU-only test.)"""
+    import frave_amd
+
+    w, h, c = shape
+    img = _mixed_image(w, h, c, 21)
+    W = fri_oracle.Wavelet(img, h, w, c)
+    coefs = W.coefficients()
+    ctx = frave_amd.Context(0)
+    P = frave_amd.Plan(ctx, w, h, c)
+    P.set_stream_order()
+    vp = np.tile(np.asarray(KAT_VALUE_PARAMS, np.float32).reshape(1, 3, 6), (c, 1, 1))
+    wp = np.tile(np.asarray(KAT_WIDTH_PARAMS, np.float32).reshape(1, 3, 6), (c, 1, 1))
+    sym, _, _, hist, oob = P.encode_image_symbols(img, fit=False, value_params=vp, width_params=wp)
+    assert not oob.any()
+    for ch in range(c):
+        b, p, want_hist, want_oob = W.predict(ch, KAT_VALUE_PARAMS, KAT_WIDTH_PARAMS)
+        assert want_oob == 0 and np.array_equal(hist[ch], want_hist)
+        ref = emit_oracle.stream_symbols(W, ch, coefs[ch], b, p)  # [(symbol, bucket)] as the reference's loop feeds its coder
+        assert len(ref) == P.num_some
+        got = sym[ch]
+        assert list(zip((got & 1023).tolist(), (got >> 10).tolist())) == ref
+    P.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(129, 65, 1), (640, 360, 3), (4096, 4096, 1)])
 def test_symbol_stream_on_the_device(shape):
     """K5 (fri_hip_symbol_stream_batch_dev): the stream equals the gather of the device's own arrays in stream order, and the .frv made from it is the

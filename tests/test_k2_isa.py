@@ -39,3 +39,21 @@ def test_the_scan_finds_a_planted_hazard(tmp_path):
     bad.write_text("\n".join(lines))
     _, errors = tool.scan(str(bad))
     assert errors and "in flight" in errors[0]
+
+
+def test_the_scan_refuses_control_flow_under_a_gather_in_flight(tmp_path):
+    """The scan is linear: a branch or a label between the block that issues a gather and the block that waits for it must be reported, not followed."""
+    tool = _tool()
+    lines = open(tool.make_assembly()).read().splitlines()
+    import re
+
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and re.search(tool.KERNEL, l))
+    for i in range(start, len(lines)):
+        if "lgkmcnt(6)" in lines[i]:
+            end = next(j for j in range(i, len(lines)) if lines[j].strip().startswith(";;#ASMEND"))
+            lines.insert(end + 1, "\ts_cbranch_scc0 .LBB0_planted")
+            break
+    bad = tmp_path / "planted_branch.s"
+    bad.write_text("\n".join(lines))
+    _, errors = tool.scan(str(bad))
+    assert errors and "control flow" in errors[0]

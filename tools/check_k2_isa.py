@@ -11,6 +11,10 @@ product kernel's assembly linearly: registers in flight, any mention of them out
 The assembly is produced by frave_amd/csrc/Makefile with the very flags the object file is built with (FLAGS + EXTRA_k2_predict);
 the Makefile runs this scan before it links libfri_hip.so, and tests/test_k2_isa.py runs it in the CPU suite.
 
+The scan is linear, so it must not meet control flow while a gather is in flight: a label (a merge point: the state of the other predecessor is unknown) or a
+branch / end of program with a non-empty in-flight set is reported as an error rather than followed - the kernel keeps every gather block, the
+node arithmetic between two blocks included, in straight-line code.
+
     python tools/check_k2_isa.py                 # make the assembly (csrc/build/k2_predict.s), then scan it; exit code 0 = clean
     python tools/check_k2_isa.py <file.s>        # scan an existing assembly file
 """
@@ -21,7 +25,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "frave_amd", "csrc")
-KERNEL = "(predict_histogram_kernel3|fit_value_kernel3)"  # every kernel of the file with hand-pipelined gather blocks
+KERNEL = "(predict_histogram_kernel3)"  # every kernel of the file with hand-pipelined gather blocks
+MIN_BLOCKS = 32  # per instantiation: two roles x two cells x (1 + 4 + 1 + ...) blocks; fewer means the scan no longer matches the kernel
 
 
 def make_assembly():
@@ -48,6 +53,8 @@ def scan(asm):
     for start in [i for i, l in enumerate(lines) if re.match(r"^_ZN.*" + KERNEL + r".*:", l)]:  # every instantiation of the kernel templates
         end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
         b, e = scan_function(lines, start, end)
+        if b < MIN_BLOCKS:
+            e.append(f"{lines[start].split(':')[0][:90]}: only {b} gather blocks (expected >= {MIN_BLOCKS}): the scan no longer matches this instantiation")
         blocks += b
         errors += e
     return blocks, errors
@@ -85,6 +92,9 @@ def scan_function(lines, start, end):
                     in_flight |= issued
             i = j + 1
             continue
+        if in_flight and (re.match(r"^\.LBB\S*:", lines[i].strip()) or re.match(r"^(s_cbranch|s_branch|s_setpc|s_endpgm|s_call|s_swappc)", line)):
+            errors.append(f"line {i + 1}: `{lines[i].strip()[:60]}` - control flow while v{sorted(in_flight)} are in flight (the linear scan cannot follow it)")
+            in_flight = set()  # (reported once)
         if line and not line.startswith(".") and not line.endswith(":"):
             if line.startswith("s_waitcnt") and "lgkmcnt(0)" in line:
                 in_flight = set()
