@@ -517,6 +517,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         build_gather_tables(tab.data(), gather_off.data(), pair_pos.data(), heap_of_pos.data());
         std::vector<uint32_t> halo_list(1024);
         build_halo_list(tab.data(), pair_pos.data(), halo_list.data());
+        build_lf_deltas(tab.data(), d.lf_delta);
         if (halo_list[0] == 0xFFFFFFFFu) { // more halo values than threads: the neighbour table is not the one the kernel was laid out for
             fri_hip_plan_destroy(p);
             return FRI_HIP_ERR_INVALID_ARGUMENT;
@@ -565,6 +566,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         }
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
+        if (env_str("FRI_HIP_K1_CACHED_STORES")) d.k1_cached_stores = env_int("FRI_HIP_K1_CACHED_STORES") > 0 ? 1 : 0; // tuning: force plain (1) / nontemporal (0) coefficient stores everywhere
         d.k2_ablate = env_int("FRI_HIP_K2_ABLATE");
         if (const char *e = env_str("FRI_HIP_K1_BATCH_SHARES")) d.k1_batch_shares = std::atoi(e) != 0;
         d.k3_ablate = env_int("FRI_HIP_K3_ABLATE");
@@ -849,6 +851,14 @@ int fri_hip_multi_transform_quant(fri_hip_multi *m, uint32_t n_images, const uin
     return FRI_HIP_OK;
 }
 
+// In a chain that goes straight from the forward kernel to the scan (parameters given: no fit in between) the forward kernel writes its coefficients with
+// plain stores instead of nontemporal ones when the launch's coefficients fit the Infinity Cache comfortably: the scan then reads them from the cache instead of
+// HBM (4096^2: K1 +1.5 us, K2 -4 us: 63.5 -> 61.0 us per image). With the fit in between (two more passes over the plane) it does not pay (161 = 162 us), and
+// a forward kernel on its own is faster with nontemporal stores (18.7 against 20.3 us).
+static bool chain_wants_cached_coefficients(const fri_hip_plan *p, uint32_t n_images, int fit) {
+    return !fit && (size_t)n_images * fri_hip_plan_coef_count(p) * sizeof(int32_t) <= ((size_t)128 << 20);
+}
+
 /* ---- prediction + histogram ----------------------------------------------------------------- */
 static int predict_launch(fri_hip_plan *p, const PredBatch &b, uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist, uint64_t *d_oob, int trust,
                           hipStream_t stream) {
@@ -1129,7 +1139,7 @@ int fri_hip_encode_image_dev(fri_hip_plan *p, const uint8_t *d_pixels, const int
     if (int rc = check_q(qmatrix, q)) return rc;
     HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
     // wavelet_transform::encode + quantization::encode (encoder.rs:24-31): one kernel, all channels; the coefficients then stay where they are
-    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, 1, d_pixels, 0, d_coefs, 0, q, (hipStream_t)stream));
+    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, 1, d_pixels, 0, d_coefs, 0, q, (hipStream_t)stream, chain_wants_cached_coefficients(p, 1, fit)));
     // |coefficient| <= 255 for quantisers of magnitude >= 1, and the kernel above wrote every one of them: the scan need not look
     return predict_image_dev(p, d_coefs, fit, value_params, width_params, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, kPredForwardOutput, (hipStream_t)stream);
 }
@@ -1150,7 +1160,7 @@ int fri_hip_encode_image_batch_dev(fri_hip_plan *p, uint32_t n_images, const uin
     if (int rc = check_q(qmatrix, q)) return rc;
     HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, q, s));
+    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, q, s, chain_wants_cached_coefficients(p, n_images, fit)));
     PredBatch b;
     b.n_planes = n_images * C;
     b.coefs = d_coefs;
@@ -1179,7 +1189,7 @@ int fri_hip_encode_symbols_batch_dev(fri_hip_plan *p, uint32_t n_images, const u
     if (int rc = check_q(qmatrix, q)) return rc;
     HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, q, s));
+    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, q, s, chain_wants_cached_coefficients(p, n_images, fit)));
     PredBatch b;
     b.n_planes = n_images * C;
     b.coefs = d_coefs;

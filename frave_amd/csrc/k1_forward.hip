@@ -143,7 +143,7 @@ __device__ __forceinline__ int quant_one(int v, int heap_index, const FwdArgs &a
 
 // Unpacks one item (HALF = 0: low halves, 1: high halves), applies the None mask and the quantiser, and stores the
 // cell's 512 int32 coefficients as four fully coalesced store instructions (1 KiB + 512 B + 256 B + 256 B).
-template <int HALF, bool MASKED, bool QID>
+template <int HALF, bool MASKED, bool QID, bool NT>
 __device__ __forceinline__ void store_item(int32_t *__restrict__ coefs, uint32_t elem_off, int lane, const int (&res)[8], uint32_t valid,
                                            const FwdArgs &a) {
     int v[8];
@@ -164,10 +164,17 @@ __device__ __forceinline__ void store_item(int32_t *__restrict__ coefs, uint32_t
     // Streaming (nontemporal) stores: the coefficients are written once and not read back by this kernel. Regular stores leave
     // up to 32 MB of dirty lines in the eight L2s, which the end-of-kernel release then has to write back while nothing else
     // runs. A/B on one box, us per 4096^2 launch: plain 27.5, nt 22.0-23.6, sc1 26.0, sc0 sc1 25.5, sc0 sc1 nt 22.0-23.2.
-    __builtin_nontemporal_store(i32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<i32x4 *>(out + 256 + 4 * lane));
-    __builtin_nontemporal_store(i32x2{v[4], v[5]}, reinterpret_cast<i32x2 *>(out + 128 + 2 * lane));
-    __builtin_nontemporal_store(v[6], out + 64 + lane);
-    __builtin_nontemporal_store(v[7], out + lane);
+    if constexpr (NT) {
+        __builtin_nontemporal_store(i32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<i32x4 *>(out + 256 + 4 * lane));
+        __builtin_nontemporal_store(i32x2{v[4], v[5]}, reinterpret_cast<i32x2 *>(out + 128 + 2 * lane));
+        __builtin_nontemporal_store(v[6], out + 64 + lane);
+        __builtin_nontemporal_store(v[7], out + lane);
+    } else { // plain stores: the coefficients may stay in the L2 / the Infinity Cache for the kernels that read them next (see launch_fwd_transform_quant)
+        *reinterpret_cast<i32x4 *>(out + 256 + 4 * lane) = i32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<i32x2 *>(out + 128 + 2 * lane) = i32x2{v[4], v[5]};
+        out[64 + lane] = v[6];
+        out[lane] = v[7];
+    }
 }
 
 
@@ -346,7 +353,7 @@ __device__ __forceinline__ ItemAddr item_addr(const FwdArgs &a, const Tile &t, c
 // K1. grid = (workgroup shares, images), block = 256 (4 waves). Each workgroup walks the tiles of its share:
 // while tile i is being transformed out of one LDS buffer (and its coefficient stores drain), the pixel
 // rectangle of tile i+1 is already in flight from HBM/L2 into registers and is committed to the other buffer.
-template <int C, bool EDGE, bool FAST, int NCH, bool QID>
+template <int C, bool EDGE, bool FAST, int NCH, bool QID, bool NT>
 __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if (ablate_flags(a.ablate) & 8) return; // timing only: what dispatching the grid alone costs
@@ -488,11 +495,11 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
                 if (!go) go = (res[c][0] ^ res[c][1] ^ res[c][2] ^ res[c][3] ^ res[c][4] ^ res[c][5] ^ res[c][6] ^ res[c][7]) == 0x12345678; // keeps the arithmetic alive
                 if (go) {
                     if (__builtin_amdgcn_readfirstlane(valid[c] == 0xFFFFFFFFu ? 1 : 0) && __all(valid[c] == 0xFFFFFFFFu)) { // no None anywhere in the pair
-                        store_item<0, false, QID>(coefs, offA[c], lane, res[c], valid[c], a);
-                        if (itA + 1 < n_items) store_item<1, false, QID>(coefs, offB[c], lane, res[c], valid[c], a);
+                        store_item<0, false, QID, NT>(coefs, offA[c], lane, res[c], valid[c], a);
+                        if (itA + 1 < n_items) store_item<1, false, QID, NT>(coefs, offB[c], lane, res[c], valid[c], a);
                     } else {
-                        store_item<0, true, QID>(coefs, offA[c], lane, res[c], valid[c], a);
-                        if (itA + 1 < n_items) store_item<1, true, QID>(coefs, offB[c], lane, res[c], valid[c], a);
+                        store_item<0, true, QID, NT>(coefs, offA[c], lane, res[c], valid[c], a);
+                        if (itA + 1 < n_items) store_item<1, true, QID, NT>(coefs, offB[c], lane, res[c], valid[c], a);
                     }
                 }
             }
@@ -528,8 +535,9 @@ bool fwd_plan_fits(const DevicePlan &p) {
 }
 
 hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, const uint8_t *pixels, size_t pixel_stride, int32_t *coefs,
-                                      size_t coef_stride, const QMatrix &q, hipStream_t stream) {
+                                      size_t coef_stride, const QMatrix &q, hipStream_t stream, bool cached_stores) {
     if (!fwd_plan_fits(p)) return hipErrorInvalidConfiguration;
+    const bool plain = p.k1_cached_stores >= 0 ? p.k1_cached_stores > 0 : cached_stores;
     FwdArgs a{};
     a.pixels = pixels;
     a.pixel_stride = pixel_stride;
@@ -562,13 +570,15 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
     const bool fast = !edge && (((size_t)p.width * p.channels) & 15) == 0; // every image row starts at the same offset mod 16
     const bool small = fwd_chunks(p) <= 4 * (size_t)kFwdThreads;           // 4 chunks per thread suffice (the common, tuned case)
     void (*kern)(FwdArgs);
-#define FRI_PICK_Q(CH, E, FA, N) (a.q_identity ? fwd_transform_quant_kernel<CH, E, FA, N, true> : fwd_transform_quant_kernel<CH, E, FA, N, false>)
+#define FRI_PICK_T(CH, E, FA, N, QI) (plain ? fwd_transform_quant_kernel<CH, E, FA, N, QI, false> : fwd_transform_quant_kernel<CH, E, FA, N, QI, true>)
+#define FRI_PICK_Q(CH, E, FA, N) (a.q_identity ? FRI_PICK_T(CH, E, FA, N, true) : FRI_PICK_T(CH, E, FA, N, false))
 #define FRI_PICK_N(CH, E, FA) (small ? FRI_PICK_Q(CH, E, FA, 4) : FRI_PICK_Q(CH, E, FA, kMaxChunksPerThread))
 #define FRI_PICK(CH) (edge ? FRI_PICK_N(CH, true, false) : fast ? FRI_PICK_N(CH, false, true) : FRI_PICK_N(CH, false, false))
     kern = p.channels == 1 ? FRI_PICK(1) : FRI_PICK(3);
 #undef FRI_PICK
 #undef FRI_PICK_N
 #undef FRI_PICK_Q
+#undef FRI_PICK_T
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

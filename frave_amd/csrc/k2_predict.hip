@@ -41,6 +41,7 @@ __device__ __forceinline__ uint32_t assign_bucket(float width) { return bucket_o
 // pack_signed, utils.rs:34-40 (k >= 0 -> 2k, k < 0 -> -2k - 1; wrapping arithmetic like a release build) = zig-zag
 __device__ __forceinline__ uint32_t pack_signed(int k) { return ((uint32_t)k << 1) ^ (uint32_t)(k >> 31); }
 
+constexpr int kLfNever = 127;
 struct PredArgs {
     const int32_t *coefs;      // one channel plane [F][512]
     const int32_t *pred_slots; // [n_tiles][kPredSlots]
@@ -66,6 +67,7 @@ struct PredArgs {
     uint8_t *junk;             // plan scratch, kPredJunkBytes per wave of the pipelined K2: output lines of block slots without a cell
     unsigned long long *trace; // diagnostic timeline, null in production
     uint32_t *acc;             // plan scratch, kPredAccWords per plane: the clearing workgroups' flags (serial numbers), the CHECK kernels' ticket, the inexact flag
+    int8_t lf_delta[8];        // slot-list offsets of the neighbour cells (left, up-left, up-right) of heap nodes 0 and 1, kLfNever = the position is never a node
     uint32_t serial;           // this launch's number on this accumulator (never 0): what the clearing workgroups publish and everybody polls for
     uint32_t n_tiles;
     uint16_t *words;      // predict_histogram_kernel3<., true>: bucket << 10 | symbol per node, [n_planes] planes out_stride apart, INSTEAD of bucket / prediction
@@ -403,14 +405,15 @@ __device__ __forceinline__ void p3_lf_hop_a(const PredArgs &a, uint32_t tile, bo
     const int slot = (1 + c / kPredBlock) * kPredSide + 1 + (c % kPredBlock);
     const int32_t *row = a.pred_slots + (size_t)(active ? tile : 0) * kPredSlots;
     it.raw = row[slot];
+    // where the three neighbour CELLS of heap nodes 0 / 1 sit in the slot list is geometry (rows 0 and 1 of the static neighbour table): kernel arguments
+    // (lf_delta, launch_predict_histogram) since round 4 - as a load of the table it was a dependent round trip in front of the slot-list loads, in the prologue
+    // of every workgroup
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const uint32_t e = a.nbr_table[it.node * 6 + k];
-        const int s7 = (e >> 9) & 7; // index into {self, +V9[0..5]}: lattice deltas as in pred_offsets_from_row
-        const int da = (int)((0x0F14u >> (2 * s7)) & 3u), db = (int)((0x14F0u >> (2 * s7)) & 3u);
-        const int delta = ((da & 1) - (da & 2)) * kPredSide + ((db & 1) - (db & 2));
-        const int r = row[slot + delta];
-        it.nb[k] = (e & 0x8000u) ? -1 : r;
+        const int d0 = a.lf_delta[k], d1 = a.lf_delta[3 + k]; // (static indices; selected per lane)
+        const int delta = it.node ? d1 : d0;
+        const int r = row[slot + (delta == kLfNever ? 0 : delta)];
+        it.nb[k] = delta == kLfNever ? -1 : r;
     }
     if (!active) it.raw = -1;
 }
@@ -888,6 +891,18 @@ __global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const Pr
 } // namespace
 
 
+// Slot-list offsets (in a tile's 6 x 6 slot list) of the three neighbour cells the low-frequency predictor reads for heap nodes 0 and 1 (p3_lf_hop_a)
+void build_lf_deltas(const uint16_t *nbr_table, int8_t *out /* [8] */) {
+    for (int node = 0; node < 2; node++)
+        for (int k = 0; k < 3; k++) {
+            const uint32_t e = nbr_table[node * 6 + k];
+            const int s7 = (e >> 9) & 7; // index into {self, +V9[0..5]}: lattice deltas as in pred_offsets_from_row
+            const int da = (int)((0x0F14u >> (2 * s7)) & 3u), db = (int)((0x14F0u >> (2 * s7)) & 3u);
+            out[node * 3 + k] = (e & 0x8000u) ? (int8_t)kLfNever : (int8_t)(((da & 1) - (da & 2)) * kPredSide + ((db & 1) - (db & 2)));
+        }
+    out[6] = out[7] = 0;
+}
+
 void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out) {
     for (int p = 0; p < kCell; p++) {
         uint32_t row[3], o[3];
@@ -963,6 +978,7 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, uint32_t
     PredArgs a{};
     a.acc = acc;
     a.serial = serial;
+    for (int k = 0; k < 8; k++) a.lf_delta[k] = p.lf_delta[k];
     a.coefs = b.coefs;
     a.coef_stride = b.coef_stride;
     a.out_stride = b.out_stride;

@@ -34,6 +34,7 @@ struct DevicePlan {
     const uint16_t *pair_pos = nullptr;   // [256] gather_layout.inc
     const uint16_t *heap_of_pos = nullptr; // [512]
     const uint32_t *halo_list = nullptr;   // [1024] K2's sparse halo staging list (build_halo_list)
+    int8_t lf_delta[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // K2's low-frequency predictor: slot-list offsets of its neighbour cells (build_lf_deltas), kernel arguments
     const int32_t *pred_slots = nullptr;  // [n_pred_tiles][kPredSlots]
     uint32_t n_pred_tiles = 0;
     uint32_t *hist_partial = nullptr;     // [hist_blocks][10*1024] scratch for the histogram reduction
@@ -46,6 +47,7 @@ struct DevicePlan {
     int32_t width = 0, height = 0, channels = 0;
     int32_t lds_pitch = 0, lds_rows = 0, cells_per_tile = 0;
     bool k1_batch_shares = true; // FRI_HIP_K1_BATCH_SHARES=0 disables the merged shares (A/B)
+    int k1_cached_stores = -1; // tuning (FRI_HIP_K1_CACHED_STORES=0 / 1): force nontemporal / plain coefficient stores; -1: the caller of the launch decides
     int32_t k1_ablate = 0; // timing-only ablation flags, see FwdArgs::ablate
     int32_t k2_ablate = 0; // the same for K2, see PredArgs::ablate
     bool k3_multiply = false; // fri_hip_plan_set_dequantiser: the inverse kernel multiplies by the quantiser instead of reproducing the reference's division
@@ -80,8 +82,9 @@ struct PredictParams {
 };
 
 // K1: address-map gather + 9-level residue transform + per-layer quantisation.
+// cached_stores: plain coefficient stores (the next kernel of a chain reads them straight away) instead of nontemporal ones (the default: written once, read later or never)
 hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, const uint8_t *pixels, size_t pixel_stride, int32_t *coefs,
-                                      size_t coef_stride, const QMatrix &q, hipStream_t stream);
+                                      size_t coef_stride, const QMatrix &q, hipStream_t stream, bool cached_stores = false);
 // K2: neighbour gather + bucket/prediction + LDS histogram, then the partial-histogram reduction.
 // acc_slot < kPredAccRing selects the plan accumulator the launch hands its sums over through (one per stream, fri_hip.cpp).
 // The planes (image x channel) one K2 / K4 launch works on: plane k reads coefs + k * coef_stride (int32 elements) and writes its
@@ -137,6 +140,7 @@ hipError_t launch_symbol_stream(const uint32_t *order, uint64_t n_symbols, uint3
 
 // K2's per-node neighbour offsets (LDS halfword offsets relative to the own slot, two per word) from the static neighbour table
 void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out /* [512][4] */);
+void build_lf_deltas(const uint16_t *nbr_table, int8_t *out /* [8] */);
 void build_gather_tables(const uint16_t *nbr_table, uint32_t *gather_off /* [512][4] */, uint16_t *pair_pos /* [256] */, uint16_t *heap_of_pos /* [512] */);
 // K2's sparse halo staging: the (halo slot, heap node) pairs a 4 x 4 block ever gathers, one per thread of its 1024-thread workgroup (0xFFFFFFFF = none)
 void build_halo_list(const uint16_t *nbr_table, const uint16_t *pair_pos, uint32_t *out /* [1024] */);

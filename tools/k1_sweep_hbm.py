@@ -31,7 +31,7 @@ C = int(os.environ.get("SWEEP_C", "1"))
 SW, SH = int(os.environ.get("SWEEP_W", "4096")), int(os.environ.get("SWEEP_H", "4096"))
 slots, n, rounds = opts["--slots"], opts["--launches"], opts["--rounds"]
 ctx = frave_amd.Context(0)
-KNOBS = ("FRI_HIP_INV_STRIDED_SHARES", "FRI_HIP_INV_SHARED", "FRI_HIP_INV_BAND_ROWS", "FRI_HIP_STRIDED_SHARES", "FRI_HIP_BAND_ROWS", "FRI_HIP_CELLS_PER_TILE", "FRI_HIP_CELLS_PER_WG", "FRI_HIP_TILE_BYTES", "FRI_HIP_TARGET_WGS", "FRI_HIP_RANKS", "FRI_HIP_RANK_WEIGHTS")
+KNOBS = ("FRI_HIP_K1_CACHED_STORES", "FRI_HIP_INV_STRIDED_SHARES", "FRI_HIP_INV_SHARED", "FRI_HIP_INV_BAND_ROWS", "FRI_HIP_STRIDED_SHARES", "FRI_HIP_BAND_ROWS", "FRI_HIP_CELLS_PER_TILE", "FRI_HIP_CELLS_PER_WG", "FRI_HIP_TILE_BYTES", "FRI_HIP_TARGET_WGS", "FRI_HIP_RANKS", "FRI_HIP_RANK_WEIGHTS")
 
 
 def make_plan(spec):
