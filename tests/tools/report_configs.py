@@ -143,6 +143,8 @@ del d_b3, d_p3, d_px, d_co
 drv = os.path.join(ROOT, "frave_amd", "host", "fri_driver")
 if os.path.exists(drv):
     print("   ", subprocess.run([drv, "batch", "1920", "1080", "1", "256"], capture_output=True, text=True).stdout.strip())
+    # pixels -> .frv bytes: device chains to the emitter's input and host rANS emits pipelined (libfri::encode_batch_bytes)
+    print("   ", subprocess.run([drv, "batch-frv", "1920", "1080", "1", "256", "--emitters", "12"], capture_output=True, text=True).stdout.strip())
 
 print("== config 4: 1024 x 4096x4096 over 8 GPUs -> this GPU's share is 128 images (image i -> rank i mod 8, no collective) ==")
 P = frave_amd.Plan(ctx, 4096, 4096, 1)

@@ -1,4 +1,4 @@
-"""Copies the summaries of a tools/profile_round3.sh run (gpurun_out/<tag>/) into profiles/ under this round's names and derives
+"""Copies the summaries of a tools/profile_round4.sh (round 3: profile_round3.sh) run (gpurun_out/<tag>/) into profiles/ under this round's names and derives
 profiles/r03_k1_traffic.json (what bench.py reports as roofline.traffic) from the K1 PMC passes.   python tools/collect_profiles.py <tag> [round]"""
 import json
 import os
@@ -8,11 +8,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 copies = {
     "kernel_stats_round3.csv": f"{rnd}_kernel_stats.csv",
+    "kernel_stats_round4.csv": f"{rnd}_kernel_stats.csv",
+    "bench_k20.json": f"{rnd}_bench_line_steps20.json",
+    "bench_traced_extras.json": f"{rnd}_bench_line_with_extras_under_rocprofv3.json",
     "pmc_k2_summary.txt": f"{rnd}_k2_pmc_summary.txt",
     "pmc_k2_k4_k3_k5_summary.txt": f"{rnd}_k2_k4_k3_k5_pmc_summary.txt",
     "pmc_k1_summary.txt": f"{rnd}_k1_pmc_summary.txt",
@@ -31,7 +34,8 @@ val = lambda name: float(re.search(name + r"\s+n=\s*\d+\s+mean=\s*([0-9.]+)", tx
 fetch, write = val("FETCH_SIZE"), val("WRITE_SIZE")
 out = {
     "kernel": "fwd_transform_quant_kernel<1,false,true,4,true>",
-    "workload": "4096x4096x1",
+    "workload": "4096x4096x1, single-image launches rotating over 32 slots (every byte from / to HBM)",
+    "bytes_convention": "counter KiB x 1024",
     "source": f"profiles/{rnd}_k1_pmc_summary.txt",
     "fetch_size_kb_raw": round(fetch, 1),
     "write_size_kb": round(write, 1),
