@@ -13,7 +13,7 @@
 #pragma once
 #include <cmath>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FRI_HD __host__ __device__
 #else
 #define FRI_HD
