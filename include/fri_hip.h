@@ -164,7 +164,9 @@ int fri_hip_predict_histogram(fri_hip_plan *plan, const int32_t *coefs, uint32_t
  * (one launch less, ~5 us). A broken promise is detected, not obeyed: the plane reports *n_out_of_alphabet == UINT64_MAX and an all-zero
  * histogram. Default: off (any int32 array accepted). */
 int fri_hip_plan_assume_forward_coefficients(fri_hip_plan *plan, int on);
-/* Device form: d_hist u32[10*1024] and d_n_out_of_alphabet u64[1] are overwritten. */
+/* Device form: d_hist u32[10*1024] and d_n_out_of_alphabet u64[1] are overwritten. Both must be DEVICE memory (hipMalloc): since round 4 the kernel clears
+ * them itself (its first workgroups, in their prologue) and adds its counts straight into them with device-scope atomics - there is no plan-side copy of the
+ * table any more. The same holds for the d_hist / d_n_out_of_alphabet arguments of every _dev / _batch_dev entry point below. */
 int fri_hip_predict_histogram_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint32_t channel, const float value_params[3][6],
                                   const float width_params[3][6], uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist,
                                   uint64_t *d_n_out_of_alphabet, void *stream);
