@@ -79,16 +79,21 @@ __device__ __forceinline__ void fit2_gather(uint32_t (&g)[6], const uint32_t (&a
         const uint32_t lo = *(lds_u16)(uintptr_t)(a[k] + OFFSET), hi = *(lds_u16)(uintptr_t)(b[k] + OFFSET);
         g[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u); // v_perm_b32: the two low halves side by side
     }
+    // The packing stays in the basic block of its loads: sunk below the boundary-mask branch that follows (where the packed values are first used), the
+    // compiler no longer knows that ds_read_u16 zero-extends and masks each of the twelve halves with 0xffff first - 12 of a pair's ~150 vector instructions.
+#pragma unroll
+    for (int k = 0; k < 6; k++) asm volatile("" : "+v"(g[k]));
 }
 
 // One pair of nodes of one cell: 28 (value fit) or 21 + 6 (width fit) sums. g: the six packed neighbour values; own: the pair's own
-// values packed the same way; mask: 0xFFFF per Some node of the pair (a None row is all zeros in the reference, :109-134).
+// values packed the same way; one: 1 per Some node of the pair, packed. A None row is all zeros in the reference (:109-134): the caller has masked g and own
+// (fit2_cell: boundary cells only - an interior cell has no None, and the one lane whose pair is not a row of the fit gathers zeros).
 template <int MODE>
-__device__ __forceinline__ void fit2_pair(const uint32_t (&g)[6], uint32_t own, uint32_t mask, const float (&vp)[6], int (&acc)[28], float (&facc)[6]) {
+__device__ __forceinline__ void fit2_pair(const uint32_t (&g)[6], uint32_t own, uint32_t one_bits, const float (&vp)[6], int (&acc)[28], float (&facc)[6]) {
     s16x2 u[7];
 #pragma unroll
-    for (int k = 0; k < 6; k++) u[k] = __builtin_bit_cast(s16x2, g[k] & mask);
-    u[6] = __builtin_bit_cast(s16x2, own & mask);
+    for (int k = 0; k < 6; k++) u[k] = __builtin_bit_cast(s16x2, g[k]);
+    u[6] = __builtin_bit_cast(s16x2, own);
     if (MODE == 0) {
         int n = 0;
 #pragma unroll
@@ -104,26 +109,31 @@ __device__ __forceinline__ void fit2_pair(const uint32_t (&g)[6], uint32_t own, 
         float pa = __fmul_rn(fa[0], vp[0]), pb = __fmul_rn(fb[0], vp[0]);
 #pragma unroll
         for (int k = 1; k < 6; k++) pa = __fadd_rn(pa, __fmul_rn(fa[k], vp[k])), pb = __fadd_rn(pb, __fmul_rn(fb[k], vp[k]));
-        const float ra = fabsf(__fsub_rn(fa[6], pa)), rb = fabsf(__fsub_rn(fb[6], pb));
+        float ra = fabsf(__fsub_rn(fa[6], pa)), rb = fabsf(__fsub_rn(fb[6], pb));
+        // |r| in a register of its own (one v_and each): as a source modifier it would force the twelve multiply-adds below into the four-cycle VOP3 encoding
+        asm volatile("" : "+v"(ra), "+v"(rb));
         // features w = [1, |v0-v3|, |v1-v2|, |v4-v5|, |v1-v5|, |v2-v4|]: packed int16 for the exact integer sums W^T W ...
         auto absdiff = [&](int k0, int k1) {
             const s16x2 d = u[k0] - u[k1];
             return __builtin_elementwise_max(d, -d);
         };
-        const s16x2 one = __builtin_bit_cast(s16x2, 0x00010001u & mask);
+        const s16x2 one = __builtin_bit_cast(s16x2, one_bits);
         const s16x2 w[6] = {one, absdiff(0, 3), absdiff(1, 2), absdiff(4, 5), absdiff(1, 5), absdiff(2, 4)};
         int n = 0;
 #pragma unroll
         for (int r0 = 0; r0 < 6; r0++)
 #pragma unroll
             for (int c0 = r0; c0 < 6; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(w[r0], w[c0], acc[n], false);
-        // ... and floats for W^T r: f32 partial sums over the nodes a lane has in a tile, f64 from there on
-        facc[0] += (float)one.x * ra + (float)one.y * rb;
-        facc[1] += fabsf(fa[0] - fa[3]) * ra + fabsf(fb[0] - fb[3]) * rb;
-        facc[2] += fabsf(fa[1] - fa[2]) * ra + fabsf(fb[1] - fb[2]) * rb;
-        facc[3] += fabsf(fa[4] - fa[5]) * ra + fabsf(fb[4] - fb[5]) * rb;
-        facc[4] += fabsf(fa[1] - fa[5]) * ra + fabsf(fb[1] - fb[5]) * rb;
-        facc[5] += fabsf(fa[2] - fa[4]) * ra + fabsf(fb[2] - fb[4]) * rb;
+        // ... and floats for W^T r: f32 partial sums over the nodes a lane has in a tile, 64-bit fixed point from there on (fit_f32_to_fixed). The
+        // features come from the packed integers (one conversion each; exact) and every product enters its sum through a fused multiply-add whose
+        // addend is the sum itself (v_fmac_f32, the two-cycle VOP2 form; a rounded product and an add are two instructions more per feature and node
+        // and no closer to the real sum). A None row's residual is |0 - 0|.
+        facc[0] = __fadd_rn(__fadd_rn(facc[0], ra), rb);
+#pragma unroll
+        for (int k = 1; k < 6; k++) {
+            facc[k] = __builtin_fmaf((float)w[k].x, ra, facc[k]);
+            facc[k] = __builtin_fmaf((float)w[k].y, rb, facc[k]);
+        }
     }
 }
 
@@ -181,31 +191,37 @@ __device__ __forceinline__ void fit2_halo_commit(int v, uint8_t *image, uint32_t
     *reinterpret_cast<short *>(image + (entry & 63u) * kSlotStride + 2u * ((entry >> 8) & 511u)) = (short)v; // None = INT32_MIN: low half 0 (unwrap_or(0))
 }
 
+// has_bits / interior_bits: bit (C >> 2) * kPredSide + (C & 3) = "the wave's block cell C holds a retained cell" / "... an interior one" (the tile's slot table as
+// two wave-uniform words, read once per tile: as two LDS reads per cell - cell index, interior flag, each waited for before a branch - they were two of the
+// three LDS round trips in a row that a cell's ~100 vector instructions had to hide behind, with four waves per SIMD).
 template <int MODE, int IMG, int C>
-__device__ __forceinline__ void fit2_cell(const int32_t *s_slot_cell, const int32_t *s_slot_interior, const uint32_t *mask_word, uint32_t mask_shift, uint32_t keep, int slot0,
+__device__ __forceinline__ void fit2_cell(const int32_t *s_slot_cell, uint32_t has_bits, uint32_t interior_bits, const uint32_t *mask_word, uint32_t mask_shift, uint32_t keep, int slot0,
                                           const uint32_t (&addr)[2][6], uint32_t own_addr, const float (&vp)[6], int (&acc)[28], float (&facc)[6]) {
-    constexpr int kOff = IMG * kFit2Image + ((C >> 2) * kPredSide + (C & 3)) * kSlotStride;
-    const int slot = slot0 + (C >> 2) * kPredSide + (C & 3);
-    const int cell = __builtin_amdgcn_readfirstlane(s_slot_cell[slot]);
-    if (cell < 0) return;
-    const uint32_t own = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(own_addr + kOff);
+    constexpr int kBit = (C >> 2) * kPredSide + (C & 3);
+    constexpr int kOff = IMG * kFit2Image + kBit * kSlotStride;
+    if (!((has_bits >> kBit) & 1u)) return;
+    uint32_t own = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(own_addr + kOff);
     uint32_t g[6];
     fit2_gather<kOff>(g, addr[0], addr[1]);
-    uint32_t mask = keep;
-    if (__builtin_amdgcn_readfirstlane(s_slot_interior[slot]) == 0) { // boundary cell: node p is bit (p & 31) of mask word p >> 5
+    uint32_t one = keep & 0x00010001u;
+    if (!((interior_bits >> kBit) & 1u)) { // boundary cell: node p is bit (p & 31) of mask word p >> 5; a None node's row is all zeros
+        const int cell = __builtin_amdgcn_readfirstlane(s_slot_cell[slot0 + kBit]);
         const uint32_t bits = mask_word[(size_t)cell * 16] >> mask_shift;
-        mask &= ((bits & 1u) ? 0x0000FFFFu : 0u) | ((bits & 2u) ? 0xFFFF0000u : 0u);
+        const uint32_t mask = ((bits & 1u) ? 0x0000FFFFu : 0u) | ((bits & 2u) ? 0xFFFF0000u : 0u);
+#pragma unroll
+        for (int k = 0; k < 6; k++) g[k] &= mask;
+        own &= mask, one &= mask;
     }
-    fit2_pair<MODE>(g, own, mask, vp, acc, facc);
+    fit2_pair<MODE>(g, own, one, vp, acc, facc);
     asm volatile("" ::: "memory"); // one cell's gathers at a time: the next cell's would cost 13 more registers
 }
 template <int MODE, int IMG, int C0>
-__device__ __forceinline__ void fit2_cells(const int32_t *s_slot_cell, const int32_t *s_slot_interior, const uint32_t *mask_word, uint32_t mask_shift, uint32_t keep, int slot0,
+__device__ __forceinline__ void fit2_cells(const int32_t *s_slot_cell, uint32_t has_bits, uint32_t interior_bits, const uint32_t *mask_word, uint32_t mask_shift, uint32_t keep, int slot0,
                                            const uint32_t (&addr)[2][6], uint32_t own_addr, const float (&vp)[6], int (&acc)[28], float (&facc)[6]) {
-    fit2_cell<MODE, IMG, C0 + 0>(s_slot_cell, s_slot_interior, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
-    fit2_cell<MODE, IMG, C0 + 1>(s_slot_cell, s_slot_interior, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
-    fit2_cell<MODE, IMG, C0 + 2>(s_slot_cell, s_slot_interior, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
-    fit2_cell<MODE, IMG, C0 + 3>(s_slot_cell, s_slot_interior, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
+    fit2_cell<MODE, IMG, C0 + 0>(s_slot_cell, has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
+    fit2_cell<MODE, IMG, C0 + 1>(s_slot_cell, has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
+    fit2_cell<MODE, IMG, C0 + 2>(s_slot_cell, has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
+    fit2_cell<MODE, IMG, C0 + 3>(s_slot_cell, has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
 }
 
 // Sum of v over the 64 lanes of the wave, in lane 63: quad_perm(1,0,3,2), quad_perm(2,3,0,1), row_half_mirror, row_mirror leave every row's total in all of its
@@ -294,7 +310,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         pp = a0.pp3[2];
     __shared__ __attribute__((aligned(16))) uint8_t s_cells[2 * kFit2Image]; // two cell images: tile i + 1 is staged while tile i is worked on
     __shared__ int32_t s_slot_cell[2][kPredSlots];
-    __shared__ int32_t s_slot_interior[2][kPredSlots];
+    __shared__ uint32_t s_slot_bits[2][2]; // per image: bit s = slot s holds a retained cell / an interior one (every block slot is below 32: fit2_cell)
     __shared__ uint32_t s_flag, s_range;
     __shared__ unsigned long long s_int[3][28];
     __shared__ unsigned long long s_fix[3][6]; // W^T r in fixed point (kFitFixBits fraction bits): integer adds commute, so the sums do not depend on who arrives when
@@ -322,7 +338,14 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
 #pragma unroll
         for (int k = 0; k < 6; k++) addr[j][k] = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * (int)(short)((rel[k >> 1] >> (16 * (k & 1))) & 0xFFFFu));
     }
-    const uint32_t own_addr = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * n0);
+    uint32_t own_addr = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * n0);
+    if (n0 == 0) { // heap nodes 0 and 1 are not rows of the fit: that lane reads the zero words behind its cell (fit2_block_commit), a row of zeros like a None's
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) addr[j][k] = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * kCell);
+        own_addr = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * kCell);
+    }
     // the pair's two bits of a boundary cell's mask (node p is bit p & 31 of word p >> 5); heap index 0 and 1 are coded by the LF predictor
     // and are not rows of the fit
     const uint32_t *const mask_word = a0.valid_mask + (n0 >> 5);
@@ -362,9 +385,19 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     }
     uint32_t tile = walk.first;
     int next_raw = -1; // thread t < 36: slot t of the tile after the current one, requested a tile ahead
-    auto slot_table = [&](int img, int raw) {
+    static_assert((kPredBlock * kPredSide + kPredBlock) < 32 && kPredSlots <= 64, "the block slots' bits fit one word; the slot table is written by one wave");
+    // Entry `tid` of a tile's slot list: uniform row address + the lane's 32-bit offset, made opaque so that it is formed where it is used - as a loop
+    // invariant it is a 64-bit per-lane pointer, two registers the width pass does not have: spilled, and reloaded once per tile behind an s_waitcnt vmcnt(0),
+    // i.e. behind the staging loads wave 0 had just issued.
+    auto slot_entry = [&](uint32_t t) {
+        uint32_t off = (uint32_t)tid * 4u;
+        asm volatile("" : "+v"(off));
+        return *reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(a0.pred_slots + (size_t)t * kPredSlots) + off);
+    };
+    auto slot_table = [&](int img, int raw) { // (threads 0..kPredSlots-1: lanes of wave 0, so the ballots are the table)
         s_slot_cell[img][tid] = pred_slot_cell(raw);
-        s_slot_interior[img][tid] = pred_slot_interior(raw) ? 1 : 0;
+        const unsigned long long has = __ballot(pred_slot_cell(raw) >= 0), interior = __ballot(pred_slot_interior(raw));
+        if (tid == 0) s_slot_bits[img][0] = (uint32_t)has, s_slot_bits[img][1] = (uint32_t)interior;
     };
     // One tile with image IMG current: publish the next tile's slot table, request its coefficients, do this tile's sums, convert and
     // write the next tile into the other image. Two barriers per tile.
@@ -375,12 +408,14 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         if (tid < kPredSlots) slot_table(IMG ^ 1, tile + walk.step < walk.end ? next_raw : -1);                                                  \
         __syncthreads();                                                                                                                         \
         float facc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                                                                          \
+        const uint32_t has_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot_bits[IMG][0]) >> slot0;                                   \
+        const uint32_t interior_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot_bits[IMG][1]) >> slot0;                              \
         {                                                                                                                                        \
             Fit2Block st;                                                                                                                        \
             fit2_block_load(st, coefs, s_slot_cell[IMG ^ 1], block_a, lane, ablate & 2);                                                         \
             const int hv = fit2_halo_load(coefs, s_slot_cell[IMG ^ 1], halo_e0, ablate & 2);                                                     \
-            if (tid < kPredSlots && tile + 2 * walk.step < walk.end) next_raw = a0.pred_slots[(size_t)(tile + 2 * walk.step) * kPredSlots + tid]; \
-            if (!(ablate & 1)) fit2_cells<MODE, IMG, 0>(s_slot_cell[IMG], s_slot_interior[IMG], mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
+            if (tid < kPredSlots && tile + 2 * walk.step < walk.end) next_raw = slot_entry(tile + 2 * walk.step);                                 \
+            if (!(ablate & 1)) fit2_cells<MODE, IMG, 0>(s_slot_cell[IMG], has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
             fit2_block_commit(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_a, lane, &s_range);                              \
             fit2_halo_commit(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e0);                                                                     \
         }                                                                                                                                        \
@@ -388,7 +423,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             Fit2Block st;                                                                                                                        \
             fit2_block_load(st, coefs, s_slot_cell[IMG ^ 1], block_b, lane, ablate & 2);                                                         \
             const int hv = fit2_halo_load(coefs, s_slot_cell[IMG ^ 1], halo_e1, ablate & 2);                                                     \
-            if (!(ablate & 1)) fit2_cells<MODE, IMG, 4>(s_slot_cell[IMG], s_slot_interior[IMG], mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
+            if (!(ablate & 1)) fit2_cells<MODE, IMG, 4>(s_slot_cell[IMG], has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
             fit2_block_commit(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_b, lane, &s_range);                              \
             fit2_halo_commit(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e1);                                                                     \
         }                                                                                                                                        \
@@ -404,8 +439,8 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         tile += walk.step;                                                                                                                       \
     }
     if (tile < walk.end) {
-        if (tid < kPredSlots) slot_table(0, a0.pred_slots[(size_t)tile * kPredSlots + tid]);
-        if (tid < kPredSlots && tile + walk.step < walk.end) next_raw = a0.pred_slots[(size_t)(tile + walk.step) * kPredSlots + tid];
+        if (tid < kPredSlots) slot_table(0, slot_entry(tile));
+        if (tid < kPredSlots && tile + walk.step < walk.end) next_raw = slot_entry(tile + walk.step);
         __syncthreads();
         {
             Fit2Block sa, sb;
