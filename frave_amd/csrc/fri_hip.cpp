@@ -874,10 +874,10 @@ static int predict_launch(fri_hip_plan *p, const PredBatch &b, uint8_t *d_bucket
 }
 // d_range (may be NULL): per plane, how many waves staged a Some coefficient outside [-256, 255] (include/fri_hip.h: the fit's precondition)
 static int fit_launch(fri_hip_plan *p, int mode, const PredBatch &b, int64_t *d_int, double *d_dbl, unsigned long long *d_range, hipStream_t stream,
-                      const FitSolve *solve = nullptr) {
+                      const FitSolve *solve = nullptr, int trust = kPredAnyInt32) {
     const int slot = acquire_acc(p, stream, b.n_planes);
     if (slot < 0) return slot;
-    const hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream, solve);
+    const hipError_t e = launch_fit_accumulate(p->dev, p->acc_slots[slot].fit_acc, mode, b, (unsigned long long *)d_int, d_dbl, d_range, stream, solve, trust);
     if (e != hipSuccess) {
         p->acc_dirty = true;
         return fail_hip(p->ctx, e, "launch_fit_accumulate");
@@ -1053,7 +1053,9 @@ static int ensure_encode_staging(fri_hip_plan *p, bool node_arrays = true) {
 // without a word to the host: value sums -> 6 x 6 solves -> width sums (with the value parameters just written) -> solves. The parameters land
 // in the device array b.params (PredictParams per plane), where the scan kernel reads them. d_range (may be NULL) receives, per plane, the
 // number of waves that staged a Some coefficient outside [-256, 255] (the sums are then not to be trusted).
-static int fit_chain(fri_hip_plan *p, const PredBatch &b, unsigned long long *d_range, hipStream_t s, float *host_params = nullptr, unsigned long long *host_range = nullptr) {
+// trust: kPredForwardOutput when this library's forward kernel wrote the planes earlier in the same call (the staging then does not look, and the count is 0).
+static int fit_chain(fri_hip_plan *p, const PredBatch &b, unsigned long long *d_range, hipStream_t s, float *host_params = nullptr, unsigned long long *host_range = nullptr,
+                     int trust = kPredAnyInt32) {
     if (!b.params) return FRI_HIP_ERR_INVALID_ARGUMENT;
     const int slot = acquire_acc(p, s, b.n_planes); // the stream's accumulators and fit scratch (the launches below find the same slot)
     if (slot < 0) return slot;
@@ -1066,9 +1068,9 @@ static int fit_chain(fri_hip_plan *p, const PredBatch &b, unsigned long long *d_
     FitSolve solve;
     solve.params = params, solve.host_params = host_params, solve.host_range = host_range;
     for (int g = 0; g < 3; g++) solve.rows[g] = rows[g];
-    if (int rc = fit_launch(p, 0, b, (int64_t *)k.sums_int, nullptr, range, s, &solve)) return rc;
+    if (int rc = fit_launch(p, 0, b, (int64_t *)k.sums_int, nullptr, range, s, &solve, trust)) return rc;
     solve.host_range = nullptr; // (the width pass does not count)
-    return fit_launch(p, 1, b, (int64_t *)k.sums_int, k.sums_dbl, nullptr, s, &solve);
+    return fit_launch(p, 1, b, (int64_t *)k.sums_int, k.sums_dbl, nullptr, s, &solve, trust);
 }
 
 // prediction::encode for all channels of one image whose coefficients are in device memory (prediction.rs:224-323 minus the host's ANS
@@ -1105,7 +1107,7 @@ static int predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, f
     if (!p->ev_fit) HIP_TRY(c, hipEventCreateWithFlags(&p->ev_fit, hipEventDisableTiming));
     b.params = reinterpret_cast<const PredictParams *>(k.params);
     char *const h = static_cast<char *>(p->h_fit), *const dh = static_cast<char *>(p->d_h_fit);
-    if (int rc = fit_chain(p, b, k.range, s, reinterpret_cast<float *>(dh), reinterpret_cast<unsigned long long *>(dh + 3 * sizeof(PredictParams)))) return rc;
+    if (int rc = fit_chain(p, b, k.range, s, reinterpret_cast<float *>(dh), reinterpret_cast<unsigned long long *>(dh + 3 * sizeof(PredictParams)), trust)) return rc;
     HIP_TRY(c, hipEventRecord(p->ev_fit, s));
     // the scan is queued before the host looks at the fit: it runs while the host picks the parameters up
     const int rc_scan = predict_launch(p, b, d_bucket, d_prediction, d_hist, d_oob, trust, s);
@@ -1168,7 +1170,7 @@ int fri_hip_encode_image_batch_dev(fri_hip_plan *p, uint32_t n_images, const uin
     b.out_stride = C > 1 ? plane : out_stride;
     b.params = reinterpret_cast<const PredictParams *>(d_params);
     if (fit)
-        if (int rc = fit_chain(p, b, (unsigned long long *)d_fit_out_of_range, s)) return rc;
+        if (int rc = fit_chain(p, b, (unsigned long long *)d_fit_out_of_range, s, nullptr, nullptr, kPredForwardOutput)) return rc;
     return predict_launch(p, b, d_bucket, d_prediction, d_hist, d_n_out_of_alphabet, kPredForwardOutput, s);
 }
 
@@ -1198,7 +1200,7 @@ int fri_hip_encode_symbols_batch_dev(fri_hip_plan *p, uint32_t n_images, const u
     b.params = reinterpret_cast<const PredictParams *>(d_params);
     b.words = d_node_words;
     if (fit)
-        if (int rc = fit_chain(p, b, (unsigned long long *)d_fit_out_of_range, s)) return rc;
+        if (int rc = fit_chain(p, b, (unsigned long long *)d_fit_out_of_range, s, nullptr, nullptr, kPredForwardOutput)) return rc;
     if (int rc = predict_launch(p, b, nullptr, nullptr, d_hist, d_n_out_of_alphabet, kPredForwardOutput, s)) return rc;
     HIP_TRY(p->ctx, launch_symbol_gather(p->d_stream_order, n, b.n_planes, d_node_words, b.out_stride, d_symbols, C > 1 ? n : symbol_stride, s));
     return FRI_HIP_OK;

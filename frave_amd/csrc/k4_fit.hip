@@ -163,10 +163,11 @@ __device__ __forceinline__ void fit2_block_load(Fit2Block &r, const int32_t *__r
         r.hi = src[1];
     }
 }
+template <bool CHECK>
 __device__ __forceinline__ void fit2_block_commit(const Fit2Block &r, const int32_t *s_slot_cell, uint8_t *image, int slot, int lane, uint32_t *range_counter) {
     auto pk = [](int lo16, int hi16) -> uint32_t { return __builtin_amdgcn_perm((uint32_t)hi16, (uint32_t)lo16, 0x05040100u); };
     const int4 lo = r.lo, hi = r.hi;
-    if (s_slot_cell[slot] >= 0) { // a None is 0x80000000: its low half stages as 0, and it is not an outlier
+    if (CHECK && s_slot_cell[slot] >= 0) { // a None is 0x80000000: its low half stages as 0, and it is not an outlier
         const int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         uint32_t m = 0;
 #pragma unroll
@@ -224,39 +225,27 @@ __device__ __forceinline__ void fit2_cells(const int32_t *s_slot_cell, uint32_t 
     fit2_cell<MODE, IMG, C0 + 3>(s_slot_cell, has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc);
 }
 
-// Sum of v over the 64 lanes of the wave, in lane 63: quad_perm(1,0,3,2), quad_perm(2,3,0,1), row_half_mirror, row_mirror leave every row's total in all of its
-// lanes; row_bcast:15 carries it into rows 1 and 3, row_bcast:31 the total of rows 0-1 into rows 2 and 3. 32-bit throughout: a lane adds at most 8 cells x
-// 2 x 256^2 = 2^20 per tile to a sum, a wave 2^26, so with a flush every 16 tiles the wave's total stays below 2^30.
-__device__ __forceinline__ int fit2_wave_total(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
-    return v;
-}
+// A wave's sums on their way to the workgroup's: across the 16 lanes of a DPP row in registers - stage by stage over ALL sums, so that no add waits for the
+// one before it (sum by sum, every one of the 4 x NI dependent DPP adds sat behind two wait states) - then one lane per row adds the row's total to the row's copy of the workgroup's sums in LDS as a
+// 64-bit integer (four lanes of one ds_add_u64, four addresses; s_int: [4 rows][3 groups][28]). 32 bits hold a row for 16 tiles in both passes (value: |u| <= 256, a lane adds at most 8 cells x 2 x 256^2 =
+// 2^20 per tile; width: features up to 511, four times that).
 template <int NI>
 __device__ __forceinline__ void fit2_wave_sums(int (&acc)[28], int group, int lane, unsigned long long (*s_int)[28]) {
+    int r[NI];
 #pragma unroll
-    for (int k = 0; k < NI; k++) {
-        if (NI == 28) { // the value pass: |u| <= 256, see fit2_wave_total
-            const int total = fit2_wave_total(acc[k]);
-            acc[k] = 0;
-            // (round 2 read the four row totals out through readlane and added them as 64-bit scalars: a vector -> scalar -> vector chain per sum, three
-            // times the instructions - a good part of the 5 us between a workgroup's last tile and its ticket)
-            if (lane == 63) atomicAdd(&s_int[group][k], (unsigned long long)(long long)total);
-        } else { // the width pass: features up to 511, a product up to 2^18 - four times the value pass's: 32 bits hold a ROW of 16 lanes for 16 tiles, not the wave
-            int r = acc[k];
-            acc[k] = 0;
-            r += __builtin_amdgcn_update_dpp(0, r, 0xB1, 0xF, 0xF, true);
-            r += __builtin_amdgcn_update_dpp(0, r, 0x4E, 0xF, 0xF, true);
-            r += __builtin_amdgcn_update_dpp(0, r, 0x141, 0xF, 0xF, true);
-            r += __builtin_amdgcn_update_dpp(0, r, 0x140, 0xF, 0xF, true);
-            const long long sum = ((long long)__builtin_amdgcn_readlane(r, 0) + __builtin_amdgcn_readlane(r, 16)) +
-                                  ((long long)__builtin_amdgcn_readlane(r, 32) + __builtin_amdgcn_readlane(r, 48));
-            if (lane == 0) atomicAdd(&s_int[group][k], (unsigned long long)sum);
-        }
+    for (int k = 0; k < NI; k++) r[k] = acc[k], acc[k] = 0;
+#pragma unroll
+    for (int k = 0; k < NI; k++) r[k] += __builtin_amdgcn_update_dpp(0, r[k], 0xB1, 0xF, 0xF, true);  // quad_perm(1,0,3,2)
+#pragma unroll
+    for (int k = 0; k < NI; k++) r[k] += __builtin_amdgcn_update_dpp(0, r[k], 0x4E, 0xF, 0xF, true);  // quad_perm(2,3,0,1)
+#pragma unroll
+    for (int k = 0; k < NI; k++) r[k] += __builtin_amdgcn_update_dpp(0, r[k], 0x141, 0xF, 0xF, true); // row_half_mirror
+#pragma unroll
+    for (int k = 0; k < NI; k++) r[k] += __builtin_amdgcn_update_dpp(0, r[k], 0x140, 0xF, 0xF, true); // row_mirror: every lane holds its row's total
+    if ((lane & 15) == 0) { // (a copy of the sums per DPP row: with one address for the four lanes the compiler's atomic optimiser turns every add into a scalar loop over the lanes)
+        unsigned long long *const mine = &s_int[(lane >> 4) * 3 + group][0];
+#pragma unroll
+        for (int k = 0; k < NI; k++) atomicAdd(mine + k, (unsigned long long)(long long)r[k]);
     }
 }
 
@@ -292,7 +281,9 @@ __device__ __attribute__((noinline)) void fit2_tail_solve(const long long *sums_
     }
 }
 
-template <int MODE>
+// CHECK = false: the coefficients were written by this library's forward kernel earlier in the same call (kPredForwardOutput): every magnitude is <= 255 by
+// construction, the staging does not look (40 of a block cell's ~75 vector instructions) and the out-of-range count stays 0.
+template <int MODE, bool CHECK>
 __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const FitArgs a0) {
     constexpr int NI = MODE == 0 ? 28 : 21;
     const uint32_t plane = blockIdx.y;
@@ -312,14 +303,14 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     __shared__ int32_t s_slot_cell[2][kPredSlots];
     __shared__ uint32_t s_slot_bits[2][2]; // per image: bit s = slot s holds a retained cell / an interior one (every block slot is below 32: fit2_cell)
     __shared__ uint32_t s_flag, s_range;
-    __shared__ unsigned long long s_int[3][28];
-    __shared__ unsigned long long s_fix[3][6]; // W^T r in fixed point (kFitFixBits fraction bits): integer adds commute, so the sums do not depend on who arrives when
+    __shared__ unsigned long long s_int[4 * 3][28]; // [DPP row][layer group][sum], see fit2_wave_sums; the hand-over adds the four rows
+    __shared__ unsigned long long s_fix[16 * 3][6]; // [copy][layer group][sum]: W^T r in fixed point (kFitFixBits fraction bits): integer adds commute, so the sums do not depend on who arrives when
     __shared__ double s_dbl[3][6];              // (the totals, for the solve in the tail)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg = wave & 3, half = wave >> 2;
-    if (tid < 3 * 28) (&s_int[0][0])[tid] = 0;
-    if (tid < 18) (&s_fix[0][0])[tid] = 0ull;
+    if (tid < 4 * 3 * 28) (&s_int[0][0])[tid] = 0;
+    if (tid < 16 * 18) (&s_fix[0][0])[tid] = 0ull;
     if (tid == 0) s_range = 0;
     trace_stamp(a0.trace, blockIdx.x, 0, tid);
 
@@ -416,7 +407,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             const int hv = fit2_halo_load(coefs, s_slot_cell[IMG ^ 1], halo_e0, ablate & 2);                                                     \
             if (tid < kPredSlots && tile + 2 * walk.step < walk.end) next_raw = slot_entry(tile + 2 * walk.step);                                 \
             if (!(ablate & 1)) fit2_cells<MODE, IMG, 0>(s_slot_cell[IMG], has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
-            fit2_block_commit(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_a, lane, &s_range);                              \
+            fit2_block_commit<CHECK>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_a, lane, &s_range);                              \
             fit2_halo_commit(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e0);                                                                     \
         }                                                                                                                                        \
         {                                                                                                                                        \
@@ -424,7 +415,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             fit2_block_load(st, coefs, s_slot_cell[IMG ^ 1], block_b, lane, ablate & 2);                                                         \
             const int hv = fit2_halo_load(coefs, s_slot_cell[IMG ^ 1], halo_e1, ablate & 2);                                                     \
             if (!(ablate & 1)) fit2_cells<MODE, IMG, 4>(s_slot_cell[IMG], has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
-            fit2_block_commit(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_b, lane, &s_range);                              \
+            fit2_block_commit<CHECK>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_b, lane, &s_range);                              \
             fit2_halo_commit(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e1);                                                                     \
         }                                                                                                                                        \
         if (MODE == 1) {                                                                                                                         \
@@ -447,8 +438,8 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             fit2_block_load(sa, coefs, s_slot_cell[0], block_a, lane, false);
             fit2_block_load(sb, coefs, s_slot_cell[0], block_b, lane, false);
             const int h0 = fit2_halo_load(coefs, s_slot_cell[0], halo_e0, false), h1 = fit2_halo_load(coefs, s_slot_cell[0], halo_e1, false);
-            fit2_block_commit(sa, s_slot_cell[0], s_cells, block_a, lane, &s_range);
-            fit2_block_commit(sb, s_slot_cell[0], s_cells, block_b, lane, &s_range);
+            fit2_block_commit<CHECK>(sa, s_slot_cell[0], s_cells, block_a, lane, &s_range);
+            fit2_block_commit<CHECK>(sb, s_slot_cell[0], s_cells, block_b, lane, &s_range);
             fit2_halo_commit(h0, s_cells, halo_e0);
             fit2_halo_commit(h1, s_cells, halo_e1);
         }
@@ -462,29 +453,28 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         }
     }
 #undef FRI_FIT2_PHASE
-    // A wave's sums go to the workgroup's in two steps: across the 16 lanes of a DPP row in registers (4 adds per sum, 32-bit: see the
-    // bound above), the four row totals through readlane into scalars, and lane 0 adds the group totals to LDS - 28 sums cost a wave
-    // ~250 instructions. (The first kernel parks all lanes' sums in LDS and lets one thread per sum walk 32-64 of them: ~6 us per
-    // workgroup, a tenth of the kernel.)
+    // A wave's sums go to the workgroup's through fit2_wave_sums (DPP row totals, one LDS add per row). (Round 1's kernel parked all lanes' sums in LDS and let
+    // one thread per sum walk 32-64 of them: ~6 us per workgroup; round 2 read the row totals out through readlane into scalar adds: ~250 instructions per wave.)
     trace_stamp(a0.trace, blockIdx.x, 13, tid);
     fit2_wave_sums<NI>(acc, group, lane, s_int);
-    if (MODE == 1) {
+    if (MODE == 1) { // a lane's six fixed-point sums go to copy (lane & 15) of the workgroup's: six LDS adds (four lanes per address and instruction) instead of a 72-step shuffle tree
+        unsigned long long *const mine = &s_fix[(lane & 15) * 3 + group][0];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            unsigned long long v = fx[k];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if (lane == 0) atomicAdd(&s_fix[group][k], v);
-        }
+        for (int k = 0; k < 6; k++) atomicAdd(mine + k, fx[k]);
     }
     __syncthreads();
     // hand-over: add into this workgroup's copy of the plane's accumulator, draw a ticket, the last workgroup sums the copies, moves the totals out
     // and re-zeroes
     if (tid < 3 * NI) {
         const int gg = tid / NI, k = tid % NI;
-        __hip_atomic_fetch_add(accs + tid, s_int[gg][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(accs + tid, (s_int[gg][k] + s_int[3 + gg][k]) + (s_int[6 + gg][k] + s_int[9 + gg][k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (MODE == 1 && tid < 18) __hip_atomic_fetch_add(accs + kFitAccDbl + tid, (&s_fix[0][0])[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (MODE == 1 && tid < 18) {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) v += (&s_fix[0][0])[c * 18 + tid];
+        __hip_atomic_fetch_add(accs + kFitAccDbl + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (tid == 0 && s_range) __hip_atomic_fetch_add(accp + kFitAccRange, (unsigned long long)s_range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wait_for_own_memory_ops_then_barrier(); // every wave has waited for its adds before the ticket is drawn
     if (tid == 0) s_flag = __hip_atomic_fetch_add(accp + kFitAccTicket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
@@ -604,7 +594,7 @@ hipError_t launch_fit_solve(int mode, uint32_t n_planes, const unsigned long lon
 }
 
 hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
-                                 unsigned long long *out_of_range, hipStream_t stream, const FitSolve *solve) {
+                                 unsigned long long *out_of_range, hipStream_t stream, const FitSolve *solve, int trust) {
     if (!acc || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
     FitArgs a{};
     a.coefs = b.coefs;
@@ -640,10 +630,9 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
     }
     if (!blocks) blocks = 1;
     (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
-    if (mode == 0)
-        hipLaunchKernelGGL(fit_accumulate_kernel2<0>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
-    else
-        hipLaunchKernelGGL(fit_accumulate_kernel2<1>, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
+    const bool check = trust != kPredForwardOutput;
+    void (*kern)(const FitArgs) = mode == 0 ? (check ? fit_accumulate_kernel2<0, true> : fit_accumulate_kernel2<0, false>) : (check ? fit_accumulate_kernel2<1, true> : fit_accumulate_kernel2<1, false>);
+    hipLaunchKernelGGL(kern, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
     return hipGetLastError();
 }
 

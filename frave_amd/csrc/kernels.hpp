@@ -64,7 +64,7 @@ struct DevicePlan {
 };
 
 constexpr uint32_t kPredJunkWaves = 16, kPredJunkBytes = 2560; // per wave: 512 B of bucket + 2 KiB of prediction
-constexpr uint32_t kFitAccWords = 3 * 28 + 18 + 2; // integer sums, f64 sums, ticket, out-of-range count
+constexpr uint32_t kFitAccWords = 3 * 28 + 18 + 2; // integer sums, fixed-point sums (W^T r), ticket, out-of-range count
 // The fit kernel's 512 workgroups all add into the same ~100 words: at the memory side same-address atomics take ~12 ns each, so 512 arrivals per
 // word were 5-6 us of every launch (per-workgroup time stamps: "loop done" -> "ticket drawn"). The accumulator of a plane is therefore kept in
 // kFitShards copies, workgroup b adds into copy b % kFitShards, and the workgroup that draws the last ticket (copy 0 holds it) sums the copies.
@@ -118,7 +118,7 @@ struct FitSolve {
     unsigned long long rows[3] = {0, 0, 0};  // mode 1: heights of the reference's matrices (F * {256, 128, 128})
 };
 hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, int mode, const PredBatch &b, unsigned long long *sums_int, double *sums_dbl,
-                                 unsigned long long *out_of_range, hipStream_t stream, const FitSolve *solve = nullptr);
+                                 unsigned long long *out_of_range, hipStream_t stream, const FitSolve *solve = nullptr, int trust = 0 /* kPredAnyInt32; kPredForwardOutput: not checked, see launch_predict_histogram */);
 // The fit's 6 x 6 solves on the device: sums of a launch_fit_accumulate (mode 0: sums_int[n_planes][3][28]; mode 1: sums_int[n_planes][3][21],
 // sums_dbl[n_planes][3][6], rows[3] = heights of the reference's matrices) -> params[n_planes] (PredictParams: mode 0 writes .value, mode 1 .width).
 // host_params / host_range (device-visible pointers into mapped host memory, or NULL): the solving threads also leave the parameters - and the
