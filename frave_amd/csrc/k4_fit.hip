@@ -68,72 +68,113 @@ static_assert(kFitAccRange + 1 == (int)kFitAccWords, "fit accumulator layout");
 // accumulators per lane): level 8 is group 0; below, lanes 0..31 are group 2 (levels 0..6), lanes 32..63 group 1 (level 7).
 // Staging, tile walk and hand-over are the kernel above's.
 // ---------------------------------------------------------------------------------------------------------------------
-// The six neighbour values of the lane's two nodes in one cell, packed {first node, second node} per register. Plain loads: a d16 load
-// into one half of a register does not keep the other half on this chip (the register's unused half comes back as zero - d16 writes
-// are whole-register when the memories run with ECC), so two 16-bit loads and one v_lshl_or_b32 per packed operand it is.
+// The six neighbour values of the lane's two nodes in one cell, packed {first node, second node} per register (the value pass's int16 image). A d16 load into
+// one half of a register does not keep the other half on this chip (the register's unused half comes back as zero - d16 writes are whole-register when the
+// memories run with ECC), so the first node's value arrives through ds_read_u16 (zero-extended), the second node's through ds_read_u16_d16_hi (already shifted)
+// and one v_or_b32 (two issue cycles; v_perm_b32 or v_lshl_or_b32: four) makes the packed operand. One asm statement with its wait inside: the compiler does
+// not track these loads, and nothing of its own can come between them and their wait.
 template <int OFFSET>
 __device__ __forceinline__ void fit2_gather(uint32_t (&g)[6], const uint32_t (&a)[6], const uint32_t (&b)[6]) {
-    typedef __attribute__((address_space(3))) const uint16_t *lds_u16;
+    uint32_t lo[6], hi[6];
+    asm volatile("ds_read_u16 %0, %12 offset:%24\n\t"
+                 "ds_read_u16 %1, %13 offset:%24\n\t"
+                 "ds_read_u16 %2, %14 offset:%24\n\t"
+                 "ds_read_u16 %3, %15 offset:%24\n\t"
+                 "ds_read_u16 %4, %16 offset:%24\n\t"
+                 "ds_read_u16 %5, %17 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %6, %18 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %7, %19 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %8, %20 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %9, %21 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %10, %22 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %11, %23 offset:%24\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(lo[4]), "=&v"(lo[5]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]),
+                   "=&v"(hi[5])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "n"(OFFSET)
+                 : "memory");
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const uint32_t lo = *(lds_u16)(uintptr_t)(a[k] + OFFSET), hi = *(lds_u16)(uintptr_t)(b[k] + OFFSET);
-        g[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u); // v_perm_b32: the two low halves side by side
-    }
-    // The packing stays in the basic block of its loads: sunk below the boundary-mask branch that follows (where the packed values are first used), the
-    // compiler no longer knows that ds_read_u16 zero-extends and masks each of the twelve halves with 0xffff first - 12 of a pair's ~150 vector instructions.
-#pragma unroll
-    for (int k = 0; k < 6; k++) asm volatile("" : "+v"(g[k]));
+    for (int k = 0; k < 6; k++) g[k] = lo[k] | hi[k];
 }
 
-// One pair of nodes of one cell: 28 (value fit) or 21 + 6 (width fit) sums. g: the six packed neighbour values; own: the pair's own
-// values packed the same way; one: 1 per Some node of the pair, packed. A None row is all zeros in the reference (:109-134): the caller has masked g and own
-// (fit2_cell: boundary cells only - an interior cell has no None, and the one lane whose pair is not a row of the fit gathers zeros).
-template <int MODE>
-__device__ __forceinline__ void fit2_pair(const uint32_t (&g)[6], uint32_t own, uint32_t one_bits, const float (&vp)[6], int (&acc)[28], float (&facc)[6]) {
+// The width pass's gather: twelve halfwords that ARE the upper halves of floats (fit2_pack<true>), loaded straight into the upper halves of twelve registers
+// (ds_read_u16_d16_hi, the other half zero: see above); one asm statement with its wait inside, like fit2_gather.
+template <int OFFSET>
+__device__ __forceinline__ void fit2_gather_floats(uint32_t (&lo)[6], uint32_t (&hi)[6], const uint32_t (&a)[6], const uint32_t (&b)[6]) {
+    asm volatile("ds_read_u16_d16_hi %0, %12 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %1, %13 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %2, %14 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %3, %15 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %4, %16 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %5, %17 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %6, %18 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %7, %19 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %8, %20 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %9, %21 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %10, %22 offset:%24\n\t"
+                 "ds_read_u16_d16_hi %11, %23 offset:%24\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(lo[4]), "=&v"(lo[5]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]),
+                   "=&v"(hi[5])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "n"(OFFSET)
+                 : "memory");
+}
+
+// One pair of nodes of one cell, value fit: the 28 sums of [v0..v5, value] [v0..v5, value]^T. g: the six packed int16 neighbour values; own: the pair's own
+// values packed the same way. A None row is all zeros in the reference (:109-134): the caller has masked g and own (fit2_cell: boundary cells only - an
+// interior cell has no None, and the one lane whose pair is not a row of the fit gathers zeros).
+__device__ __forceinline__ void fit2_pair_value(const uint32_t (&g)[6], uint32_t own, int (&acc)[28]) {
     s16x2 u[7];
 #pragma unroll
     for (int k = 0; k < 6; k++) u[k] = __builtin_bit_cast(s16x2, g[k]);
     u[6] = __builtin_bit_cast(s16x2, own);
-    if (MODE == 0) {
-        int n = 0;
+    int n = 0;
 #pragma unroll
-        for (int r0 = 0; r0 < 7; r0++)
+    for (int r0 = 0; r0 < 7; r0++)
 #pragma unroll
-            for (int c0 = r0; c0 < 7; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(u[r0], u[c0], acc[n], false);
-    } else {
-        // residual r = |f32(value) - A x| in f32, left to right like nalgebra's gemv (context_modeling.rs:150-160), for both nodes; a None row
-        // has every u masked to 0, hence every feature, and contributes nothing
-        float fa[7], fb[7];
+        for (int c0 = r0; c0 < 7; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(u[r0], u[c0], acc[n], false);
+}
+
+// One pair of nodes of one cell, width fit: 21 integer sums W^T W and six f32 sums W^T r. The width pass stages the UPPER HALVES OF THE VALUES' FLOATS (K2's
+// image format: exact for |v| <= 256, the fit's precondition), so a gathered halfword is the float after one shift - the pass needs every value as a float
+// (the residual r = |f32(value) - A x| in f32, left to right like nalgebra's gemv, context_modeling.rs:150-160) and a conversion costs four issue cycles where a
+// shift, an f32 add or multiply cost two (tools/micro/valu_rate2.hip; with the int16 image of the value pass a pair spent 24 of its ~100 vector instructions
+// on v_cvt_f32_i32). The features w = [1, |v0-v3|, |v1-v2|, |v4-v5|, |v1-v5|, |v2-v4|] are exact f32 differences; their packed int16 form for v_dot2c comes out
+// of the mantissa: |d| + 2^23 holds the integer |d| <= 511 in its low bits. lo / hi: the first / second node's six neighbour values as floats (fit2_gather_floats); own: both
+// nodes' own halfwords; one_bits: 1 per Some node. A None row: everything masked to 0 by the caller, its residual is |0 - 0|.
+__device__ __forceinline__ void fit2_pair_width(const uint32_t (&lo)[6], const uint32_t (&hi)[6], uint32_t own, uint32_t one_bits, const float (&vp)[6], int (&acc)[28],
+                                                float (&facc)[6]) {
+    float fa[7], fb[7];
 #pragma unroll
-        for (int k = 0; k < 7; k++) fa[k] = (float)u[k].x, fb[k] = (float)u[k].y;
-        float pa = __fmul_rn(fa[0], vp[0]), pb = __fmul_rn(fb[0], vp[0]);
+    for (int k = 0; k < 6; k++) fa[k] = __builtin_bit_cast(float, lo[k]), fb[k] = __builtin_bit_cast(float, hi[k]);
+    fa[6] = __builtin_bit_cast(float, own << 16), fb[6] = __builtin_bit_cast(float, own & 0xFFFF0000u);
+    float pa = __fmul_rn(fa[0], vp[0]), pb = __fmul_rn(fb[0], vp[0]);
 #pragma unroll
-        for (int k = 1; k < 6; k++) pa = __fadd_rn(pa, __fmul_rn(fa[k], vp[k])), pb = __fadd_rn(pb, __fmul_rn(fb[k], vp[k]));
-        float ra = fabsf(__fsub_rn(fa[6], pa)), rb = fabsf(__fsub_rn(fb[6], pb));
-        // |r| in a register of its own (one v_and each): as a source modifier it would force the twelve multiply-adds below into the four-cycle VOP3 encoding
-        asm volatile("" : "+v"(ra), "+v"(rb));
-        // features w = [1, |v0-v3|, |v1-v2|, |v4-v5|, |v1-v5|, |v2-v4|]: packed int16 for the exact integer sums W^T W ...
-        auto absdiff = [&](int k0, int k1) {
-            const s16x2 d = u[k0] - u[k1];
-            return __builtin_elementwise_max(d, -d);
-        };
-        const s16x2 one = __builtin_bit_cast(s16x2, one_bits);
-        const s16x2 w[6] = {one, absdiff(0, 3), absdiff(1, 2), absdiff(4, 5), absdiff(1, 5), absdiff(2, 4)};
-        int n = 0;
+    for (int k = 1; k < 6; k++) pa = __fadd_rn(pa, __fmul_rn(fa[k], vp[k])), pb = __fadd_rn(pb, __fmul_rn(fb[k], vp[k]));
+    const float ra = fabsf(__fsub_rn(fa[6], pa)), rb = fabsf(__fsub_rn(fb[6], pb));
+    constexpr int kD0[5] = {0, 1, 4, 1, 2}, kD1[5] = {3, 2, 5, 5, 4};
+    float da[5], db[5];
 #pragma unroll
-        for (int r0 = 0; r0 < 6; r0++)
+    for (int j = 0; j < 5; j++) da[j] = fabsf(__fsub_rn(fa[kD0[j]], fa[kD1[j]])), db[j] = fabsf(__fsub_rn(fb[kD0[j]], fb[kD1[j]]));
+    s16x2 w[6];
+    w[0] = __builtin_bit_cast(s16x2, one_bits);
 #pragma unroll
-            for (int c0 = r0; c0 < 6; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(w[r0], w[c0], acc[n], false);
-        // ... and floats for W^T r: f32 partial sums over the nodes a lane has in a tile, 64-bit fixed point from there on (fit_f32_to_fixed). The
-        // features come from the packed integers (one conversion each; exact) and every product enters its sum through a fused multiply-add whose
-        // addend is the sum itself (v_fmac_f32, the two-cycle VOP2 form; a rounded product and an add are two instructions more per feature and node
-        // and no closer to the real sum). A None row's residual is |0 - 0|.
-        facc[0] = __fadd_rn(__fadd_rn(facc[0], ra), rb);
+    for (int j = 0; j < 5; j++) {
+        const uint32_t ia = __builtin_bit_cast(uint32_t, __fadd_rn(da[j], 8388608.0f)), ib = __builtin_bit_cast(uint32_t, __fadd_rn(db[j], 8388608.0f));
+        w[1 + j] = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(ib, ia, 0x05040100u));
+    }
+    int n = 0;
 #pragma unroll
-        for (int k = 1; k < 6; k++) {
-            facc[k] = __builtin_fmaf((float)w[k].x, ra, facc[k]);
-            facc[k] = __builtin_fmaf((float)w[k].y, rb, facc[k]);
-        }
+    for (int r0 = 0; r0 < 6; r0++)
+#pragma unroll
+        for (int c0 = r0; c0 < 6; c0++, n++) acc[n] = __builtin_amdgcn_sdot2(w[r0], w[c0], acc[n], false);
+    // W^T r: f32 partial sums over the nodes a lane has in a tile, 64-bit fixed point from there on (fit_f32_to_fixed); every product enters its sum through a
+    // fused multiply-add (a rounded product and an add are two instructions more per feature and node and no closer to the real sum)
+    facc[0] = __fadd_rn(__fadd_rn(facc[0], ra), rb);
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        facc[1 + j] = __builtin_fmaf(da[j], ra, facc[1 + j]);
+        facc[1 + j] = __builtin_fmaf(db[j], rb, facc[1 + j]);
     }
 }
 
@@ -163,9 +204,16 @@ __device__ __forceinline__ void fit2_block_load(Fit2Block &r, const int32_t *__r
         r.hi = src[1];
     }
 }
-template <bool CHECK>
+// FLOATS = false (value pass): a staged halfword is the value's int16 (the packed operands of v_dot2c_i32_i16). FLOATS = true (width pass): the upper half of
+// the value's float, K2's image format (fit2_pair_width); the conversion reads the low half of the dword sign-extended, so None (0x80000000) is 0 here too.
+template <bool FLOATS>
+__device__ __forceinline__ uint32_t fit2_pack(int first, int second) {
+    if (!FLOATS) return __builtin_amdgcn_perm((uint32_t)second, (uint32_t)first, 0x05040100u);
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, (float)(short)second), __builtin_bit_cast(uint32_t, (float)(short)first), 0x07060302u);
+}
+template <bool CHECK, bool FLOATS>
 __device__ __forceinline__ void fit2_block_commit(const Fit2Block &r, const int32_t *s_slot_cell, uint8_t *image, int slot, int lane, uint32_t *range_counter) {
-    auto pk = [](int lo16, int hi16) -> uint32_t { return __builtin_amdgcn_perm((uint32_t)hi16, (uint32_t)lo16, 0x05040100u); };
+    auto pk = [](int lo16, int hi16) -> uint32_t { return fit2_pack<FLOATS>(lo16, hi16); };
     const int4 lo = r.lo, hi = r.hi;
     if (CHECK && s_slot_cell[slot] >= 0) { // a None is 0x80000000: its low half stages as 0, and it is not an outlier
         const int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -188,8 +236,10 @@ __device__ __forceinline__ int fit2_halo_load(const int32_t *__restrict__ coefs,
     const int cell = skip ? -1 : s_slot_cell[entry & 63u];
     return cell >= 0 ? coefs[(size_t)cell * kCell + ((entry >> 8) & 511u)] : 0;
 }
+template <bool FLOATS>
 __device__ __forceinline__ void fit2_halo_commit(int v, uint8_t *image, uint32_t entry) {
-    *reinterpret_cast<short *>(image + (entry & 63u) * kSlotStride + 2u * ((entry >> 8) & 511u)) = (short)v; // None = INT32_MIN: low half 0 (unwrap_or(0))
+    const uint16_t h = FLOATS ? (uint16_t)(__builtin_bit_cast(uint32_t, (float)(short)v) >> 16) : (uint16_t)v; // None = INT32_MIN: low half 0 (unwrap_or(0))
+    *reinterpret_cast<uint16_t *>(image + (entry & 63u) * kSlotStride + 2u * ((entry >> 8) & 511u)) = h;
 }
 
 // has_bits / interior_bits: bit (C >> 2) * kPredSide + (C & 3) = "the wave's block cell C holds a retained cell" / "... an interior one" (the tile's slot table as
@@ -202,18 +252,33 @@ __device__ __forceinline__ void fit2_cell(const int32_t *s_slot_cell, uint32_t h
     constexpr int kOff = IMG * kFit2Image + kBit * kSlotStride;
     if (!((has_bits >> kBit) & 1u)) return;
     uint32_t own = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(own_addr + kOff);
-    uint32_t g[6];
-    fit2_gather<kOff>(g, addr[0], addr[1]);
     uint32_t one = keep & 0x00010001u;
-    if (!((interior_bits >> kBit) & 1u)) { // boundary cell: node p is bit (p & 31) of mask word p >> 5; a None node's row is all zeros
-        const int cell = __builtin_amdgcn_readfirstlane(s_slot_cell[slot0 + kBit]);
-        const uint32_t bits = mask_word[(size_t)cell * 16] >> mask_shift;
-        const uint32_t mask = ((bits & 1u) ? 0x0000FFFFu : 0u) | ((bits & 2u) ? 0xFFFF0000u : 0u);
+    const bool boundary = !((interior_bits >> kBit) & 1u); // boundary cell: node p is bit (p & 31) of mask word p >> 5; a None node's row is all zeros
+    if (MODE == 0) {
+        uint32_t g[6];
+        fit2_gather<kOff>(g, addr[0], addr[1]);
+        if (boundary) {
+            const int cell = __builtin_amdgcn_readfirstlane(s_slot_cell[slot0 + kBit]);
+            const uint32_t bits = mask_word[(size_t)cell * 16] >> mask_shift;
+            const uint32_t mask = ((bits & 1u) ? 0x0000FFFFu : 0u) | ((bits & 2u) ? 0xFFFF0000u : 0u);
 #pragma unroll
-        for (int k = 0; k < 6; k++) g[k] &= mask;
-        own &= mask, one &= mask;
+            for (int k = 0; k < 6; k++) g[k] &= mask;
+            own &= mask;
+        }
+        fit2_pair_value(g, own, acc);
+    } else {
+        uint32_t lo[6], hi[6];
+        fit2_gather_floats<kOff>(lo, hi, addr[0], addr[1]);
+        if (boundary) {
+            const int cell = __builtin_amdgcn_readfirstlane(s_slot_cell[slot0 + kBit]);
+            const uint32_t bits = mask_word[(size_t)cell * 16] >> mask_shift;
+            const uint32_t first = (bits & 1u) ? 0xFFFFFFFFu : 0u, second = (bits & 2u) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+            for (int k = 0; k < 6; k++) lo[k] &= first, hi[k] &= second;
+            own &= (first & 0xFFFFu) | (second << 16), one &= (first & 0xFFFFu) | (second << 16);
+        }
+        fit2_pair_width(lo, hi, own, one, vp, acc, facc);
     }
-    fit2_pair<MODE>(g, own, one, vp, acc, facc);
     asm volatile("" ::: "memory"); // one cell's gathers at a time: the next cell's would cost 13 more registers
 }
 template <int MODE, int IMG, int C0>
@@ -407,16 +472,16 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             const int hv = fit2_halo_load(coefs, s_slot_cell[IMG ^ 1], halo_e0, ablate & 2);                                                     \
             if (tid < kPredSlots && tile + 2 * walk.step < walk.end) next_raw = slot_entry(tile + 2 * walk.step);                                 \
             if (!(ablate & 1)) fit2_cells<MODE, IMG, 0>(s_slot_cell[IMG], has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
-            fit2_block_commit<CHECK>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_a, lane, &s_range);                              \
-            fit2_halo_commit(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e0);                                                                     \
+            fit2_block_commit<CHECK, MODE == 1>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_a, lane, &s_range);                              \
+            fit2_halo_commit<MODE == 1>(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e0);                                                                     \
         }                                                                                                                                        \
         {                                                                                                                                        \
             Fit2Block st;                                                                                                                        \
             fit2_block_load(st, coefs, s_slot_cell[IMG ^ 1], block_b, lane, ablate & 2);                                                         \
             const int hv = fit2_halo_load(coefs, s_slot_cell[IMG ^ 1], halo_e1, ablate & 2);                                                     \
             if (!(ablate & 1)) fit2_cells<MODE, IMG, 4>(s_slot_cell[IMG], has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
-            fit2_block_commit<CHECK>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_b, lane, &s_range);                              \
-            fit2_halo_commit(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e1);                                                                     \
+            fit2_block_commit<CHECK, MODE == 1>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_b, lane, &s_range);                              \
+            fit2_halo_commit<MODE == 1>(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e1);                                                                     \
         }                                                                                                                                        \
         if (MODE == 1) {                                                                                                                         \
             _Pragma("unroll") for (int k = 0; k < 6; k++) fx[k] += fit_f32_to_fixed(facc[k]);                                                    \
@@ -438,10 +503,10 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             fit2_block_load(sa, coefs, s_slot_cell[0], block_a, lane, false);
             fit2_block_load(sb, coefs, s_slot_cell[0], block_b, lane, false);
             const int h0 = fit2_halo_load(coefs, s_slot_cell[0], halo_e0, false), h1 = fit2_halo_load(coefs, s_slot_cell[0], halo_e1, false);
-            fit2_block_commit<CHECK>(sa, s_slot_cell[0], s_cells, block_a, lane, &s_range);
-            fit2_block_commit<CHECK>(sb, s_slot_cell[0], s_cells, block_b, lane, &s_range);
-            fit2_halo_commit(h0, s_cells, halo_e0);
-            fit2_halo_commit(h1, s_cells, halo_e1);
+            fit2_block_commit<CHECK, MODE == 1>(sa, s_slot_cell[0], s_cells, block_a, lane, &s_range);
+            fit2_block_commit<CHECK, MODE == 1>(sb, s_slot_cell[0], s_cells, block_b, lane, &s_range);
+            fit2_halo_commit<MODE == 1>(h0, s_cells, halo_e0);
+            fit2_halo_commit<MODE == 1>(h1, s_cells, halo_e1);
         }
         __syncthreads();
         trace_stamp(a0.trace, blockIdx.x, 1, tid);
