@@ -31,7 +31,8 @@ struct FitArgs {
     const uint32_t *valid_mask;
     uint32_t n_tiles;
     PredictParams pp;
-    const uint32_t *pred_off;  // [512][4] packed neighbour offsets per node (build_pred_offsets)
+    const uint32_t *pred_off;  // [512][4] packed neighbour BYTE offsets per node in K2's permuted 1 KiB cell layout (build_gather_tables)
+    const uint16_t *pair_pos;  // [256] dword position of a pair of sibling nodes inside a cell (gather_layout.inc)
     const uint32_t *halo_list; // [1024] the halo values a tile needs (build_halo_list), two per thread of kernel2
     unsigned long long *gram; // [3][28]   (MODE 0)
     unsigned long long *wtw;  // [3][21]   (MODE 1)
@@ -181,13 +182,19 @@ __device__ __forceinline__ void fit2_pair_width(const uint32_t (&lo)[6], const u
 // Staging in two steps, so that a tile's global loads fly while the tile before it is worked on: the loads (a block cell and a halo value per
 // step), and - behind half of the current tile's sums - the conversion to int16 and the LDS writes into the OTHER of two cell images. Layout and
 // range check are pred_stage_tile's (gather_common.hpp).
-constexpr int kFit2Image = kPredSlots * kSlotStride; // 37 440 B; image 1 sits behind image 0, inside the gathers' 16-bit offset field
-static_assert(kFit2Image + (kPredSide + kPredBlock) * kSlotStride < 65536, "image + cell offset must fit a DS instruction's offset field");
+// K2's cell geometry since round 4: 1 KiB per cell, pairs at gather_layout.inc's positions. (Rounds 2-3: 1040 bytes per cell - sixteen zero bytes behind each cell
+// for the "never a node" entries - which puts neighbouring cells four banks apart: 216 LDS cycles for the 48 gather instructions of a cell in heap order, 199 with
+// K2's pair positions, against 135 / 110 with cells 1 KiB apart, tools/lds_layout_search.py --k4. The zero those entries read is now heap node 0's halfword: the
+// DC value, which no node ever gathers and the fit has no row for, staged as 0.)
+constexpr int kFit2Slot = 1024;
+constexpr int kFit2Image = kPredSlots * kFit2Slot; // 36 864 B; image 1 sits behind image 0, inside the gathers' 16-bit offset field
+static_assert(kFit2Image + (kPredSide + kPredBlock) * kFit2Slot < 65536, "image + cell offset must fit a DS instruction's offset field");
 // Round 3: the same sparse halo as K2 (k2_predict.hip, build_halo_list). A tile's 16 block cells are staged whole - two per wave, one behind each
 // half of the current tile's sums - but of its 20 halo cells only the 902 values a 4 x 4 block ever gathers, two per thread: 45 KB of loads per
-// tile instead of 72, a third of the conversions. Values land in heap order at 2 bytes each (this kernel's layout), None as 0. (K2's annealed pair
-// positions inside a slot - this kernel's waves gather exactly the node patterns of K2's roles - were tried in round 3: the bank conflicts are not what
-// limits this kernel, 37.2 / 55.1 us either way, and the four scattered dword writes per lane cost the width pass its last free registers.)
+// tile instead of 72, a third of the conversions. Values land at K2's pair positions (gather_layout.inc; this kernel's waves gather exactly the node patterns
+// of K2's roles), two bytes each, None as 0. (Round 3 tried those positions with cells 1040 bytes apart and found nothing - 37.2 / 55.1 us either way: at that
+// distance they are worth 8 % of the gathers' LDS cycles, see kFit2Slot; with cells 1 KiB apart, bank conflicts went from 44 % to 18 % of the LDS-active cycles
+// and the value pass from 33.0 to 30.6 us.)
 struct Fit2Block {
     int4 lo, hi;
 };
@@ -212,7 +219,7 @@ __device__ __forceinline__ uint32_t fit2_pack(int first, int second) {
     return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, (float)(short)second), __builtin_bit_cast(uint32_t, (float)(short)first), 0x07060302u);
 }
 template <bool CHECK, bool FLOATS>
-__device__ __forceinline__ void fit2_block_commit(const Fit2Block &r, const int32_t *s_slot_cell, uint8_t *image, int slot, int lane, uint32_t *range_counter) {
+__device__ __forceinline__ void fit2_block_commit(const Fit2Block &r, const int32_t *s_slot_cell, uint8_t *image, int slot, int lane, uint32_t stage_pos, uint32_t *range_counter) {
     auto pk = [](int lo16, int hi16) -> uint32_t { return fit2_pack<FLOATS>(lo16, hi16); };
     const int4 lo = r.lo, hi = r.hi;
     if (CHECK && s_slot_cell[slot] >= 0) { // a None is 0x80000000: its low half stages as 0, and it is not an outlier
@@ -222,16 +229,13 @@ __device__ __forceinline__ void fit2_block_commit(const Fit2Block &r, const int3
         for (int j = 0; j < 8; j++) m |= v[j] == kNone ? 0u : ((uint32_t)v[j] + 256u) & 0xFFFFFE00u;
         if (__any(m != 0) && lane == 0) atomicAdd(range_counter, 1u);
     }
-    uint4 packed;
-    packed.x = pk(lo.x, lo.y);
-    packed.y = pk(lo.z, lo.w);
-    packed.z = pk(hi.x, hi.y);
-    packed.w = pk(hi.z, hi.w);
-    uint8_t *dst = image + slot * kSlotStride;
-    *reinterpret_cast<uint4 *>(dst + 16 * lane) = packed;
-    if (lane == 0) *reinterpret_cast<uint4 *>(dst + 1024) = make_uint4(0, 0, 0, 0);
+    uint8_t *dst = image + slot * kFit2Slot;
+    *reinterpret_cast<uint32_t *>(dst + 4u * (stage_pos & 255u)) = pk(lo.x, lo.y) & (lane == 0 ? 0xFFFF0000u : 0xFFFFFFFFu); // heap node 0: the cell's zero (see kFit2Slot)
+    *reinterpret_cast<uint32_t *>(dst + 4u * ((stage_pos >> 8) & 255u)) = pk(lo.z, lo.w);
+    *reinterpret_cast<uint32_t *>(dst + 4u * ((stage_pos >> 16) & 255u)) = pk(hi.x, hi.y);
+    *reinterpret_cast<uint32_t *>(dst + 4u * (stage_pos >> 24)) = pk(hi.z, hi.w);
 }
-// one halo value: entry = slot | heap << 8 (build_halo_list; threads without an entry stage into the unused corner slot 0)
+// one halo value: entry = slot | heap << 8 | byte position inside the cell << 20 (build_halo_list; threads without an entry stage into the unused corner slot 0)
 __device__ __forceinline__ int fit2_halo_load(const int32_t *__restrict__ coefs, const int32_t *s_slot_cell, uint32_t entry, bool skip) {
     const int cell = skip ? -1 : s_slot_cell[entry & 63u];
     return cell >= 0 ? coefs[(size_t)cell * kCell + ((entry >> 8) & 511u)] : 0;
@@ -239,7 +243,7 @@ __device__ __forceinline__ int fit2_halo_load(const int32_t *__restrict__ coefs,
 template <bool FLOATS>
 __device__ __forceinline__ void fit2_halo_commit(int v, uint8_t *image, uint32_t entry) {
     const uint16_t h = FLOATS ? (uint16_t)(__builtin_bit_cast(uint32_t, (float)(short)v) >> 16) : (uint16_t)v; // None = INT32_MIN: low half 0 (unwrap_or(0))
-    *reinterpret_cast<uint16_t *>(image + (entry & 63u) * kSlotStride + 2u * ((entry >> 8) & 511u)) = h;
+    *reinterpret_cast<uint16_t *>(image + (entry & 63u) * kFit2Slot + (entry >> 20)) = h; // (bits 20+: the value's byte position inside its cell)
 }
 
 // has_bits / interior_bits: bit (C >> 2) * kPredSide + (C & 3) = "the wave's block cell C holds a retained cell" / "... an interior one" (the tile's slot table as
@@ -249,9 +253,9 @@ template <int MODE, int IMG, int C>
 __device__ __forceinline__ void fit2_cell(const int32_t *s_slot_cell, uint32_t has_bits, uint32_t interior_bits, const uint32_t *mask_word, uint32_t mask_shift, uint32_t keep, int slot0,
                                           const uint32_t (&addr)[2][6], uint32_t own_addr, const float (&vp)[6], int (&acc)[28], float (&facc)[6]) {
     constexpr int kBit = (C >> 2) * kPredSide + (C & 3);
-    constexpr int kOff = IMG * kFit2Image + kBit * kSlotStride;
+    constexpr int kOff = IMG * kFit2Image + kBit * kFit2Slot;
     if (!((has_bits >> kBit) & 1u)) return;
-    uint32_t own = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(own_addr + kOff);
+    uint32_t own = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(own_addr + kOff) & keep; // (keep: 0 for the one lane whose pair is heap nodes 0 and 1)
     uint32_t one = keep & 0x00010001u;
     const bool boundary = !((interior_bits >> kBit) & 1u); // boundary cell: node p is bit (p & 31) of mask word p >> 5; a None node's row is all zeros
     if (MODE == 0) {
@@ -392,15 +396,18 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         const u32x4 o = reinterpret_cast<const u32x4 *>(a0.pred_off)[n0 + j];
         const uint32_t rel[3] = {o.x, o.y, o.z};
 #pragma unroll
-        for (int k = 0; k < 6; k++) addr[j][k] = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * (int)(short)((rel[k >> 1] >> (16 * (k & 1))) & 0xFFFFu));
+        for (int k = 0; k < 6; k++) {
+            // K2's table: byte offset from the own cell, 0x7FFF = never a node: the own cell's first halfword (heap node 0, staged as 0)
+            const int r = (int)(short)((rel[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+            addr[j][k] = cells_lds + (uint32_t)(slot0 * kFit2Slot + (r == 0x7FFF ? 0 : r));
+        }
     }
-    uint32_t own_addr = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * n0);
-    if (n0 == 0) { // heap nodes 0 and 1 are not rows of the fit: that lane reads the zero words behind its cell (fit2_block_commit), a row of zeros like a None's
+    uint32_t own_addr = cells_lds + (uint32_t)(slot0 * kFit2Slot) + 4u * a0.pair_pos[n0 >> 1];
+    if (n0 == 0) { // heap nodes 0 and 1 are not rows of the fit: that lane gathers the zero at the head of its cell, and its own pair is masked (keep)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int k = 0; k < 6; k++) addr[j][k] = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * kCell);
-        own_addr = cells_lds + (uint32_t)(slot0 * kSlotStride + 2 * kCell);
+            for (int k = 0; k < 6; k++) addr[j][k] = cells_lds + (uint32_t)(slot0 * kFit2Slot);
     }
     // the pair's two bits of a boundary cell's mask (node p is bit p & 31 of word p >> 5); heap index 0 and 1 are coded by the LF predictor
     // and are not rows of the fit
@@ -419,6 +426,8 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     int tiles_since_flush = 0, trace_it = 0;
     // the thread's two halo values per tile; entries >= 1024 - 122 of the list stage into the unused corner slot, where two of them may meet: harmless
     const uint32_t halo_e0 = a0.halo_list[tid], halo_e1 = a0.halo_list[tid + kPredThreads];
+    // where the four pairs a lane stages of a block cell (heap nodes 8 lane .. 8 lane + 7) live inside the cell: dword positions, one byte each
+    const uint32_t stage_pos = (uint32_t)a0.pair_pos[4 * lane] | (uint32_t)a0.pair_pos[4 * lane + 1] << 8 | (uint32_t)a0.pair_pos[4 * lane + 2] << 16 | (uint32_t)a0.pair_pos[4 * lane + 3] << 24;
     const int block_a = fit2_block_slot(wave, 0), block_b = fit2_block_slot(wave, 1);
 
     const int ablate = ablate_flags(a0.ablate);
@@ -472,7 +481,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             const int hv = fit2_halo_load(coefs, s_slot_cell[IMG ^ 1], halo_e0, ablate & 2);                                                     \
             if (tid < kPredSlots && tile + 2 * walk.step < walk.end) next_raw = slot_entry(tile + 2 * walk.step);                                 \
             if (!(ablate & 1)) fit2_cells<MODE, IMG, 0>(s_slot_cell[IMG], has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
-            fit2_block_commit<CHECK, MODE == 1>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_a, lane, &s_range);                              \
+            fit2_block_commit<CHECK, MODE == 1>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_a, lane, stage_pos, &s_range);                              \
             fit2_halo_commit<MODE == 1>(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e0);                                                                     \
         }                                                                                                                                        \
         {                                                                                                                                        \
@@ -480,7 +489,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             fit2_block_load(st, coefs, s_slot_cell[IMG ^ 1], block_b, lane, ablate & 2);                                                         \
             const int hv = fit2_halo_load(coefs, s_slot_cell[IMG ^ 1], halo_e1, ablate & 2);                                                     \
             if (!(ablate & 1)) fit2_cells<MODE, IMG, 4>(s_slot_cell[IMG], has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
-            fit2_block_commit<CHECK, MODE == 1>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_b, lane, &s_range);                              \
+            fit2_block_commit<CHECK, MODE == 1>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_b, lane, stage_pos, &s_range);                              \
             fit2_halo_commit<MODE == 1>(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e1);                                                                     \
         }                                                                                                                                        \
         if (MODE == 1) {                                                                                                                         \
@@ -503,8 +512,8 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             fit2_block_load(sa, coefs, s_slot_cell[0], block_a, lane, false);
             fit2_block_load(sb, coefs, s_slot_cell[0], block_b, lane, false);
             const int h0 = fit2_halo_load(coefs, s_slot_cell[0], halo_e0, false), h1 = fit2_halo_load(coefs, s_slot_cell[0], halo_e1, false);
-            fit2_block_commit<CHECK, MODE == 1>(sa, s_slot_cell[0], s_cells, block_a, lane, &s_range);
-            fit2_block_commit<CHECK, MODE == 1>(sb, s_slot_cell[0], s_cells, block_b, lane, &s_range);
+            fit2_block_commit<CHECK, MODE == 1>(sa, s_slot_cell[0], s_cells, block_a, lane, stage_pos, &s_range);
+            fit2_block_commit<CHECK, MODE == 1>(sb, s_slot_cell[0], s_cells, block_b, lane, stage_pos, &s_range);
             fit2_halo_commit<MODE == 1>(h0, s_cells, halo_e0);
             fit2_halo_commit<MODE == 1>(h1, s_cells, halo_e1);
         }
@@ -668,7 +677,8 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
     for (int k = 0; k < 3; k++) a.pp3[k] = b.pp[k];
     a.pred_slots = p.pred_slots;
     a.nbr_table = p.nbr_table;
-    a.pred_off = p.pred_off;
+    a.pred_off = p.gather_off;
+    a.pair_pos = p.pair_pos;
     a.halo_list = p.halo_list;
     a.interior = p.interior;
     a.valid_mask = p.valid_mask;

@@ -49,7 +49,10 @@ def group_nodes(g):
 
 
 class Layout:
-    def __init__(self, table):
+    def __init__(self, table, slot_dwords=SLOT_HW // 2, fit_writes=False):
+        """slot_dwords: distance of two cells in LDS (K2: 256 = 1 KiB; K4: 260 - its cells carry their zero words behind them, so neighbouring cells are
+        four banks apart). fit_writes: K4's staging writes (lane L writes pairs 4 L + w, w = 0..3) instead of K2's."""
+        self.slot_dwords = slot_dwords
         self.pair_pos = list(range(256))  # pair q = heap nodes 2q, 2q+1 -> dword position inside the slot
         self.desc = []                    # [group][k] -> list of (slot offset in dwords, pair, or -1 = "never a node": the zero word)
         for g in range(16):
@@ -58,7 +61,7 @@ class Layout:
                 lst = []
                 for p in group_nodes(g):
                     h, s, nv = table[p][k]
-                    lst.append((None, -1) if nv else ((DA[s] * SIDE + DB[s]) * (SLOT_HW // 2), h >> 1))
+                    lst.append((None, -1) if nv else ((DA[s] * SIDE + DB[s]) * slot_dwords, h >> 1))
                 row.append(lst)
             self.desc.append(row)
         # staging writes (ds_write_b32, one pair per lane and instruction, two lane groups each). Halo cells: instruction w of a wave
@@ -66,6 +69,8 @@ class Layout:
         # role-0 waves stage pairs L and 64 + L of their own cells (w = 4, 5); quarter cells: pair 64 q + L (w = 6..9, the first two
         # coincide with w = 4, 5)
         def wpairs(w, lane):
+            if fit_writes:
+                return 4 * lane + (w & 3)
             return 2 * lane + (w & 1) + 128 * (w >> 1) if w < 4 else 64 * (w - 4) + lane
         self.wdesc = [[[wpairs(w, lane) for lane in range(32 * half, 32 * half + 32)] for half in range(2)] for w in range(8)]
         self.refs = [set() for _ in range(256)]
@@ -83,7 +88,7 @@ class Layout:
         banks = {}
         if key[0] == "g":
             for so, q in self.desc[key[1]][key[2]]:
-                a = 10 ** 6 if q < 0 else so + self.pair_pos[q] + 100 * SLOT_HW
+                a = 10 ** 6 if q < 0 else so + self.pair_pos[q] + 100 * self.slot_dwords * 32
                 banks.setdefault(a & 31, set()).add(a)
             mx = max(len(s) for s in banks.values())
             return mx + 0.02 * sum(len(s) - 1 for s in banks.values())
@@ -138,8 +143,20 @@ def main():
     ap.add_argument("--iters", type=int, default=600000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--write", action="store_true")
+    ap.add_argument("--k4", action="store_true", help="K4's geometry: cells 1040 B apart, its staging writes; evaluates heap order, K2's layout and an annealed one (never written)")
     args = ap.parse_args()
     table = load_table()
+    if args.k4:
+        lay = Layout(table, 260, True)
+        gathers = lambda l: sum(int(l.cost(("g", g, k))) for g in range(16) for k in range(6))
+        print(f"K4 geometry, heap order: {gathers(lay)} LDS cycles for the 48 gather instructions of a cell (conflict-free: 96)")
+        inc = open(os.path.join(ROOT, "frave_amd", "csrc", "gather_layout.inc")).read()
+        lay.pair_pos = [int(v) for v in "".join(l for l in inc.splitlines() if not l.startswith("//")).replace(" ", "").split(",") if v]
+        print(f"K4 geometry, K2's layout: {gathers(lay)} LDS cycles")
+        lay.pair_pos = list(range(256))
+        cycles, wmax = anneal(lay, args.iters, args.seed)
+        print(f"K4 geometry, annealed for it: {cycles} LDS cycles; staging writes at most {wmax}-way on a bank")
+        return
     lay = Layout(table)
     base = sum(int(lay.cost(("g", g, k))) for g in range(16) for k in range(6))
     print(f"heap order: {base} LDS cycles for the 48 gather instructions of a cell (conflict-free: 96)")
