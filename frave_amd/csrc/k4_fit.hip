@@ -378,6 +378,46 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg = wave & 3, half = wave >> 2;
+    const int n0 = pg == 0 ? 128 + 2 * lane : pg == 1 ? 2 * lane : 256 + 4 * lane + 2 * (pg & 1);
+    const int ablate = ablate_flags(a0.ablate);
+    PredTileWalk walk(a0.n_tiles);
+    // Two workgroups share a CU, and the one dispatched first keeps most of its issue slots (older waves win the arbitration): per-workgroup time
+    // stamps showed the second one taking 8-9 us per tile beside 4.7 us for the first, then running its last tiles alone on the CU - at the lower
+    // rate of a half-empty CU - long after the first had finished. As in K1 the split follows the dispatch rank: workgroups b and b + gridDim / 2
+    // (the pair of one CU under in-order dispatch; a wrong guess costs speed, never correctness) walk ONE strided sequence of tiles, the older one
+    // its first older_eighths / 8, the younger one the rest.
+    if (a0.older_eighths > 0 && gridDim.x >= 16u && gridDim.x % 16u == 0u) {
+        const uint32_t per_xcd = gridDim.x / 8u, pairs = per_xcd / 2u;                     // workgroups / pairs per XCD range
+        const uint32_t xcd = blockIdx.x % 8u, in_xcd = blockIdx.x / 8u, pair = in_xcd % pairs, younger = in_xcd / pairs;
+        const uint32_t lo = (uint32_t)((uint64_t)a0.n_tiles * xcd / 8u), hi = (uint32_t)((uint64_t)a0.n_tiles * (xcd + 1u) / 8u);
+        const uint32_t n_pair = lo + pair < hi ? (hi - lo - pair + pairs - 1u) / pairs : 0u; // tiles of the pair: lo + pair + pairs * k
+        const uint32_t n_older = min(n_pair, (n_pair * (uint32_t)a0.older_eighths + 3u) / 8u);
+        walk.step = pairs;
+        walk.first = lo + pair + (younger ? n_older * pairs : 0u);
+        walk.end = younger ? hi : min(hi, lo + pair + n_older * pairs);
+        if (walk.first > walk.end) walk.first = walk.end;
+    }
+    // Entry `tid` of a tile's slot list: uniform row address + the lane's 32-bit offset, made opaque so that it is formed where it is used - as a loop
+    // invariant it is a 64-bit per-lane pointer, two registers the width pass does not have: spilled, and reloaded once per tile behind an s_waitcnt vmcnt(0),
+    // i.e. behind the staging loads wave 0 had just issued.
+    auto slot_entry = [&](uint32_t t) {
+        uint32_t off = (uint32_t)tid * 4u;
+        asm volatile("" : "+v"(off));
+        return *reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(a0.pred_slots + (size_t)t * kPredSlots) + off);
+    };
+    // EVERYTHING the prologue reads from global memory that does not depend on other loads is requested here, in one go: the lane's neighbour offsets and pair
+    // positions, its halo entries, the slot lists of the workgroup's first two tiles. Read where they were first used they were three dependent round trips in
+    // front of the first tile's coefficients (offsets; halo entries; the first slot list, waited for on the spot): the prologue's 4.9 us are 3.9 now.
+    const u32x4 off_a = reinterpret_cast<const u32x4 *>(a0.pred_off)[n0], off_b = reinterpret_cast<const u32x4 *>(a0.pred_off)[n0 + 1];
+    const uint32_t own_pos = a0.pair_pos[n0 >> 1];
+    // the thread's two halo values per tile; entries >= 1024 - 122 of the list stage into the unused corner slot, where two of them may meet: harmless
+    const uint32_t halo_e0 = a0.halo_list[tid], halo_e1 = a0.halo_list[tid + kPredThreads];
+    // where the four pairs a lane stages of a block cell (heap nodes 8 lane .. 8 lane + 7) live inside the cell: dword positions, one byte each
+    const uint32_t stage_pos = (uint32_t)a0.pair_pos[4 * lane] | (uint32_t)a0.pair_pos[4 * lane + 1] << 8 | (uint32_t)a0.pair_pos[4 * lane + 2] << 16 | (uint32_t)a0.pair_pos[4 * lane + 3] << 24;
+    int first_raw = -1, next_raw = -1; // thread t < 36: slot t of the workgroup's first tile / of the tile after the current one, requested a tile ahead
+    if (tid < kPredSlots && walk.first < walk.end) first_raw = slot_entry(walk.first);
+    if (tid < kPredSlots && walk.first + walk.step < walk.end) next_raw = slot_entry(walk.first + walk.step);
+    __builtin_amdgcn_sched_barrier(0); // (all of the above is in flight before anything below looks at a loaded value)
     if (tid < 4 * 3 * 28) (&s_int[0][0])[tid] = 0;
     if (tid < 16 * 18) (&s_fix[0][0])[tid] = 0ull;
     if (tid == 0) s_range = 0;
@@ -386,14 +426,13 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     // The wave's pair of nodes per lane: wave & 3 = 0: level 7 (128 + 2 lane, + 1), 1: levels 0..6 (2 lane, + 1), 2 and 3: level 8 (256 + 4 lane +
     // {0, 1} and {2, 3}) - one layer group per wave, so the value parameters are scalars and a wave's sums have one destination.
     // Loop invariants of the lane: LDS addresses (first of the wave's eight cells) of the six neighbours of its two nodes, and of the pair itself.
-    const int n0 = pg == 0 ? 128 + 2 * lane : pg == 1 ? 2 * lane : 256 + 4 * lane + 2 * (pg & 1);
     const int group = pg == 0 ? 1 : pg == 1 ? 2 : 0;
     const int slot0 = (1 + 2 * half) * kPredSide + 1; // first block cell of the wave's two block rows
     const uint32_t cells_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_cells;
     uint32_t addr[2][6];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        const u32x4 o = reinterpret_cast<const u32x4 *>(a0.pred_off)[n0 + j];
+        const u32x4 o = j == 0 ? off_a : off_b;
         const uint32_t rel[3] = {o.x, o.y, o.z};
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -402,7 +441,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             addr[j][k] = cells_lds + (uint32_t)(slot0 * kFit2Slot + (r == 0x7FFF ? 0 : r));
         }
     }
-    uint32_t own_addr = cells_lds + (uint32_t)(slot0 * kFit2Slot) + 4u * a0.pair_pos[n0 >> 1];
+    uint32_t own_addr = cells_lds + (uint32_t)(slot0 * kFit2Slot) + 4u * own_pos;
     if (n0 == 0) { // heap nodes 0 and 1 are not rows of the fit: that lane gathers the zero at the head of its cell, and its own pair is masked (keep)
 #pragma unroll
         for (int j = 0; j < 2; j++)
@@ -424,41 +463,10 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
 #pragma unroll
     for (int k = 0; k < 6; k++) fx[k] = 0ull;
     int tiles_since_flush = 0, trace_it = 0;
-    // the thread's two halo values per tile; entries >= 1024 - 122 of the list stage into the unused corner slot, where two of them may meet: harmless
-    const uint32_t halo_e0 = a0.halo_list[tid], halo_e1 = a0.halo_list[tid + kPredThreads];
-    // where the four pairs a lane stages of a block cell (heap nodes 8 lane .. 8 lane + 7) live inside the cell: dword positions, one byte each
-    const uint32_t stage_pos = (uint32_t)a0.pair_pos[4 * lane] | (uint32_t)a0.pair_pos[4 * lane + 1] << 8 | (uint32_t)a0.pair_pos[4 * lane + 2] << 16 | (uint32_t)a0.pair_pos[4 * lane + 3] << 24;
     const int block_a = fit2_block_slot(wave, 0), block_b = fit2_block_slot(wave, 1);
 
-    const int ablate = ablate_flags(a0.ablate);
-    PredTileWalk walk(a0.n_tiles);
-    // Two workgroups share a CU, and the one dispatched first keeps most of its issue slots (older waves win the arbitration): per-workgroup time
-    // stamps showed the second one taking 8-9 us per tile beside 4.7 us for the first, then running its last tiles alone on the CU - at the lower
-    // rate of a half-empty CU - long after the first had finished. As in K1 the split follows the dispatch rank: workgroups b and b + gridDim / 2
-    // (the pair of one CU under in-order dispatch; a wrong guess costs speed, never correctness) walk ONE strided sequence of tiles, the older one
-    // its first older_eighths / 8, the younger one the rest.
-    if (a0.older_eighths > 0 && gridDim.x >= 16u && gridDim.x % 16u == 0u) {
-        const uint32_t per_xcd = gridDim.x / 8u, pairs = per_xcd / 2u;                     // workgroups / pairs per XCD range
-        const uint32_t xcd = blockIdx.x % 8u, in_xcd = blockIdx.x / 8u, pair = in_xcd % pairs, younger = in_xcd / pairs;
-        const uint32_t lo = (uint32_t)((uint64_t)a0.n_tiles * xcd / 8u), hi = (uint32_t)((uint64_t)a0.n_tiles * (xcd + 1u) / 8u);
-        const uint32_t n_pair = lo + pair < hi ? (hi - lo - pair + pairs - 1u) / pairs : 0u; // tiles of the pair: lo + pair + pairs * k
-        const uint32_t n_older = min(n_pair, (n_pair * (uint32_t)a0.older_eighths + 3u) / 8u);
-        walk.step = pairs;
-        walk.first = lo + pair + (younger ? n_older * pairs : 0u);
-        walk.end = younger ? hi : min(hi, lo + pair + n_older * pairs);
-        if (walk.first > walk.end) walk.first = walk.end;
-    }
     uint32_t tile = walk.first;
-    int next_raw = -1; // thread t < 36: slot t of the tile after the current one, requested a tile ahead
     static_assert((kPredBlock * kPredSide + kPredBlock) < 32 && kPredSlots <= 64, "the block slots' bits fit one word; the slot table is written by one wave");
-    // Entry `tid` of a tile's slot list: uniform row address + the lane's 32-bit offset, made opaque so that it is formed where it is used - as a loop
-    // invariant it is a 64-bit per-lane pointer, two registers the width pass does not have: spilled, and reloaded once per tile behind an s_waitcnt vmcnt(0),
-    // i.e. behind the staging loads wave 0 had just issued.
-    auto slot_entry = [&](uint32_t t) {
-        uint32_t off = (uint32_t)tid * 4u;
-        asm volatile("" : "+v"(off));
-        return *reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(a0.pred_slots + (size_t)t * kPredSlots) + off);
-    };
     auto slot_table = [&](int img, int raw) { // (threads 0..kPredSlots-1: lanes of wave 0, so the ballots are the table)
         s_slot_cell[img][tid] = pred_slot_cell(raw);
         const unsigned long long has = __ballot(pred_slot_cell(raw) >= 0), interior = __ballot(pred_slot_interior(raw));
@@ -504,8 +512,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         tile += walk.step;                                                                                                                       \
     }
     if (tile < walk.end) {
-        if (tid < kPredSlots) slot_table(0, slot_entry(tile));
-        if (tid < kPredSlots && tile + walk.step < walk.end) next_raw = slot_entry(tile + walk.step);
+        if (tid < kPredSlots) slot_table(0, first_raw);
         __syncthreads();
         {
             Fit2Block sa, sb;
