@@ -510,8 +510,6 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         DevicePlan &d = p->dev;
         int rc = FRI_HIP_OK;
         std::vector<uint16_t> tab(&st.nbr_table[0][0], &st.nbr_table[0][0] + kCell * 6);
-        std::vector<uint32_t> pred_off((size_t)kCell * 4);
-        build_pred_offsets(tab.data(), pred_off.data());
         std::vector<uint32_t> gather_off((size_t)kCell * 4);
         std::vector<uint16_t> pair_pos(256), heap_of_pos(kCell);
         build_gather_tables(tab.data(), gather_off.data(), pair_pos.data(), heap_of_pos.data());
@@ -527,7 +525,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         }
         if ((rc = upload(p, g.tiles, d.tiles)) || (rc = upload(p, g.tile_cells, d.tile_cells)) || (rc = upload(p, g.tile_meta, d.tile_meta)) || (rc = upload(p, g.wg_tiles, d.wg_tiles)) || (rc = upload(p, g.wg_tiles_batch, d.wg_tiles_batch)) || (rc = upload(p, g.centers, d.centers)) ||
             (rc = upload(p, g.interior, d.interior)) || (rc = upload(p, g.valid_mask, d.valid_mask)) ||
-            (rc = upload(p, g.nbr_cells, d.nbr_cells)) || (rc = upload(p, g.pred_slots, d.pred_slots)) || (rc = upload(p, tab, d.nbr_table)) || (rc = upload(p, pred_off, d.pred_off)) ||
+            (rc = upload(p, g.nbr_cells, d.nbr_cells)) || (rc = upload(p, g.pred_slots, d.pred_slots)) || (rc = upload(p, tab, d.nbr_table)) ||
             (rc = upload(p, gather_off, d.gather_off)) || (rc = upload(p, pair_pos, d.pair_pos)) || (rc = upload(p, heap_of_pos, d.heap_of_pos)) ||
             (rc = upload(p, halo_list, d.halo_list))) {
             fri_hip_plan_destroy(p);

@@ -46,8 +46,7 @@ struct PredArgs {
     const int32_t *coefs;      // one channel plane [F][512]
     const int32_t *pred_slots; // [n_tiles][kPredSlots]
     const uint16_t *nbr_table; // [512][6]
-    const uint32_t *pred_off;  // [512][4] packed neighbour offsets of every node: halfwords from the own slot at stride 1040 for the earlier kernels
-                               // (build_pred_offsets), bytes from the own slot in the permuted 1 KiB layout for kernel3 (build_gather_tables)
+    const uint32_t *pred_off;  // [512][4] packed neighbour offsets of every node: bytes from the own slot in the permuted 1 KiB layout (build_gather_tables)
     const uint16_t *pair_pos;  // [256] dword position of halfword pair q inside a 1 KiB slot (gather_layout.inc)
     const uint16_t *heap_of_pos; // [512] its inverse per halfword: heap index stored at halfword position i
     const uint32_t *halo_list; // [kP3Threads] the halo values a tile needs, one per thread (build_halo_list)
@@ -896,23 +895,14 @@ void build_lf_deltas(const uint16_t *nbr_table, int8_t *out /* [8] */) {
     for (int node = 0; node < 2; node++)
         for (int k = 0; k < 3; k++) {
             const uint32_t e = nbr_table[node * 6 + k];
-            const int s7 = (e >> 9) & 7; // index into {self, +V9[0..5]}: lattice deltas as in pred_offsets_from_row
+            const int s7 = (e >> 9) & 7; // index into {self, +V9[0..5]}: lattice deltas as in build_gather_tables
             const int da = (int)((0x0F14u >> (2 * s7)) & 3u), db = (int)((0x14F0u >> (2 * s7)) & 3u);
             out[node * 3 + k] = (e & 0x8000u) ? (int8_t)kLfNever : (int8_t)(((da & 1) - (da & 2)) * kPredSide + ((db & 1) - (db & 2)));
         }
     out[6] = out[7] = 0;
 }
 
-void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out) {
-    for (int p = 0; p < kCell; p++) {
-        uint32_t row[3], o[3];
-        std::memcpy(row, nbr_table + p * 6, sizeof(row));
-        pred_offsets_from_row(row, o);
-        out[4 * p] = o[0], out[4 * p + 1] = o[1], out[4 * p + 2] = o[2], out[4 * p + 3] = 0;
-    }
-}
-
-// The permuted 1 KiB cell layout of kernel3 (and of the fit kernels once they move to it): pair_pos from gather_layout.inc, its
+// The permuted 1 KiB cell layout of kernel3 and - since round 4 - of the fit kernels: pair_pos from gather_layout.inc, its
 // inverse, and per node the six neighbour offsets in bytes from the own slot (0x7FFF = "never a node": the image's zero word).
 void build_gather_tables(const uint16_t *nbr_table, uint32_t *gather_off /* [512][4] */, uint16_t *pair_pos /* [256] */, uint16_t *heap_of_pos /* [512] */) {
     static const uint16_t kPairPos[256] = {
@@ -986,7 +976,6 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, uint32_t
     for (int k = 0; k < 3; k++) a.pp3[k] = b.pp[k];
     a.pred_slots = p.pred_slots;
     a.nbr_table = p.nbr_table;
-    a.pred_off = p.pred_off;
     a.interior = p.interior;
     a.valid_mask = p.valid_mask;
     a.bucket = bucket;

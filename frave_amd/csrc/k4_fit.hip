@@ -180,8 +180,7 @@ __device__ __forceinline__ void fit2_pair_width(const uint32_t (&lo)[6], const u
 }
 
 // Staging in two steps, so that a tile's global loads fly while the tile before it is worked on: the loads (a block cell and a halo value per
-// step), and - behind half of the current tile's sums - the conversion to int16 and the LDS writes into the OTHER of two cell images. Layout and
-// range check are pred_stage_tile's (gather_common.hpp).
+// step), and - behind half of the current tile's sums - the conversion and the LDS writes into the OTHER of two cell images.
 // K2's cell geometry since round 4: 1 KiB per cell, pairs at gather_layout.inc's positions. (Rounds 2-3: 1040 bytes per cell - sixteen zero bytes behind each cell
 // for the "never a node" entries - which puts neighbouring cells four banks apart: 216 LDS cycles for the 48 gather instructions of a cell in heap order, 199 with
 // K2's pair positions, against 135 / 110 with cells 1 KiB apart, tools/lds_layout_search.py --k4. The zero those entries read is now heap node 0's halfword: the

@@ -29,7 +29,6 @@ struct DevicePlan {
     const uint32_t *valid_mask = nullptr; // [F][16]
     const int32_t *nbr_cells = nullptr;   // [F][kNbr]
     const uint16_t *nbr_table = nullptr;  // [512][6]
-    const uint32_t *pred_off = nullptr;   // [512][4] K2's packed LDS offsets per node, derived from nbr_table
     const uint32_t *gather_off = nullptr; // [512][4] the same in bytes for the permuted 1 KiB cell layout (build_gather_tables)
     const uint16_t *pair_pos = nullptr;   // [256] gather_layout.inc
     const uint16_t *heap_of_pos = nullptr; // [512]
@@ -139,7 +138,6 @@ hipError_t launch_symbol_stream(const uint32_t *order, uint64_t n_symbols, uint3
                                 const int32_t *prediction, size_t out_stride, uint16_t *out, size_t stream_stride, hipStream_t stream);
 
 // K2's per-node neighbour offsets (LDS halfword offsets relative to the own slot, two per word) from the static neighbour table
-void build_pred_offsets(const uint16_t *nbr_table, uint32_t *out /* [512][4] */);
 void build_lf_deltas(const uint16_t *nbr_table, int8_t *out /* [8] */);
 void build_gather_tables(const uint16_t *nbr_table, uint32_t *gather_off /* [512][4] */, uint16_t *pair_pos /* [256] */, uint16_t *heap_of_pos /* [512] */);
 // K2's sparse halo staging: the (halo slot, heap node) pairs a 4 x 4 block ever gathers, one per thread of its 1024-thread workgroup (0xFFFFFFFF = none)
