@@ -69,6 +69,12 @@ def kernels(w, h, c, slots, label):
 
     k2 = timed(lambda: P.predict_histogram_dev(co(), 0, vp, wp, pb, pp, ph, po, stream=s), 30)
     line("K2 predict+histogram (per channel)", k2, w * h, F * 512 * 9 + 40960)
+    # the same with the caller's promise that the planes are the forward kernel's output (fri_hip_plan_assume_forward_coefficients: still checked, no exact
+    # kernel behind it) - what a host that keeps the coefficients between calls would use; the chains below need no promise
+    P.assume_forward_coefficients(True)
+    k2p = timed(lambda: P.predict_histogram_dev(co(), 0, vp, wp, pb, pp, ph, po, stream=s), 30)
+    P.assume_forward_coefficients(False)
+    line("K2, forward coefficients promised", k2p, w * h, F * 512 * 9 + 40960)
     pk = d_back.data_ptr()
     k3 = timed(lambda: P.inverse_transform_dev(co(), pk, stream=s), 30)
     ok = bool(torch.equal(d_back, d_px[rot[0]]))
