@@ -1,11 +1,13 @@
 // libfri.cpp -- see libfri.hpp. Host glue over the C ABI; no compute here.
 #include "libfri.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <utility>
@@ -354,6 +356,16 @@ std::string emit_streamed(const StreamedImage &im, uint32_t c, uint64_t n, uint3
 }
 } // namespace
 
+fri_hip_plan *Device::stream_plan(uint32_t width, uint32_t height, uint32_t channels, std::string &err) {
+    fri_hip_plan *p = plan(width, height, channels, err);
+    if (!p) return nullptr;
+    if (std::find(ordered_.begin(), ordered_.end(), p) != ordered_.end()) return p;
+    err = set_plan_stream_order(p, *this);
+    if (!err.empty()) return nullptr;
+    ordered_.push_back(p);
+    return p;
+}
+
 // FRIEncoder::encode (encoder.rs:87-109) end to end through the symbol stream route: the device runs the stage chain AND the emitter's gather
 // (sort_lattice order, entropy_coding.rs:285-336), the host receives 2 bytes per symbol and runs the rANS loop and the serializer. Byte for byte
 // the .frv of encode_bytes below (tests/test_emit.py); 34 MB instead of 153 MB come down per 4096 x 4096 plane.
@@ -397,6 +409,17 @@ Result<std::vector<uint8_t>> FRIEncoder::encode_bytes_streamed(std::vector<uint8
 
 Result<std::vector<std::vector<uint8_t>>> encode_batch_bytes(const std::vector<const uint8_t *> &images, uint32_t height, uint32_t width, ColorSpace colorspace,
                                                              const EncoderOpts &opts, const std::vector<int> &devices, unsigned emit_threads, BatchStats *stats) {
+    std::vector<std::unique_ptr<Device>> owned;
+    std::vector<Device *> devs;
+    for (int d : devices) {
+        owned.emplace_back(new Device(d));
+        devs.push_back(owned.back().get());
+    }
+    return encode_batch_bytes(images, height, width, colorspace, opts, devs, emit_threads, stats);
+}
+
+Result<std::vector<std::vector<uint8_t>>> encode_batch_bytes(const std::vector<const uint8_t *> &images, uint32_t height, uint32_t width, ColorSpace colorspace,
+                                                             const EncoderOpts &opts, const std::vector<Device *> &devices, unsigned emit_threads, BatchStats *stats) {
     Result<std::vector<std::vector<uint8_t>>> r;
     const size_t n_images = images.size();
     const uint32_t c = num_channels(colorspace);
@@ -423,11 +446,10 @@ Result<std::vector<std::vector<uint8_t>>> encode_batch_bytes(const std::vector<c
     std::vector<std::thread> producers, emitters;
     for (uint32_t d = 0; d < n_dev; d++)
         producers.emplace_back([&, d]() {
-            Device dev(devices[d]);
+            Device &dev = *devices[d];
             std::string err;
-            fri_hip_plan *plan = dev.ok() ? dev.plan(width, height, c, err) : nullptr;
-            if (!plan) err = dev.ok() ? err : dev.error();
-            if (plan) err = set_plan_stream_order(plan, dev);
+            fri_hip_plan *plan = dev.ok() ? dev.stream_plan(width, height, c, err) : nullptr;
+            if (!plan && err.empty()) err = dev.error();
             if (!err.empty()) fail(err);
             const uint64_t n = plan ? fri_hip_plan_num_some(plan) : 0;
             if (d == 0) {
