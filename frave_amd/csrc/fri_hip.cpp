@@ -519,7 +519,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         bool node0_gathered = false; // the fit kernels stage heap node 0 (the DC value) as the zero their "never a node" entries read: no node with a row may gather it
         for (int n = 2; n < kCell; n++)
             for (int k = 0; k < 6; k++) node0_gathered |= !(tab[(size_t)n * 6 + k] & 0x8000u) && (tab[(size_t)n * 6 + k] & 511u) == 0;
-        if (halo_list[0] == 0xFFFFFFFFu || node0_gathered) { // more halo values than threads / ...: the neighbour table is not the one the kernels were laid out for
+        if (halo_list[0] == 0xFFFFFFFFu || node0_gathered || pair_pos[0] != 0) { // (pair 0 = heap nodes 0 and 1 at the head of a cell: where the fit kernels' zero lives) // more halo values than threads / ...: the neighbour table is not the one the kernels were laid out for
             fri_hip_plan_destroy(p);
             return FRI_HIP_ERR_INVALID_ARGUMENT;
         }
