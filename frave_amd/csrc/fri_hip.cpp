@@ -227,7 +227,8 @@ int acquire_acc(fri_hip_plan *p, hipStream_t stream, uint32_t n_planes = 1) {
     }
     auto &a = p->acc_slots[idx];
     if (a.planes < n_planes) { // grow: the old buffers may still be in use by queued launches, so they are retired, not freed
-        const uint32_t planes = n_planes < 4 ? 4 : n_planes;
+        // (geometric: a caller whose batches grow by one plane per call retires at most 16 generations per slot - ADVICE r3)
+        const uint32_t planes = std::min<uint32_t>(65535u, std::max<uint32_t>({4u, n_planes, 2u * a.planes}));
         void *pa = nullptr, *fa = nullptr, *si = nullptr, *sd = nullptr, *rg = nullptr, *pr = nullptr;
         const size_t pb = (size_t)planes * kPredAccWords * sizeof(uint32_t), fb = (size_t)planes * kFitShards * kFitAccWords * sizeof(unsigned long long);
         hipError_t e = hipMalloc(&pa, pb);
