@@ -228,6 +228,19 @@ def main():
     ap.add_argument("--extras", action="store_true", help="(kept for older command lines: the extras are in the default line now; adds the PCIe byte counts)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process has not touched the GPU and never will - it starts the N ranks as a child
+        # process (torch.distributed.run, one rank per GPU over RCCL), relays rank 0's line and exits with the child's code; a line for another
+        # number of GPUs is an error, never a one-GPU number under an N-GPU command (frave_amd/dist.py, tests/test_bench_spawn.py).
+        from frave_amd.dist import spawn_ranks
+
+        code, line = spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+        if line is not None and code == 0:
+            print(json.dumps(line), flush=True)
+        sys.exit(code)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -239,9 +252,9 @@ def main():
 
     import frave_amd
 
-    if world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1", file=sys.stderr)
-        args.gpus = world
+    if world != args.gpus:  # a launcher started another number of ranks than the command asks for: refuse, do not measure something else
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("FRI_BENCH_FORCE_DIST") == "1":  # the env knob exercises the RCCL path with a single rank
@@ -300,7 +313,10 @@ def main():
         timed["call_us"] = (time.perf_counter() - t_call) * 1e6
 
     # barrier + device synchronisation on both sides, MAX over ranks (the protocol tests/test_multi_gloo.py exercises on gloo)
-    elapsed = timed_region(timed_steps, dist=dist, device_sync=torch.cuda.synchronize, device="cuda")
+    # (closing fence: the native call has polled its end event, so the launch stream - the only stream this rank has put work on - is idle when it
+    # returns; hipStreamQuery proves it without the ~160 us a device-wide synchronise costs under an attached profiler. If the query says busy,
+    # timed_region synchronises as before.)
+    elapsed = timed_region(timed_steps, dist=dist, device_sync=torch.cuda.synchronize, device="cuda", device_idle=torch.cuda.current_stream().query)
     kernel_us = timed["kernel_us"]
     achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
 

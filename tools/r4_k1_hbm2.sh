@@ -4,6 +4,7 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
+make -s -C tools/micro stream_floor
 ./tools/micro/stream_floor 32 300 > $OUT/stream_floor_32.log 2>&1
 ./tools/micro/stream_floor 4 300 > $OUT/stream_floor_4.log 2>&1
 python3 tools/k1_sweep_hbm.py --slots 32 --launches 300 --rounds 3 "" "FRI_HIP_BAND_ROWS=8" "FRI_HIP_BAND_ROWS=12" "FRI_HIP_BAND_ROWS=16" "FRI_HIP_BAND_ROWS=20" "FRI_HIP_BAND_ROWS=24" "FRI_HIP_BAND_ROWS=28" \
