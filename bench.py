@@ -261,6 +261,11 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "RANK" not in os.environ:  # FRI_BENCH_FORCE_DIST=1 without a launcher: a one-rank job of its own
+            from frave_amd.dist import _free_port
+
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = frave_amd.Context(local_rank)  # raises if the HIP library or a gfx950 GPU is missing: no fallback

@@ -28,7 +28,7 @@ SYMBOLS = [
     "fri_hip_fit_params_batch_dev", "fri_hip_encode_image_batch_dev", "fri_hip_fit_value_params_batch_dev", "fri_hip_fit_width_params_batch_dev",
     "fri_hip_plan_assume_forward_coefficients", "fri_hip_encode_image_batch", "fri_hip_multi_encode_image",
     "fri_hip_plan_set_stream_order", "fri_hip_symbol_stream_batch_dev", "fri_hip_encode_image_symbols", "fri_hip_encode_symbols_batch_dev",
-    "fri_hip_plan_set_dequantiser",
+    "fri_hip_plan_set_dequantiser", "fri_hip_plan_tune_forward", "fri_hip_time_transform_quant_streams_dev",
 ]
 
 
@@ -122,6 +122,8 @@ def load_library():
     L.fri_hip_plan_read_trace.argtypes = [vp, vp]
     L.fri_hip_plan_inverse_lists.argtypes = [vp, vp]
     L.fri_hip_time_transform_quant_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, u32, vp, C.POINTER(C.c_double)]
+    L.fri_hip_time_transform_quant_streams_dev.argtypes = [vp, u32, vp, sz, vp, vp, sz, u32, u32, C.POINTER(C.c_double)]
+    L.fri_hip_plan_tune_forward.argtypes = [vp, u32, C.c_char_p, sz]
     L.fri_hip_shard_size.restype, L.fri_hip_shard_size.argtypes = u32, [u32, u32, u32]
     L.fri_hip_shard_image.restype, L.fri_hip_shard_image.argtypes = u32, [u32, u32, u32]
     L.fri_hip_multi_create.argtypes = [vp, u32, u32, u32, u32, C.POINTER(vp)]
@@ -586,6 +588,21 @@ class Plan:
     def inverse_transform_dev(self, d_coefs, d_pixels, qmatrix=None, stream=0):
         q = _q(qmatrix)
         _check(load_library().fri_hip_inverse_transform_dev(self._h, d_coefs, _p(q), d_pixels, stream), "fri_hip_inverse_transform_dev", self.ctx)
+
+    def tune_forward(self, launches=0):
+        """fri_hip_plan_tune_forward: measure candidate tilings of the forward kernel on this device and keep the fastest. Returns the report (dict)."""
+        import json
+
+        buf = C.create_string_buffer(4096)
+        _check(load_library().fri_hip_plan_tune_forward(self._h, launches, buf, len(buf)), "fri_hip_plan_tune_forward", self.ctx)
+        return json.loads(buf.value.decode() or "{}")
+
+    def time_transform_quant_streams_dev(self, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, iters, n_streams, qmatrix=None):
+        q = _q(qmatrix)
+        us = C.c_double(0)
+        _check(load_library().fri_hip_time_transform_quant_streams_dev(self._h, n_images, d_pixels, pixel_stride, _p(q), d_coefs, coef_stride, iters, n_streams,
+                                                                       C.byref(us)), "fri_hip_time_transform_quant_streams_dev", self.ctx)
+        return us.value
 
     def time_transform_quant_dev(self, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, iters, qmatrix=None, stream=0):
         q = _q(qmatrix)

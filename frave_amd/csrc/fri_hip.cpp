@@ -10,6 +10,8 @@
 #include <cmath>
 #include <atomic>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -109,6 +111,11 @@ struct fri_hip_plan {
     uint32_t acc_next = 0;
     bool acc_dirty = false; // a launch on this plan failed: the accumulators are re-zeroed before the next use
     hipEvent_t ev_begin = nullptr, ev_end = nullptr; // timing helper's events, created with the plan (creating an event is not work to be timed)
+    // fri_hip_plan_tune_forward: the parameters the forward tiling was built with, and whether the plan may exchange it (a plan whose tiling the
+    // environment pinned, whose inverse kernel shares the forward tiles, or that is cut into many short shares keeps what it has)
+    TilingParams fwd_tp;
+    bool fwd_tunable = false;
+    std::string fwd_tiling_note = "default";
 };
 
 struct fri_hip_multi {
@@ -321,6 +328,124 @@ int ensure_encode_slots(fri_hip_plan *p, bool want_bucket, bool want_prediction)
     return FRI_HIP_OK;
 }
 
+
+// ---- forward tiling chosen by measurement (fri_hip_plan_tune_forward) ---------------------------------------------------------------------------------
+// Which tiling the forward kernel runs fastest on is not monotonic in any parameter and differs by image size (at 4096^2 contiguous
+// shares with bands of 72 rows beat the default by 4 %, at 6000 x 4000 they lose 13 %; nine cells per tile win at 4096^2 and lose at 2048^2), because with
+// four or five tiles per share the tile count quantises the one round of shares differently at every size. So the plan can MEASURE, like an FFT plan: a
+// handful of candidate tilings are built, uploaded and timed on scratch buffers large enough that every byte comes from HBM, and the winner replaces the
+// default tiling. Results never depend on the tiling (the parity tests run on tuned and untuned plans alike); only the forward kernel's speed does.
+struct FwdTiling {  // one candidate: host geometry + its device tables
+    TilingParams tp;
+    Geometry geo;
+    DevicePlan dev;            // p->dev with this candidate's tiling swapped in
+    std::vector<void *> bufs;  // device tables of this candidate
+    std::string label;
+    double us = 0;
+};
+
+void fill_forward_tiling(DevicePlan &d, const Geometry &g) {
+    d.n_tiles = (uint32_t)g.tiles.size();
+    d.lds_pitch = g.lds_pitch;
+    d.lds_rows = g.lds_rows;
+    d.cells_per_tile = g.cells_per_tile;
+    d.max_tile_cells = g.max_tile_cells;
+    d.max_wg_tiles = std::max(g.max_wg_tiles, g.max_wg_tiles_batch);
+    d.n_wg_batch = (uint32_t)g.wg_tiles_batch.size() - 1;
+    d.max_wg_cells = g.max_wg_cells;
+    d.n_wg = (uint32_t)g.wg_tiles.size() - 1;
+}
+
+template <typename T>
+hipError_t upload_raw(const std::vector<T> &v, const T *&out, std::vector<void *> &bufs) {
+    void *d = nullptr;
+    const size_t bytes = std::max(v.size(), (size_t)1) * sizeof(T);
+    if (hipError_t e = hipMalloc(&d, bytes)) return e;
+    bufs.push_back(d);
+    if (!v.empty())
+        if (hipError_t e = hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)) return e;
+    out = static_cast<const T *>(d);
+    return hipSuccess;
+}
+
+// builds candidate `c.tp` for the plan's shape; false = it does not fit the forward kernel with the plan's resident workgroup count (not a candidate)
+bool build_forward_candidate(const fri_hip_plan *p, FwdTiling &c) {
+    const Geometry &g0 = p->geo;
+    if (!build_geometry(g0.width, g0.height, g0.channels, c.tp, c.geo).empty()) return false;
+    if (c.geo.centers.size() != g0.centers.size()) return false;
+    DevicePlan probe;
+    probe.channels = (int32_t)g0.channels;
+    probe.lds_pitch = c.geo.lds_pitch;
+    probe.lds_rows = c.geo.lds_rows;
+    probe.max_tile_cells = c.geo.max_tile_cells;
+    probe.max_wg_tiles = std::max(c.geo.max_wg_tiles, c.geo.max_wg_tiles_batch);
+    if (!fwd_plan_fits(probe)) return false;
+    if ((int)std::min<size_t>(4, (160 * 1024) / fwd_lds_bytes(probe)) < c.tp.ranks) return false; // the shares are sized for tp.ranks resident workgroups per CU
+    return true;
+}
+
+hipError_t upload_forward_candidate(const fri_hip_plan *p, FwdTiling &c) {
+    c.dev = p->dev;
+    hipError_t e;
+    if ((e = upload_raw(c.geo.tiles, c.dev.tiles, c.bufs)) || (e = upload_raw(c.geo.tile_cells, c.dev.tile_cells, c.bufs)) || (e = upload_raw(c.geo.tile_meta, c.dev.tile_meta, c.bufs)) ||
+        (e = upload_raw(c.geo.wg_tiles, c.dev.wg_tiles, c.bufs)) || (e = upload_raw(c.geo.wg_tiles_batch, c.dev.wg_tiles_batch, c.bufs)))
+        return e;
+    fill_forward_tiling(c.dev, c.geo);
+    return hipSuccess;
+}
+
+// the plan takes the candidate's tiling: host vectors and device tables (the old tables stay allocated until the plan is destroyed - a launch may still read them)
+void adopt_forward_tiling(fri_hip_plan *p, FwdTiling &c) {
+    Geometry &g = p->geo;
+    g.tiles.swap(c.geo.tiles), g.tile_cells.swap(c.geo.tile_cells), g.tile_meta.swap(c.geo.tile_meta), g.wg_tiles.swap(c.geo.wg_tiles), g.wg_tiles_batch.swap(c.geo.wg_tiles_batch);
+    g.max_wg_tiles_batch = c.geo.max_wg_tiles_batch, g.lds_pitch = c.geo.lds_pitch, g.lds_rows = c.geo.lds_rows, g.band_rows = c.geo.band_rows, g.cells_per_tile = c.geo.cells_per_tile;
+    g.cells_per_wg = c.geo.cells_per_wg, g.max_tile_cells = c.geo.max_tile_cells, g.max_wg_tiles = c.geo.max_wg_tiles, g.max_wg_cells = c.geo.max_wg_cells;
+    DevicePlan &d = p->dev;
+    d.tiles = c.dev.tiles, d.tile_cells = c.dev.tile_cells, d.tile_meta = c.dev.tile_meta, d.wg_tiles = c.dev.wg_tiles, d.wg_tiles_batch = c.dev.wg_tiles_batch;
+    fill_forward_tiling(d, g);
+    d.inv_max_wg_tiles = d.max_wg_tiles, d.inv_max_wg_cells = d.max_wg_cells; // (only read by an inverse kernel on the forward tiling; tunable plans have their own)
+    for (void *b : c.bufs) p->owned.push_back(b);
+    c.bufs.clear();
+    p->fwd_tp = c.tp;
+    p->fwd_tiling_note = c.label;
+}
+
+std::string tiling_label(const TilingParams &tp, const Geometry &g) {
+    char b[96];
+    std::snprintf(b, sizeof b, "%s/band%d/cells%d", tp.strided_shares ? "interleaved" : "contiguous", g.band_rows, g.cells_per_tile);
+    return b;
+}
+
+// winners of this process, per (device, width, height, channels): later plans of the same shape start from them without measuring again
+struct TunedKey {
+    int device;
+    uint32_t w, h, c;
+    bool operator==(const TunedKey &o) const { return device == o.device && w == o.w && h == o.h && c == o.c; }
+};
+std::mutex g_tuned_mu;
+std::vector<std::pair<TunedKey, TilingParams>> g_tuned;
+
+void adopt_cached_forward_tiling(fri_hip_plan *p) {
+    TilingParams tp;
+    {
+        std::lock_guard<std::mutex> lk(g_tuned_mu);
+        const TunedKey k{p->ctx->device, p->geo.width, p->geo.height, p->geo.channels};
+        auto it = std::find_if(g_tuned.begin(), g_tuned.end(), [&](const auto &e) { return e.first == k; });
+        if (it == g_tuned.end()) return;
+        tp = it->second;
+    }
+    FwdTiling c;
+    c.tp = tp;
+    if (!build_forward_candidate(p, c)) return;
+    if (upload_forward_candidate(p, c) != hipSuccess) {
+        for (void *b : c.bufs) (void)hipFree(b);
+        (void)hipGetLastError();
+        return;
+    }
+    c.label = tiling_label(c.tp, c.geo) + " (measured earlier in this process)";
+    adopt_forward_tiling(p, c);
+}
+
 } // namespace
 
 extern "C" {
@@ -466,6 +591,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             }
         }
     }
+    const TilingParams tp_forward = tp; // what the forward tiling was built with (fri_hip_plan_tune_forward starts from it)
     // (from ~400 000 cells on - 16384^2 - the inverse kernel is fastest on groups of the forward plan's short shares, as in round 3: 386 against 408 us)
     if (ctx && (env_str("FRI_HIP_INV_SHARED") ? env_int("FRI_HIP_INV_SHARED") <= 0 : p->geo.centers.size() < kOwnInverseMaxCells)) {
         // the inverse kernel's own tiling: one share per resident workgroup (it prefers that at every size), dispatch-rank weights, interleaved, bands of
@@ -622,6 +748,11 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             std::vector<int32_t>().swap(gi.nbr_cells), std::vector<int32_t>().swap(gi.pred_slots);
         }
     }
+    p->fwd_tp = tp_forward;
+    p->fwd_tunable = ctx && p->own_inverse_tiling && !many_shares && !p->dev.trace && !env_str("FRI_HIP_BAND_ROWS") && !env_str("FRI_HIP_CELLS_PER_TILE") &&
+                     !env_str("FRI_HIP_CELLS_PER_WG") && !env_str("FRI_HIP_STRIDED_SHARES") && !env_str("FRI_HIP_TARGET_WGS") && !env_str("FRI_HIP_RANKS") &&
+                     !env_str("FRI_HIP_TILE_BYTES") && !env_str("FRI_HIP_RANK_WEIGHTS");
+    if (p->fwd_tunable) adopt_cached_forward_tiling(p); // a tiling measured for this device and shape earlier in the process (fri_hip_plan_tune_forward)
     *out = p;
     return FRI_HIP_OK;
 }
@@ -1495,6 +1626,198 @@ int fri_hip_time_transform_quant_dev(fri_hip_plan *p, uint32_t n_images, const u
     HIP_TRY(p->ctx, hipEventElapsedTime(&ms, e0, e1));
     *mean_us = (double)ms * 1000.0 / iters;
     return FRI_HIP_OK;
+}
+
+
+/* The same loop with the launches dealt over `n_streams` streams of the library's own (launch i on stream i mod n_streams; the images are independent):
+ * launch i + 1's workgroups move into the CUs launch i's early finishers leave, so the drain of one launch overlaps the ramp of the next. mean_us is the
+ * launch PERIOD (time from the first launch's begin to the last one's end over iters) - not a kernel duration: with more than one stream launches overlap. */
+int fri_hip_time_transform_quant_streams_dev(fri_hip_plan *p, uint32_t n_images, const uint8_t *d_pixels, size_t pixel_stride, const int32_t qmatrix[32],
+                                             int32_t *d_coefs, size_t coef_stride, uint32_t iters, uint32_t n_streams, double *mean_us) {
+    if (int rc = need_device(p)) return rc;
+    if (!d_pixels || !d_coefs || !n_images || !iters || !mean_us || !n_streams || n_streams > 8) return FRI_HIP_ERR_INVALID_ARGUMENT;
+    QMatrix q;
+    if (int rc = check_q(qmatrix, q)) return rc;
+    fri_hip_ctx *c = p->ctx;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st[8] = {};
+    hipEvent_t done[8] = {}, e0 = nullptr, e1 = nullptr;
+    int rc = FRI_HIP_OK;
+    auto cleanup = [&]() {
+        for (uint32_t k = 0; k < n_streams; k++) {
+            if (done[k]) (void)hipEventDestroy(done[k]);
+            if (st[k]) (void)hipStreamDestroy(st[k]);
+        }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+#define TRY_OR_CLEAN(expr)                                  \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) {                             \
+            rc = fail_hip(c, e_, #expr);                    \
+            (void)hipDeviceSynchronize();                   \
+            cleanup();                                      \
+            return rc;                                      \
+        }                                                   \
+    } while (0)
+    for (uint32_t k = 0; k < n_streams; k++) {
+        TRY_OR_CLEAN(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+        TRY_OR_CLEAN(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+    }
+    TRY_OR_CLEAN(hipEventCreate(&e0));
+    TRY_OR_CLEAN(hipEventCreate(&e1));
+    TRY_OR_CLEAN(hipDeviceSynchronize()); // whatever the caller has queued is done before the clock starts
+    TRY_OR_CLEAN(hipEventRecord(e0, st[0]));
+    for (uint32_t k = 1; k < n_streams; k++) TRY_OR_CLEAN(hipStreamWaitEvent(st[k], e0, 0)); // nobody starts before the begin event
+    for (uint32_t i = 0; i < iters; i++) {
+        const uint32_t k = i % n_images;
+        TRY_OR_CLEAN(launch_fwd_transform_quant(p->dev, 1, d_pixels + (size_t)k * pixel_stride, 0, d_coefs + (size_t)k * coef_stride, 0, q, st[i % n_streams]));
+    }
+    for (uint32_t k = 1; k < n_streams; k++) {
+        TRY_OR_CLEAN(hipEventRecord(done[k], st[k]));
+        TRY_OR_CLEAN(hipStreamWaitEvent(st[0], done[k], 0)); // the end event is behind every stream's last launch
+    }
+    TRY_OR_CLEAN(hipEventRecord(e1, st[0]));
+    TRY_OR_CLEAN(hipEventSynchronize(e1));
+    float ms = 0.f;
+    TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
+#undef TRY_OR_CLEAN
+    *mean_us = (double)ms * 1000.0 / iters;
+    cleanup();
+    return rc;
+}
+
+/* Measures candidate tilings of the forward kernel on this plan's device and keeps the fastest (see "forward tiling chosen by measurement" above). */
+int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, size_t report_bytes) {
+    if (int rc = need_device(p)) return rc;
+    std::string rep;
+    auto finish = [&](int rc) {
+        if (report && report_bytes) {
+            std::snprintf(report, report_bytes, "%s", rep.c_str());
+        }
+        return rc;
+    };
+    if (!p->fwd_tunable) {
+        rep = "{\"tuned\": false, \"kept\": \"" + p->fwd_tiling_note + "\", \"why\": \"tiling pinned by the environment, shared with the inverse kernel, or a many-shares plan\"}";
+        return finish(FRI_HIP_OK);
+    }
+    fri_hip_ctx *c = p->ctx;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!launches) launches = 96;
+    const Geometry &g0 = p->geo;
+    const bool rgb = g0.channels != 1;
+    // candidates: the plan's tiling first, then the settings that won somewhere in round 4's sweeps (tools/r4_k1_hbm*.sh, r4_cells.sh)
+    std::vector<std::unique_ptr<FwdTiling>> cand;
+    auto add = [&](int strided, int band, int cells_delta) {
+        auto t = std::make_unique<FwdTiling>();
+        t->tp = p->fwd_tp;
+        if (strided >= 0) t->tp.strided_shares = strided != 0;
+        if (band > 0) t->tp.band_rows = band;
+        if (cells_delta) t->tp.cells_per_tile = g0.cells_per_tile + cells_delta;
+        if (t->tp.cells_per_tile < 0) return;
+        if (!build_forward_candidate(p, *t)) return;
+        t->label = tiling_label(t->tp, t->geo);
+        for (const auto &o : cand)
+            if (o->label == t->label) return; // the builder clamped it to something already there
+        cand.push_back(std::move(t));
+    };
+    add(-1, 0, 0);
+    if (cand.empty()) {
+        rep = "{\"tuned\": false, \"why\": \"the plan's own tiling could not be rebuilt\"}";
+        return finish(FRI_HIP_OK);
+    }
+    if (!rgb) {
+        add(0, 72, 0), add(1, 16, 1), add(1, 32, 0), add(1, 8, 0), add(0, 8, 0), add(1, 24, 0), add(0, 48, 0), add(1, 16, -1);
+    } else {
+        add(1, 12, 0), add(1, 24, 0), add(0, 16, 0), add(1, 8, 0), add(0, 32, 0);
+    }
+    // scratch: enough distinct images that the pixels cannot come from the 256 MiB Infinity Cache, and coefficient slots whose rewrites are > 512 MB apart
+    const size_t px_bytes = fri_hip_plan_pixel_bytes(p), co_bytes = fri_hip_plan_coef_count(p) * sizeof(int32_t);
+    const uint32_t px_slots = (uint32_t)std::min<size_t>(64, std::max<size_t>(2, ((size_t)420 << 20) / px_bytes + 1));
+    const uint32_t co_slots = (uint32_t)std::min<size_t>(px_slots, std::max<size_t>(2, ((size_t)512 << 20) / co_bytes + 1));
+    uint8_t *d_px = nullptr;
+    int32_t *d_co = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t stream = nullptr;
+    int rc = FRI_HIP_OK;
+    auto cleanup = [&]() {
+        (void)hipDeviceSynchronize();
+        for (auto &t : cand)
+            for (void *b : t->bufs) (void)hipFree(b);
+        if (d_px) (void)hipFree(d_px);
+        if (d_co) (void)hipFree(d_co);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (stream) (void)hipStreamDestroy(stream);
+    };
+#define TRY_OR_CLEAN(expr)                                  \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) {                             \
+            rc = fail_hip(c, e_, #expr);                    \
+            cleanup();                                      \
+            return finish(rc);                              \
+        }                                                   \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc((void **)&d_px, (size_t)px_slots * px_bytes));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_co, (size_t)co_slots * co_bytes));
+    TRY_OR_CLEAN(hipMemset(d_px, 0x5A, (size_t)px_slots * px_bytes)); // the forward kernel's time does not depend on the pixel values
+    TRY_OR_CLEAN(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    TRY_OR_CLEAN(hipEventCreate(&e0));
+    TRY_OR_CLEAN(hipEventCreate(&e1));
+    for (auto &t : cand) TRY_OR_CLEAN(upload_forward_candidate(p, *t));
+    QMatrix q;
+    for (int i = 0; i < 32; i++) q.q[i] = 1;
+    constexpr int kRounds = 5;
+    std::vector<std::vector<double>> times(cand.size());
+    uint32_t it = 0;
+    auto run = [&](const FwdTiling &t, uint32_t n) -> hipError_t {
+        for (uint32_t i = 0; i < n; i++, it++)
+            if (hipError_t e = launch_fwd_transform_quant(t.dev, 1, d_px + (size_t)(it % px_slots) * px_bytes, 0, d_co + (size_t)(it % co_slots) * (co_bytes / 4), 0, q, stream)) return e;
+        return hipSuccess;
+    };
+    TRY_OR_CLEAN(run(*cand[0], 4 * launches)); // clocks and translations up before anything is compared
+    for (int r = 0; r < kRounds; r++)
+        for (size_t k = 0; k < cand.size(); k++) { // interleaved rounds: a drift of the clocks hits every candidate alike
+            TRY_OR_CLEAN(run(*cand[k], 8));
+            TRY_OR_CLEAN(hipEventRecord(e0, stream));
+            TRY_OR_CLEAN(run(*cand[k], launches));
+            TRY_OR_CLEAN(hipEventRecord(e1, stream));
+            TRY_OR_CLEAN(hipEventSynchronize(e1));
+            float ms = 0.f;
+            TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
+            times[k].push_back((double)ms * 1000.0 / launches);
+        }
+#undef TRY_OR_CLEAN
+    size_t best = 0;
+    for (size_t k = 0; k < cand.size(); k++) {
+        std::sort(times[k].begin(), times[k].end());
+        cand[k]->us = times[k][times[k].size() / 2];
+        if (cand[k]->us < cand[best]->us) best = k;
+    }
+    // the default stays unless a candidate beats it by more than the noise between rounds (1.5 %)
+    if (cand[best]->us > cand[0]->us * 0.985) best = 0;
+    char b[160];
+    rep = "{\"tuned\": true, \"launches\": " + std::to_string(launches) + ", \"rounds\": " + std::to_string(kRounds) + ", \"pixel_slots\": " + std::to_string(px_slots) +
+          ", \"coef_slots\": " + std::to_string(co_slots) + ", \"winner\": \"" + cand[best]->label + "\", \"candidates_us\": {";
+    for (size_t k = 0; k < cand.size(); k++) {
+        std::snprintf(b, sizeof b, "%s\"%s\": %.3f", k ? ", " : "", cand[k]->label.c_str(), cand[k]->us);
+        rep += b;
+    }
+    rep += "}}";
+    (void)hipDeviceSynchronize();
+    if (best != 0) adopt_forward_tiling(p, *cand[best]);
+    else p->fwd_tiling_note = cand[0]->label + " (measured: the default won)";
+    {
+        std::lock_guard<std::mutex> lk(g_tuned_mu);
+        const TunedKey k{c->device, g0.width, g0.height, g0.channels};
+        auto itc = std::find_if(g_tuned.begin(), g_tuned.end(), [&](const auto &e) { return e.first == k; });
+        if (itc == g_tuned.end()) g_tuned.emplace_back(k, p->fwd_tp);
+        else itc->second = p->fwd_tp;
+    }
+    cleanup();
+    return finish(FRI_HIP_OK);
 }
 
 } // extern "C"

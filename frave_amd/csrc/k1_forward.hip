@@ -35,15 +35,32 @@ struct FwdArgs {
 };
 
 // ---- packed arithmetic: two (cell, channel) items per register ------------------------------------------------------
-// Every value of the transform fits 16 bits (differences in [-255, 255], low-pass values in [0, 255]) and K1 is bound by
-// VALU issue (a wave64 integer instruction occupies its SIMD for 4 cycles), so one wave transforms TWO items at once:
-// item A in the low half, item B in the high half of each VGPR, v_pk_*_i16 arithmetic. DPP / permlane moves carry both.
+// Every value of the transform fits 16 bits (differences in [-255, 255], low-pass values in [0, 255]), so one wave transforms TWO
+// items at once: item A in the low half, item B in the high half of each VGPR; DPP / permlane moves carry both.
 // d = l - r;  s = r + trunc(d / 2) = (l + r + (l < r)) >> 1  for l, r >= 0   (wavelet_transform.rs:211-218).
 // Missing (None) operands enter as 0, which is exactly what try_apply substitutes (wavelet_transform.rs:14-26); which
 // outputs are None is decided separately from the validity tree (boundary cells only).
-__device__ __forceinline__ void pk_pair(u16x2 l, u16x2 r, s16x2 &d, u16x2 &s) {
-    d = (s16x2)l - (s16x2)r;
-    s = (l + r + ((u16x2)d >> 15)) >> 1;
+//
+// Round 5: the butterfly without packed-16 instructions (tools/micro/valu_rate2.hip: every v_pk_* holds the SIMD for 4 cycles, plain
+// 32-bit add / sub / shift / xor for 2; rounds 1-4 spent five v_pk_* per butterfly and two more instructions to unpack each d):
+//   x = l - r            one plain 32-bit subtraction. Low half: d_A mod 2^16, exact. High half: d_B - (l_A < r_A), off by the borrow.
+//   s = v_lerp_u8(l, r, x >> 15)      per BYTE (l + r + (c & 1)) >> 1: bytes 0 and 2 hold the two items' values, bytes 1 and 3 are 0 and
+//                        stay 0. The rounding bit only matters when l + r is odd, i.e. d != 0, and then the sign of (d_B - borrow) IS
+//                        the sign of d_B (d_B >= 1 -> >= 0, d_B <= -1 -> < 0): bit 15 / bit 31 of x are good enough.
+//   d_A, d_B             where a difference is an output, it is formed straight as int32 from the 16-bit fields (v_sub_u32_sdwa
+//                        WORD_0 / WORD_1: the compiler's choice for the expressions below) - nothing to unpack in front of the stores.
+// Three instructions per butterfly on the low-pass chain, five where both d leave (were five + two).
+__device__ __forceinline__ uint32_t pk_low(uint32_t l, uint32_t r, uint32_t x) { return __builtin_amdgcn_lerp(l, r, x >> 15); }
+__device__ __forceinline__ void pk_pair(uint32_t l, uint32_t r, int &dA, int &dB, uint32_t &s) {
+    s = pk_low(l, r, l - r);
+    dA = (int)(l & 0xFFFFu) - (int)(r & 0xFFFFu);
+    dB = (int)(l >> 16) - (int)(r >> 16);
+}
+// x = l - r as one 32-bit word (see above) -> the two int32 differences: the low half sign-extended; the high half + the borrow the
+// low half took (adding 0x8000 carries into the high half exactly when bit 15, the low difference's sign, is set).
+__device__ __forceinline__ void unpack_x(uint32_t x, int &dA, int &dB) {
+    dA = (int)(short)(x & 0xFFFFu);
+    dB = (int)(x + 0x8000u) >> 16;
 }
 
 // Round J of the cross-lane part of the tree (level 5-J): combine the two child groups of 2^J lanes.
@@ -54,61 +71,62 @@ __device__ __forceinline__ void pk_pair(u16x2 l, u16x2 r, s16x2 &d, u16x2 &s) {
 // All lanes of a child group hold the same low-pass value, so fetching from ANY lane of the sibling group is
 // enough -- that is what lets every round be a VALU cross-lane op instead of an LDS permute.
 // Bit J of the lane clear = left child (the right child is the one that adds the LITERAL).
+// J < 4: no selects into (l, r). x = other - own is d in the lanes of the right child (own = r) and -d in the left child's; the
+// low-pass value is symmetric in its operands except for the rounding bit, (l < r) = sign(x) in right-child lanes and its
+// complement in left-child lanes (d = 0: the bit does not matter) - one xor with a per-lane constant. The detail a lane keeps
+// (tz == J: bit J is its lowest set bit) is always taken in a right-child lane, where x = d.
 template <int J>
-__device__ __forceinline__ void xlane_children(int lane, int v, int &l, int &r) {
+__device__ __forceinline__ uint32_t dpp_sibling(uint32_t v) {
+    constexpr int ctrl = J == 0 ? 0xB1 : J == 1 ? 0x4E : J == 2 ? 0x141 : 0x140;
+    // every lane has a source under these controls, so the `old` operand is never used: mov_dpp leaves it undefined and the
+    // compiler needs no copy of v in front of each v_mov_b32_dpp
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, ctrl, 0xF, 0xF, true);
+}
+template <int J>
+__device__ __forceinline__ void pk_cross(int lane, int tz, uint32_t &s, uint32_t &vlow) {
+    uint32_t x;
     if constexpr (J < 4) {
-        constexpr int ctrl = J == 0 ? 0xB1 : J == 1 ? 0x4E : J == 2 ? 0x141 : 0x140;
-        // every lane has a source under these controls, so the `old` operand is never used: mov_dpp leaves it undefined and the
-        // compiler needs no copy of v in front of each v_mov_b32_dpp
-        const int other = __builtin_amdgcn_mov_dpp(v, ctrl, 0xF, 0xF, true);
-        const bool hi = (lane >> J) & 1;
-        l = hi ? other : v;
-        r = hi ? v : other;
-    } else if constexpr (J == 4) {
-        const uint2v w = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
-        l = (int)w.x;
-        r = (int)w.y;
+        const uint32_t other = dpp_sibling<J>(s);
+        x = other - s;
+        const uint32_t flip = ((lane >> J) & 1) ? 0u : 0x00010001u; // loop invariant: a register per round
+        s = __builtin_amdgcn_lerp(s, other, (x >> 15) ^ flip);
     } else {
-        const uint2v w = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-        l = (int)w.x;
-        r = (int)w.y;
+        const uint2v w = J == 4 ? __builtin_amdgcn_permlane16_swap(s, s, false, false) : __builtin_amdgcn_permlane32_swap(s, s, false, false);
+        x = w.x - w.y;
+        s = pk_low(w.x, w.y, x);
+    }
+    if (tz == J) vlow = x;
+}
+// the same routing for the validity OR-tree (symmetric: no roles)
+template <int J>
+__device__ __forceinline__ int xlane_or(int v) {
+    if constexpr (J < 4) {
+        return v | (int)dpp_sibling<J>((uint32_t)v);
+    } else {
+        const uint2v w = J == 4 ? __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false) : __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        return (int)(w.x | w.y);
     }
 }
 
-template <int J>
-__device__ __forceinline__ void pk_cross(int lane, int tz, u16x2 &s, int &vlow) {
-    int l, r;
-    xlane_children<J>(lane, __builtin_bit_cast(int, s), l, r);
-    s16x2 d;
-    pk_pair(__builtin_bit_cast(u16x2, l), __builtin_bit_cast(u16x2, r), d, s);
-    if (tz == J) vlow = __builtin_bit_cast(int, d);
-}
-
-// The 9-level transform of two items held by one wave. leaf[j] = pixels of leaf 8*lane + j of item A (.x) and B (.y).
-// res[0..3] = coef[256+4L .. +3], res[4..5] = coef[128+2L ..], res[6] = coef[64+L], res[7] = coef[L], both items packed.
-__device__ __forceinline__ void fwd_wave_pk(const u16x2 (&leaf)[8], int lane, int (&res)[8]) {
-    s16x2 d8[4], d7[2], d6;
-    u16x2 s8[4], s7[2], s;
+// The 9-level transform of two items held by one wave. leaf[j] = pixels of leaf 8*lane + j of item A (low half) and B (high half).
+// rA / rB[0..3] = coef[256+4L .. +3], [4..5] = coef[128+2L ..], [6] = coef[64+L], [7] = coef[L] of item A / B, as int32.
+__device__ __forceinline__ void fwd_wave_pk(const uint32_t (&leaf)[8], int lane, int (&rA)[8], int (&rB)[8]) {
+    uint32_t s8[4], s7[2], s;
 #pragma unroll
-    for (int i = 0; i < 4; i++) pk_pair(leaf[2 * i], leaf[2 * i + 1], d8[i], s8[i]); // level 8: nodes 256 + 4L + i
+    for (int i = 0; i < 4; i++) pk_pair(leaf[2 * i], leaf[2 * i + 1], rA[i], rB[i], s8[i]); // level 8: nodes 256 + 4L + i
 #pragma unroll
-    for (int i = 0; i < 2; i++) pk_pair(s8[2 * i], s8[2 * i + 1], d7[i], s7[i]); // level 7: nodes 128 + 2L + i
-    pk_pair(s7[0], s7[1], d6, s);                                                 // level 6: node 64 + L
+    for (int i = 0; i < 2; i++) pk_pair(s8[2 * i], s8[2 * i + 1], rA[4 + i], rB[4 + i], s7[i]); // level 7: nodes 128 + 2L + i
+    pk_pair(s7[0], s7[1], rA[6], rB[6], s);                                                        // level 6: node 64 + L
     const int tz = lane ? __builtin_ctz(lane) : 6;
-    int vlow = 0;
+    uint32_t vlow = 0;
     pk_cross<0>(lane, tz, s, vlow); // level 5
     pk_cross<1>(lane, tz, s, vlow);
     pk_cross<2>(lane, tz, s, vlow);
     pk_cross<3>(lane, tz, s, vlow);
     pk_cross<4>(lane, tz, s, vlow);
     pk_cross<5>(lane, tz, s, vlow); // level 0 (root)
-    if (lane == 0) vlow = __builtin_bit_cast(int, s); // coefficients[0] = low_pass_values[1] (wavelet_transform.rs:221)
-#pragma unroll
-    for (int i = 0; i < 4; i++) res[i] = __builtin_bit_cast(int, d8[i]);
-    res[4] = __builtin_bit_cast(int, d7[0]);
-    res[5] = __builtin_bit_cast(int, d7[1]);
-    res[6] = __builtin_bit_cast(int, d6);
-    res[7] = __shfl(vlow, low_source_lane(lane));
+    if (lane == 0) vlow = s; // coefficients[0] = low_pass_values[1] (wavelet_transform.rs:221); values <= 255 in both halves: unpack_x leaves them alone
+    unpack_x((uint32_t)__shfl((int)vlow, low_source_lane(lane)), rA[7], rB[7]);
 }
 
 // Which outputs of a boundary cell are None: a node is Some iff at least one leaf below it is inside the image
@@ -121,13 +139,13 @@ __device__ __forceinline__ uint32_t validity_tree_pk(uint32_t m, int lane) {
     int sv = (int)((v7 | (v7 >> 4)) & 0x00010001u);     // node 64+L
     const uint32_t v6 = (uint32_t)sv;
     const int tz = lane ? __builtin_ctz(lane) : 6;
-    int vlow = 0, l, r;
-    xlane_children<0>(lane, sv, l, r); sv = l | r; if (tz == 0) vlow = sv;
-    xlane_children<1>(lane, sv, l, r); sv = l | r; if (tz == 1) vlow = sv;
-    xlane_children<2>(lane, sv, l, r); sv = l | r; if (tz == 2) vlow = sv;
-    xlane_children<3>(lane, sv, l, r); sv = l | r; if (tz == 3) vlow = sv;
-    xlane_children<4>(lane, sv, l, r); sv = l | r; if (tz == 4) vlow = sv;
-    xlane_children<5>(lane, sv, l, r); sv = l | r; if (tz == 5) vlow = sv;
+    int vlow = 0;
+    sv = xlane_or<0>(sv); if (tz == 0) vlow = sv;
+    sv = xlane_or<1>(sv); if (tz == 1) vlow = sv;
+    sv = xlane_or<2>(sv); if (tz == 2) vlow = sv;
+    sv = xlane_or<3>(sv); if (tz == 3) vlow = sv;
+    sv = xlane_or<4>(sv); if (tz == 4) vlow = sv;
+    sv = xlane_or<5>(sv); if (tz == 5) vlow = sv;
     if (lane == 0) vlow = sv;
     const uint32_t low = (uint32_t)__shfl(vlow, low_source_lane(lane));
     // compact: level 8 bits 0,2,4,6 -> 0..3 ; level 7 bits 0,4 -> 4,5 ; level 6 -> 6 ; low -> 7   (per 16-bit half)
@@ -141,7 +159,7 @@ __device__ __forceinline__ int quant_one(int v, int heap_index, const FwdArgs &a
     return v == kNone ? v : v / a.q.q[quant_layer(heap_index)];
 }
 
-// Unpacks one item (HALF = 0: low halves, 1: high halves), applies the None mask and the quantiser, and stores the
+// One item (HALF = 0: item A, 1: item B of the pair - selects the half of `valid`): applies the None mask and the quantiser, and stores the
 // cell's 512 int32 coefficients as four fully coalesced store instructions (1 KiB + 512 B + 256 B + 256 B).
 template <int HALF, bool MASKED, bool QID, bool NT>
 __device__ __forceinline__ void store_item(int32_t *__restrict__ coefs, uint32_t elem_off, int lane, const int (&res)[8], uint32_t valid,
@@ -149,7 +167,7 @@ __device__ __forceinline__ void store_item(int32_t *__restrict__ coefs, uint32_t
     int v[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        v[i] = HALF ? (res[i] >> 16) : (int)(short)(res[i] & 0xFFFF);
+        v[i] = res[i];
         if (MASKED && !((valid >> (16 * HALF + i)) & 1u)) v[i] = kNone;
     }
     if (!QID) { // QID: the all-ones matrix of today's reference (quantization.rs:3-5) - no division code in that kernel at all
@@ -302,8 +320,8 @@ __device__ __forceinline__ void fetch_windows_rgb(int buf_off, const int (&rb)[3
 }
 // {byte I of a, byte I of b} zero-extended into the two 16-bit halves.
 template <int I>
-__device__ __forceinline__ u16x2 pair_bytes(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0C000C00u | ((4u + I) << 16) | (unsigned)I));
+__device__ __forceinline__ uint32_t pair_bytes(uint32_t a, uint32_t b) {
+    return __builtin_amdgcn_perm(b, a, 0x0C000C00u | ((4u + I) << 16) | (unsigned)I);
 }
 
 // One item of a pair: where its 8 leaves sit in the staged rectangle, and which of them are inside the image.
@@ -418,7 +436,7 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
         const TileCell *meta = reinterpret_cast<const TileCell *>(cur + a.meta_off);
         const int n_items = (ablate_flags(a.ablate) & 2) ? 0 : t.cell_count * C;
         const uint32_t sh_base = a16 + (uint32_t)t.x_lo * C;
-        int res[kMaxPairsPerWave][8];
+        int resA[kMaxPairsPerWave][8], resB[kMaxPairsPerWave][8];
         uint32_t offA[kMaxPairsPerWave], offB[kMaxPairsPerWave], valid[kMaxPairsPerWave];
 #pragma unroll
         for (int c = 0; c < kMaxPairsPerWave; c++) {
@@ -431,7 +449,7 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
                 const ItemAddr B = item_addr<C, FAST>(a, t, meta, itB, ldx, ldy, lane_rb, buf_off, sh_base, wc16);
                 offA[c] = A.elem_off;
                 offB[c] = B.elem_off;
-                u16x2 leaf[8];
+                uint32_t leaf[8];
                 if constexpr (C == 1) {
                     // Sub-dword LDS reads are slow (a ds_read_u8 wave-instruction holds the LDS pipe for ~16 cycles), and a
                     // lane's 8 leaves sit in three 4-byte windows: row 0 = x..x+3, rows 1 and 2 = x-1..x+2. Fetch each window
@@ -469,12 +487,12 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
                     if ((A.leaf_mask & B.leaf_mask) != 0xFFu) { // some lane has a leaf outside the image: it enters as 0, the None outputs come from the validity tree
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
-                            if (!((A.leaf_mask >> j) & 1u)) leaf[j].x = 0;
-                            if (!((B.leaf_mask >> j) & 1u)) leaf[j].y = 0;
+                            if (!((A.leaf_mask >> j) & 1u)) leaf[j] &= 0xFFFF0000u;
+                            if (!((B.leaf_mask >> j) & 1u)) leaf[j] &= 0x0000FFFFu;
                         }
                     }
                 }
-                fwd_wave_pk(leaf, lane, res[c]);
+                fwd_wave_pk(leaf, lane, resA[c], resB[c]);
                 if constexpr (C == 1) {
                     if (c == 0)
                         __builtin_amdgcn_s_setprio(2);
@@ -492,14 +510,15 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
             const int itA = 2 * (wave + kFwdWaves * c);
             if (itA < n_items) {
                 bool go = !(ablate_flags(a.ablate) & 4);
-                if (!go) go = (res[c][0] ^ res[c][1] ^ res[c][2] ^ res[c][3] ^ res[c][4] ^ res[c][5] ^ res[c][6] ^ res[c][7]) == 0x12345678; // keeps the arithmetic alive
+                if (!go) go = (resA[c][0] ^ resA[c][1] ^ resA[c][2] ^ resA[c][3] ^ resA[c][4] ^ resA[c][5] ^ resA[c][6] ^ resA[c][7] ^ resB[c][0] ^ resB[c][1] ^ resB[c][2] ^ resB[c][3] ^
+                               resB[c][4] ^ resB[c][5] ^ resB[c][6] ^ resB[c][7]) == 0x12345678; // keeps the arithmetic alive
                 if (go) {
                     if (__builtin_amdgcn_readfirstlane(valid[c] == 0xFFFFFFFFu ? 1 : 0) && __all(valid[c] == 0xFFFFFFFFu)) { // no None anywhere in the pair
-                        store_item<0, false, QID, NT>(coefs, offA[c], lane, res[c], valid[c], a);
-                        if (itA + 1 < n_items) store_item<1, false, QID, NT>(coefs, offB[c], lane, res[c], valid[c], a);
+                        store_item<0, false, QID, NT>(coefs, offA[c], lane, resA[c], valid[c], a);
+                        if (itA + 1 < n_items) store_item<1, false, QID, NT>(coefs, offB[c], lane, resB[c], valid[c], a);
                     } else {
-                        store_item<0, true, QID, NT>(coefs, offA[c], lane, res[c], valid[c], a);
-                        if (itA + 1 < n_items) store_item<1, true, QID, NT>(coefs, offB[c], lane, res[c], valid[c], a);
+                        store_item<0, true, QID, NT>(coefs, offA[c], lane, resA[c], valid[c], a);
+                        if (itA + 1 < n_items) store_item<1, true, QID, NT>(coefs, offB[c], lane, resB[c], valid[c], a);
                     }
                 }
             }

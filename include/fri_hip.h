@@ -349,6 +349,24 @@ int fri_hip_time_transform_quant_dev(fri_hip_plan *plan, uint32_t n_images, cons
                                      const int32_t qmatrix[32], int32_t *d_coefs, size_t coef_stride, uint32_t iters, void *stream,
                                      double *mean_us);
 
+/* The same loop with launch i on stream i mod n_streams of the library's own streams (1..8; the images are independent, crates/fri-cli/src/commands/bench.rs:15-120):
+ * launch i + 1's workgroups move into the CUs launch i's early finishers leave. mean_us is the launch PERIOD (first begin to last end over iters), not a
+ * kernel duration - with more than one stream the launches overlap. Synchronises the device before and after. */
+int fri_hip_time_transform_quant_streams_dev(fri_hip_plan *plan, uint32_t n_images, const uint8_t *d_pixels, size_t pixel_stride,
+                                             const int32_t qmatrix[32], int32_t *d_coefs, size_t coef_stride, uint32_t iters, uint32_t n_streams,
+                                             double *mean_us);
+
+/* ---- forward tiling by measurement ------------------------------------------------------------- */
+/* How the cells of an image are cut into tiles and dealt to workgroups (Fractal::extract_coefficients is per-cell independent,
+ * stages/wavelet_transform.rs:179-225: any partition gives the same coefficients) decides the forward kernel's speed by a few percent, and which
+ * partition wins depends on the image size. fri_hip_plan_create picks a default that is good everywhere; this call MEASURES a handful of candidate
+ * tilings on the plan's device (`launches` launches each, 0 = 96, in five interleaved rounds, on scratch buffers of its own - about 1 GB at 4096^2,
+ * freed before it returns - large enough that every byte comes from HBM), keeps the fastest and remembers it for later plans of the same shape on the
+ * same device in this process. Results never change; a plan whose tiling was pinned through the tuning environment, a host-only plan's, or one the
+ * inverse kernel shares (>= 400 000 cells) is left alone. `report` (may be NULL): a JSON object with the candidates' microseconds per launch.
+ * Blocks for tens of milliseconds; call it once after fri_hip_plan_create, outside anything that is timed. Not thread-safe per plan. */
+int fri_hip_plan_tune_forward(fri_hip_plan *plan, uint32_t launches, char *report, size_t report_bytes);
+
 /* The inverse kernel's static write-out lists (diagnostics / tests): out[5] = {built (0/1), whole 16-byte quads, whole dwords inside
  * partly owned quads, bytes owned inside partly owned dwords, LDS bytes of the largest tile rectangle}.
  * 16 * out[1] + 4 * out[2] + out[3] equals the number of bytes of the image that belong to a retained cell. */

@@ -367,16 +367,8 @@ static void build_global_position_map(fri_oracle_wavelet *w) {
     }
 }
 
-fri_oracle_wavelet *fri_oracle_from_raster(const uint8_t *data, uint32_t height, uint32_t width, uint32_t channels) {
-    if (!data || (channels != 1 && channels != 3) || !height || !width) return NULL;
-    fri_oracle_wavelet *w = (fri_oracle_wavelet *)calloc(1, sizeof(*w));
-    w->height = height;
-    w->width = width;
-    w->channels = channels;
-    w->data = data;
-    cmap_init(&w->fractal_lattice, 1024);
-
-    fractal_divide(w, width, height, BASE_FRAC_DEPTH); /* :406-410 */
+/* The part of from_raster that does not depend on which cells the BFS found: coefficients, retain(), canonical order, position map. */
+static void finish_from_raster(fri_oracle_wavelet *w) {
     for (size_t i = 0; i < w->n_cells; i++) extract_coefficients(w->cells[i], w, w->cells[i]->depth); /* :412-414 */
 
     /* retain(): keep cells whose DC is Some in all three channel slots (:415-416).
@@ -389,7 +381,7 @@ fri_oracle_wavelet *fri_oracle_from_raster(const uint8_t *data, uint32_t height,
     for (size_t i = 0; i < w->n_cells; i++) {
         fractal *f = w->cells[i];
         int all = 1;
-        for (uint32_t c = 0; c < (channels == 3 ? 3u : 1u); c++) all &= f->coefficients[c][0].some;
+        for (uint32_t c = 0; c < (w->channels == 3 ? 3u : 1u); c++) all &= f->coefficients[c][0].some;
         f->retained = all;
         if (all) {
             w->order[w->n_retained++] = (uint32_t)i;
@@ -400,10 +392,62 @@ fri_oracle_wavelet *fri_oracle_from_raster(const uint8_t *data, uint32_t height,
     w->fractal_lattice = kept;
     g_sort_ctx = w;
     qsort(w->order, w->n_retained, sizeof(uint32_t), cmp_cells);
-
     build_global_position_map(w); /* :418 */
     w->data = NULL;
+}
+
+fri_oracle_wavelet *fri_oracle_from_raster(const uint8_t *data, uint32_t height, uint32_t width, uint32_t channels) {
+    if (!data || (channels != 1 && channels != 3) || !height || !width) return NULL;
+    fri_oracle_wavelet *w = (fri_oracle_wavelet *)calloc(1, sizeof(*w));
+    w->height = height;
+    w->width = width;
+    w->channels = channels;
+    w->data = data;
+    cmap_init(&w->fractal_lattice, 1024);
+
+    fractal_divide(w, width, height, BASE_FRAC_DEPTH); /* :406-410 */
+    finish_from_raster(w);                             /* :412-418 */
     return w;
+}
+
+/* from_raster over a GIVEN set of cell centres instead of fractal_divide's BFS (config 5's sampled checks: the whole 16384^2 lattice
+ * would take this hash-map-shaped restatement ~40 GB). Everything per cell is the reference's (Fractal::new :42-69, extract_coefficients
+ * :179-225, the retain rule :415-416, the position map :434-448); a node's context (fri_oracle_context_at) is the full image's as long
+ * as every cell its neighbour positions fall into is among the centres - the caller passes a cell together with its lattice
+ * neighbourhood. Duplicate centres are taken once. */
+fri_oracle_wavelet *fri_oracle_from_raster_cells(const uint8_t *data, uint32_t height, uint32_t width, uint32_t channels, const int32_t *centers, uint32_t n_centers) {
+    if (!data || !centers || !n_centers || (channels != 1 && channels != 3) || !height || !width) return NULL;
+    fri_oracle_wavelet *w = (fri_oracle_wavelet *)calloc(1, sizeof(*w));
+    w->height = height;
+    w->width = width;
+    w->channels = channels;
+    w->data = data;
+    cmap_init(&w->fractal_lattice, 2 * (size_t)n_centers + 8);
+    for (uint32_t i = 0; i < n_centers; i++) {
+        const cpx c = {centers[2 * i], centers[2 * i + 1]};
+        if (!cmap_contains(&w->fractal_lattice, c)) push_cell(w, fractal_new(BASE_FRAC_DEPTH, c));
+    }
+    finish_from_raster(w);
+    return w;
+}
+
+/* One cell on its own: Fractal::new(depth 9, centre) + extract_coefficients (wavelet_transform.rs:42-69, :179-225) - the transform is
+ * per-cell independent. out[channels][512] in heap order, None = FRI_ORACLE_NONE. Returns 1 if the retain rule (:415-416, the C ABI's
+ * channel-0 rule for planes) keeps the cell, 0 if not, -1 on bad arguments. */
+int fri_oracle_cell(const uint8_t *data, uint32_t height, uint32_t width, uint32_t channels, int32_t center_re, int32_t center_im, int32_t *out) {
+    if (!data || !out || (channels != 1 && channels != 3) || !height || !width) return -1;
+    fri_oracle_wavelet w;
+    memset(&w, 0, sizeof w);
+    w.height = height, w.width = width, w.channels = channels, w.data = data;
+    fractal *f = fractal_new(BASE_FRAC_DEPTH, (cpx){center_re, center_im});
+    extract_coefficients(f, &w, f->depth);
+    int all = 1;
+    for (uint32_t c = 0; c < channels; c++) {
+        all &= f->coefficients[c][0].some;
+        for (int i = 0; i < NODES; i++) out[(size_t)c * NODES + i] = f->coefficients[c][i].some ? f->coefficients[c][i].v : FRI_ORACLE_NONE;
+    }
+    fractal_free(f);
+    return all;
 }
 
 void fri_oracle_free(fri_oracle_wavelet *w) {

@@ -31,6 +31,15 @@ typedef struct fri_oracle_wavelet fri_oracle_wavelet; /* WaveletImage, stages/wa
 fri_oracle_wavelet *fri_oracle_from_raster(const uint8_t *data, uint32_t height, uint32_t width,
                                            uint32_t channels);
 void fri_oracle_free(fri_oracle_wavelet *w);
+/* from_raster over a given set of cell centres ([n][2] = (re, im), duplicates taken once) instead of fractal_divide's BFS: per cell exactly
+ * the reference's Fractal::new + extract_coefficients + retain rule + position map. For sampled checks of images whose whole lattice this
+ * restatement cannot hold (config 5, 16384^2): pass a cell together with its lattice neighbourhood and fri_oracle_context_at gives the
+ * full image's answer for the cell's nodes. */
+fri_oracle_wavelet *fri_oracle_from_raster_cells(const uint8_t *data, uint32_t height, uint32_t width, uint32_t channels, const int32_t *centers,
+                                                 uint32_t n_centers);
+/* One cell on its own (the transform is per-cell independent, wavelet_transform.rs:179-225): out[channels][512], heap order,
+ * None = FRI_ORACLE_NONE. Returns 1 if the retain rule keeps the cell, 0 if not, -1 on bad arguments. */
+int fri_oracle_cell(const uint8_t *data, uint32_t height, uint32_t width, uint32_t channels, int32_t center_re, int32_t center_im, int32_t *out);
 
 uint32_t fri_oracle_num_cells(const fri_oracle_wavelet *w);     /* after the retain() at :415-416 */
 uint32_t fri_oracle_num_bfs_cells(const fri_oracle_wavelet *w); /* fractal_divide() output size */

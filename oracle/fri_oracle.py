@@ -33,6 +33,10 @@ def lib():
         L.fri_oracle_from_raster.restype = vp
         L.fri_oracle_from_raster.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
         L.fri_oracle_free.argtypes = [vp]
+        L.fri_oracle_from_raster_cells.restype = vp
+        L.fri_oracle_from_raster_cells.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32]
+        L.fri_oracle_cell.restype = C.c_int
+        L.fri_oracle_cell.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, vp]
         for n in ("num_cells", "num_bfs_cells", "channels"):
             f = getattr(L, "fri_oracle_" + n)
             f.restype = C.c_uint32
@@ -76,11 +80,16 @@ def _p(a):
 class Wavelet:
     """WaveletImage restatement (stages/wavelet_transform.rs:384-432)."""
 
-    def __init__(self, pixels, height, width, channels):
+    def __init__(self, pixels, height, width, channels, centers=None):
+        """centers (optional, [n][2] = (re, im)): only these cells instead of the BFS lattice (fri_oracle_from_raster_cells: sampled checks of huge images)"""
         px = np.ascontiguousarray(pixels, dtype=np.uint8).reshape(-1)
         assert px.size == height * width * channels
         self.h, self.w, self.c = height, width, channels
-        self._h = lib().fri_oracle_from_raster(_p(px), height, width, channels)
+        if centers is None:
+            self._h = lib().fri_oracle_from_raster(_p(px), height, width, channels)
+        else:
+            cs = np.ascontiguousarray(centers, np.int32).reshape(-1, 2)
+            self._h = lib().fri_oracle_from_raster_cells(_p(px), height, width, channels, _p(cs), len(cs))
         if not self._h:
             raise ValueError("fri_oracle_from_raster failed")
 
@@ -162,6 +171,21 @@ class Wavelet:
         out = np.empty((n, 2), np.int32)
         lib().fri_oracle_sorted_level(self._h, level, _p(out))
         return out
+
+
+def cell_coefficients(pixels, height, width, channels, centers):
+    """fri_oracle_cell for each centre ([n][2] = (re, im)): (coefficients [n][channels][512], retained [n] bool)"""
+    px = np.ascontiguousarray(pixels, dtype=np.uint8).reshape(-1)
+    assert px.size == height * width * channels
+    cs = np.ascontiguousarray(centers, np.int32).reshape(-1, 2)
+    out = np.empty((len(cs), channels, 512), np.int32)
+    kept = np.empty(len(cs), bool)
+    f = lib().fri_oracle_cell
+    for i, (re, im) in enumerate(cs):
+        rc = f(_p(px), height, width, channels, int(re), int(im), out[i].ctypes.data)
+        assert rc >= 0
+        kept[i] = rc == 1
+    return out, kept
 
 
 def pair(l, r):

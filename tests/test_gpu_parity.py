@@ -301,9 +301,12 @@ def test_config3_batch_of_1080p_frames(ctx, oracle):
         assert np.array_equal(got.reshape(-1), d_co[k].cpu().numpy())
 
 
-def test_config5_16384_square(ctx):
+def test_config5_16384_square(ctx, oracle):
     """BASELINE config 5 at full size: 526 369 cells, 269.5 M coefficient slots (1.08 GB of int32: 64-bit offsets),
-    histogram on the device. Checked through size-independent properties."""
+    histogram on the device. Checked through size-independent properties AND against the oracle on samples: the whole lattice does not fit the
+    hash-map-shaped restatement (~40 GB), but the transform is per-cell independent (wavelet_transform.rs:179-225) and a node's context needs
+    its cell's lattice neighbourhood only - K1: >= 4096 random cells plus EVERY boundary cell through fri_oracle_cell; K2: all 512 nodes of
+    512 cells (128 of them boundary cells: 262 144 nodes) through the oracle built from the pixels over those cells' two-hop neighbourhoods."""
     import torch
 
     w = h = 16384
@@ -332,6 +335,43 @@ def test_config5_16384_square(ctx):
     assert int(d_b.max()) <= 9
     # the predictor outputs of None nodes stay (0, 0)
     assert int(d_b.view(P.num_cells, 512)[~valid].max()) == 0 and int(d_p.view(P.num_cells, 512)[~valid].abs().max()) == 0
+    # ---- against the oracle, on samples ----
+    img = d_px.cpu().numpy()
+    centres = P.centers()
+    boundary = np.flatnonzero(~P.valid_bits().all(axis=1))
+    assert len(boundary) == P.num_cells - P.num_interior_cells
+    rng = np.random.default_rng(16384)
+    sample = np.unique(np.concatenate([boundary, rng.integers(0, P.num_cells, 4608)]))
+    assert len(sample) >= 4096 + len(boundary) - 200
+    want, kept = oracle.cell_coefficients(img, h, w, 1, centres[sample])
+    assert kept.all()
+    got = co[torch.from_numpy(sample).cuda()].cpu().numpy()
+    assert np.array_equal(got, want[:, 0])  # K1: every boundary cell and 4.5 K random cells, all 512 coefficients
+    # K2: the oracle over the union of the sampled cells' two-hop lattice neighbourhoods, from the PIXELS (its own transform), then node by node
+    cells = np.concatenate([rng.choice(boundary, 128, replace=False), rng.integers(0, P.num_cells, 384)])
+    v = np.array(oracle.nearby_vectors(9), np.int64)
+    hop = {tuple(x) for x in centres[cells]}
+    for _ in range(2):
+        hop |= {(re + dx, im + dy) for re, im in hop for dx, dy in v}
+    Wp = oracle.Wavelet(img, h, w, 1, centers=np.array(sorted(hop), np.int32))
+    idx = {tuple(x): i for i, x in enumerate(Wp.centers())}
+    dev_idx = {tuple(x): i for i, x in enumerate(centres[cells])}
+    assert set(dev_idx) <= set(idx)
+    vpa, wpa = np.ascontiguousarray(KAT_VALUE_PARAMS, np.float32).reshape(3, 6), np.ascontiguousarray(KAT_WIDTH_PARAMS, np.float32).reshape(3, 6)
+    sel = torch.from_numpy(cells).cuda()
+    gb, gp = d_b.view(P.num_cells, 512)[sel].cpu().numpy(), d_p.view(P.num_cells, 512)[sel].cpu().numpy()
+    gv = valid[sel].cpu().numpy()
+    n_checked = 0
+    for j, cell in enumerate(cells):
+        k = idx[tuple(centres[cell])]
+        for heap in range(512):
+            r = Wp.context_at(0, k, heap, vpa, wpa)
+            assert (r is not None) == bool(gv[j, heap]), (cell, heap)
+            if r is not None:
+                assert r == (gb[j, heap], gp[j, heap]), (cell, heap, r, gb[j, heap], gp[j, heap])
+                n_checked += 1
+    Wp.close()
+    assert n_checked > 200000
 
 
 def test_large_image_short_shares_against_the_oracle(ctx, oracle):

@@ -43,6 +43,35 @@ KERNEL(k_dpp, "v_add_u32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_ma
 KERNEL(k_cvtub, "v_cvt_f32_ubyte1_e32 %0, %0")
 KERNEL(k_pkfma, "v_pk_fma_f16 %0, %0, %1, %2")
 KERNEL(k_maxf, "v_max_f32_e32 %0, %1, %0")
+// round 5: what K1's butterflies and routing are made of
+KERNEL(k_lerp, "v_lerp_u8 %0, %0, %1, %2")
+KERNEL(k_subu, "v_sub_u32_e32 %0, %1, %0")
+KERNEL(k_sub_sdwa, "v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1")
+KERNEL(k_sub_sdwa0, "v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0")
+KERNEL(k_cnd_vcc, "v_cndmask_b32_e32 %0, %1, %0, vcc")
+KERNEL(k_cnd_sgpr, "v_cndmask_b32_e64 %0, %1, %0, s[10:11]")
+KERNEL(k_movdpp, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+KERNEL(k_movdpp_rm, "v_mov_b32_dpp %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1")
+KERNEL(k_bfei, "v_bfe_i32 %0, %0, 0, 16")
+KERNEL(k_ashr, "v_ashrrev_i32_e32 %0, 16, %0")
+KERNEL(k_lshr, "v_lshrrev_b32_e32 %0, 15, %0")
+KERNEL(k_xor, "v_xor_b32_e32 %0, %1, %0")
+KERNEL(k_alignbyte, "v_alignbyte_b32 %0, %0, %1, %2")
+KERNEL(k_add3, "v_add3_u32 %0, %0, %1, %2")
+KERNEL(k_pkadd, "v_pk_add_u16 %0, %0, %1")
+KERNEL(k_pklshr, "v_pk_lshrrev_b16 %0, 1, %0 op_sel_hi:[0,1]")
+KERNEL(k_or3, "v_or3_b32 %0, %0, %1, %2")
+KERNEL(k_andor, "v_and_or_b32 %0, %0, %1, %2")
+KERNEL(k_lshladd, "v_lshl_add_u32 %0, %0, 1, %1")
+KERNEL(k_xad, "v_xad_u32 %0, %0, %1, %2")
+KERNEL(k_cmp, "v_cmp_lt_i32_e64 s[12:13], %0, %1")
+KERNEL(k_pl16, "v_permlane16_swap_b32_e32 %0, %1")
+KERNEL(k_pl32, "v_permlane32_swap_b32_e32 %0, %1")
+KERNEL(k_mov, "v_mov_b32_e32 %0, %1")
+KERNEL(k_bfeu, "v_bfe_u32 %0, %0, 8, 8")
+KERNEL(k_sext_sdwa, "v_mov_b32_sdwa %0, sext(%0) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0")
+KERNEL(k_sext_sdwa1, "v_mov_b32_sdwa %0, sext(%0) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
+KERNEL(k_subdpp, "v_sub_u32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
 
 int main() {
     const int blocks = 256, threads = 1024, iters = 20000;
@@ -94,5 +123,33 @@ int main() {
     RUN(k_sad, "v_sad_u16")
     RUN(k_mad24, "v_mad_u32_u24")
     RUN(k_dpp, "v_add_u32_dpp quad_perm")
+    RUN(k_lerp, "v_lerp_u8")
+    RUN(k_subu, "v_sub_u32_e32")
+    RUN(k_sub_sdwa, "v_sub_u32_sdwa WORD_1 WORD_1")
+    RUN(k_sub_sdwa0, "v_sub_u32_sdwa WORD_0 WORD_0")
+    RUN(k_cnd_vcc, "v_cndmask_b32_e32 (vcc)")
+    RUN(k_cnd_sgpr, "v_cndmask_b32_e64 (sgpr pair)")
+    RUN(k_movdpp, "v_mov_b32_dpp quad_perm")
+    RUN(k_movdpp_rm, "v_mov_b32_dpp row_mirror")
+    RUN(k_subdpp, "v_sub_u32_dpp quad_perm")
+    RUN(k_bfei, "v_bfe_i32")
+    RUN(k_bfeu, "v_bfe_u32")
+    RUN(k_sext_sdwa, "v_mov_b32_sdwa sext WORD_0")
+    RUN(k_sext_sdwa1, "v_mov_b32_sdwa sext WORD_1")
+    RUN(k_ashr, "v_ashrrev_i32_e32")
+    RUN(k_lshr, "v_lshrrev_b32_e32")
+    RUN(k_xor, "v_xor_b32_e32")
+    RUN(k_mov, "v_mov_b32_e32")
+    RUN(k_alignbyte, "v_alignbyte_b32")
+    RUN(k_add3, "v_add3_u32")
+    RUN(k_or3, "v_or3_b32")
+    RUN(k_andor, "v_and_or_b32")
+    RUN(k_lshladd, "v_lshl_add_u32")
+    RUN(k_xad, "v_xad_u32")
+    RUN(k_pkadd, "v_pk_add_u16")
+    RUN(k_pklshr, "v_pk_lshrrev_b16")
+    RUN(k_cmp, "v_cmp_lt_i32_e64 -> sgpr pair")
+    RUN(k_pl16, "v_permlane16_swap_b32")
+    RUN(k_pl32, "v_permlane32_swap_b32")
     return 0;
 }
