@@ -354,6 +354,7 @@ void fill_forward_tiling(DevicePlan &d, const Geometry &g) {
     d.n_wg_batch = (uint32_t)g.wg_tiles_batch.size() - 1;
     d.max_wg_cells = g.max_wg_cells;
     d.n_wg = (uint32_t)g.wg_tiles.size() - 1;
+    d.pf_lines_per_row = g.pf_lines_per_row;
 }
 
 template <typename T>
@@ -398,6 +399,7 @@ hipError_t upload_forward_candidate(const fri_hip_plan *p, FwdTiling &c) {
 void adopt_forward_tiling(fri_hip_plan *p, FwdTiling &c) {
     Geometry &g = p->geo;
     g.tiles.swap(c.geo.tiles), g.tile_cells.swap(c.geo.tile_cells), g.tile_meta.swap(c.geo.tile_meta), g.wg_tiles.swap(c.geo.wg_tiles), g.wg_tiles_batch.swap(c.geo.wg_tiles_batch);
+    g.pf_lines_per_row = c.geo.pf_lines_per_row;
     g.max_wg_tiles_batch = c.geo.max_wg_tiles_batch, g.lds_pitch = c.geo.lds_pitch, g.lds_rows = c.geo.lds_rows, g.band_rows = c.geo.band_rows, g.cells_per_tile = c.geo.cells_per_tile;
     g.cells_per_wg = c.geo.cells_per_wg, g.max_tile_cells = c.geo.max_tile_cells, g.max_wg_tiles = c.geo.max_wg_tiles, g.max_wg_cells = c.geo.max_wg_cells;
     DevicePlan &d = p->dev;
@@ -412,7 +414,8 @@ void adopt_forward_tiling(fri_hip_plan *p, FwdTiling &c) {
 
 std::string tiling_label(const TilingParams &tp, const Geometry &g) {
     char b[96];
-    std::snprintf(b, sizeof b, "%s/band%d/cells%d", tp.strided_shares ? "interleaved" : "contiguous", g.band_rows, g.cells_per_tile);
+    std::snprintf(b, sizeof b, "%s/band%d/cells%d%s", tp.strided_shares ? "interleaved" : "contiguous", g.band_rows, g.cells_per_tile,
+                  g.pf_lines_per_row ? (tp.prefetch > 1 ? "/prefetch2" : "/prefetch") : "");
     return b;
 }
 
@@ -506,6 +509,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
     tp.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
     tp.cells_per_wg = env_int("FRI_HIP_CELLS_PER_WG");
     tp.batch_share_tiles = env_int("FRI_HIP_BATCH_SHARE_TILES");
+    tp.prefetch = env_str("FRI_HIP_K1_PREFETCH") ? env_int("FRI_HIP_K1_PREFETCH") : 0; // row-run prefetch distance in rounds (geometry.cpp); 0 = off
     // Interleaved shares (geometry.cpp): the resident workgroups work on one window sliding over the image. Default since round 4 (4096^2 from HBM: planes
     // 20.3 -> 19.1 us, RGB 55.5 -> 51.9 us, the inverse 29.6 -> 27.8 / 86 -> 72 us); FRI_HIP_STRIDED_SHARES=0 (tuning) restores one contiguous run per share.
     // Up to ~200 000 cells, that is: at 12000^2 and 16384^2 (282 K / 526 K cells, many short shares dispatched in order: the resident set slides already) the
@@ -601,6 +605,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         ti.band_rows = env_int("FRI_HIP_INV_BAND_ROWS") > 0 ? env_int("FRI_HIP_INV_BAND_ROWS") : (channels == 1 ? 32 : 16);
         ti.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
         ti.cells_per_wg = 0;
+        ti.prefetch = 0; // (the inverse kernel reads coefficients, one contiguous 2 KiB piece per cell: nothing to gather into runs)
         ti.target_wgs = ctx_wgs(ctx, tp.ranks);
         ti.strided_shares = env_str("FRI_HIP_INV_STRIDED_SHARES") ? env_int("FRI_HIP_INV_STRIDED_SHARES") > 0 : (strided_env ? tp.strided_shares : true); // interleaved at every size it is built for
         bool ok = false;
@@ -666,6 +671,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.channels = (int32_t)g.channels;
         d.lds_pitch = g.lds_pitch;
         d.lds_rows = g.lds_rows;
+        d.pf_lines_per_row = g.pf_lines_per_row;
         d.cells_per_tile = g.cells_per_tile;
         d.max_tile_cells = g.max_tile_cells;
         d.covers_image = g.n_valid_leaves == (uint64_t)g.width * g.height;
@@ -848,8 +854,10 @@ int fri_hip_plan_read_trace(fri_hip_plan *p, uint64_t *out) {
 int fri_hip_plan_tile_table(const fri_hip_plan *p, int32_t *tiles, int32_t *tile_cells, int32_t *wg_tiles) {
     if (!p) return FRI_HIP_ERR_INVALID_ARGUMENT;
     const Geometry &g = p->geo;
-    static_assert(sizeof(Tile) == 6 * sizeof(int32_t), "Tile layout");
-    if (tiles) std::memcpy(tiles, g.tiles.data(), g.tiles.size() * sizeof(Tile));
+    static_assert(sizeof(Tile) == 8 * sizeof(int32_t), "Tile layout");
+    if (tiles)
+        for (size_t t = 0; t < g.tiles.size(); t++) std::memcpy(tiles + 6 * t, &g.tiles[t], 6 * sizeof(int32_t)); // the ABI's six fields; the prefetch slice stays inside
+
     if (tile_cells) std::memcpy(tile_cells, g.tile_cells.data(), g.tile_cells.size() * sizeof(int32_t));
     if (wg_tiles) std::memcpy(wg_tiles, g.wg_tiles.data(), g.wg_tiles.size() * sizeof(int32_t));
     return FRI_HIP_OK;
@@ -995,6 +1003,15 @@ static bool chain_wants_cached_coefficients(const fri_hip_plan *p, uint32_t n_im
 /* ---- prediction + histogram ----------------------------------------------------------------- */
 static int predict_launch(fri_hip_plan *p, const PredBatch &b, uint8_t *d_bucket, int32_t *d_prediction, uint32_t *d_hist, uint64_t *d_oob, int trust,
                           hipStream_t stream) {
+    // The scan's histogram hand-over numbers its launches on the HOST (pred_serial below, a kernel argument): a captured launch would freeze that number, and from the
+    // second replay on the clearing workgroups' flags already hold it - nothing would order the clearing of the histogram before the other workgroups' adds any more
+    // (counts wiped or doubled). So a scan launch refuses to be captured, loudly, instead of recording something that must not be replayed.
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) {
+        if (p->ctx) p->ctx->last_error = "the predict + histogram kernel cannot be captured into a HIP graph (its hand-over counts launches on the host): launch it on a stream";
+        return FRI_HIP_ERR_INVALID_ARGUMENT;
+    }
+    (void)hipGetLastError();
     const int slot = acquire_acc(p, stream, b.n_planes);
     if (slot < 0) return slot;
     auto &acc = p->acc_slots[slot];
@@ -1709,9 +1726,10 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
     const bool rgb = g0.channels != 1;
     // candidates: the plan's tiling first, then the settings that won somewhere in round 4's sweeps (tools/r4_k1_hbm*.sh, r4_cells.sh)
     std::vector<std::unique_ptr<FwdTiling>> cand;
-    auto add = [&](int strided, int band, int cells_delta) {
+    auto add = [&](int strided, int band, int cells_delta, int prefetch = 0) {
         auto t = std::make_unique<FwdTiling>();
         t->tp = p->fwd_tp;
+        t->tp.prefetch = prefetch;
         if (strided >= 0) t->tp.strided_shares = strided != 0;
         if (band > 0) t->tp.band_rows = band;
         if (cells_delta) t->tp.cells_per_tile = g0.cells_per_tile + cells_delta;
@@ -1722,14 +1740,16 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
             if (o->label == t->label) return; // the builder clamped it to something already there
         cand.push_back(std::move(t));
     };
-    add(-1, 0, 0);
+    add(-1, 0, 0, p->fwd_tp.prefetch);
     if (cand.empty()) {
         rep = "{\"tuned\": false, \"why\": \"the plan's own tiling could not be rebuilt\"}";
         return finish(FRI_HIP_OK);
     }
     if (!rgb) {
+        add(1, 16, 0, 1), add(1, 16, 0, 2), add(1, 8, 0, 1), add(1, 32, 0, 1), add(1, 16, 1, 1);
         add(0, 72, 0), add(1, 16, 1), add(1, 32, 0), add(1, 8, 0), add(0, 8, 0), add(1, 24, 0), add(0, 48, 0), add(1, 16, -1);
     } else {
+        add(1, 16, 0, 1), add(1, 16, 0, 2), add(1, 12, 0, 1), add(1, 24, 0, 1);
         add(1, 12, 0), add(1, 24, 0), add(0, 16, 0), add(1, 8, 0), add(0, 32, 0);
     }
     // scratch: enough distinct images that the pixels cannot come from the 256 MiB Infinity Cache, and coefficient slots whose rewrites are > 512 MB apart

@@ -372,7 +372,7 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         y0 = std::max(y0, 0);
         x1 = std::min(x1, W - 1);
         y1 = std::min(y1, H - 1);
-        Tile t{x0, y0, x1 - x0 + 1, y1 - y0 + 1, (int32_t)i, (int32_t)(j - i)};
+        Tile t{x0, y0, x1 - x0 + 1, y1 - y0 + 1, (int32_t)i, (int32_t)(j - i), 0, 0};
         max_w = std::max(max_w, t.width_px);
         max_r = std::max(max_r, t.n_rows);
         g.max_tile_cells = std::max(g.max_tile_cells, t.cell_count);
@@ -483,6 +483,43 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         g.tiles.swap(tiles2);
         g.tile_meta.swap(meta2);
         g.tile_cells.swap(cells2);
+    }
+    if (tp.strided_shares && tp.prefetch > 0 && n_wg >= 8) {
+        // Row-run prefetch (round 5). A tile's staging loads are a 170-byte piece of each of ~50 image rows: every piece opens another DRAM page, and with
+        // a thousand workgroups asking at once the memory controller cannot put the pieces of one row together again - the 21 MB of pixel reads cost a
+        // 4096^2 launch 4-5 us, as much as a third of its 68 MB of stores (timing-only ablations). But WHICH rows an XCD's
+        // workgroups stage in round k + 1 is known: with interleaved shares it is one horizontal stripe of the image (the XCD's ~128 consecutive tiles of
+        // that round). So while a workgroup works on tile k it pulls its slice of that stripe - whole rows, 128-byte steps handed to consecutive lanes,
+        // consecutive slices to consecutive shares - into its XCD's L2, and the staging loads of round k + 1 hit there. Same bytes from HBM, read as
+        // long runs. The slices ride in the tile descriptors (Tile::pf_line / pf_count), one per tile.
+        const int row_bytes = W * (int)channels;
+        const int lpr = (row_bytes + 127) / 128 + 1; // steps of 128 bytes from the 128-byte boundary below a row's first byte cover it whatever the alignment
+        g.pf_lines_per_row = lpr;
+        const size_t q = n_wg >> 3, r = n_wg & 7;
+        for (size_t x = 0; x < 8; x++) {
+            const size_t s0 = x * q + std::min(x, r), s1 = s0 + q + (x < r ? 1 : 0); // the shares of XCD x (device_common.hpp: xcd_contiguous_share)
+            for (int k = 0; k < g.max_wg_tiles; k++) {
+                // rows the XCD stages in round k + d, and the shares that are still running tile k (they do the pulling)
+                int y0 = INT_MAX, y1 = INT_MIN;
+                std::vector<size_t> alive;
+                for (size_t sh = s0; sh < s1; sh++) {
+                    const int n = g.wg_tiles[sh + 1] - g.wg_tiles[sh];
+                    if (k < n) alive.push_back(sh);
+                    if (k + tp.prefetch < n) {
+                        const Tile &t = g.tiles[g.wg_tiles[sh] + k + tp.prefetch];
+                        y0 = std::min(y0, t.y_lo), y1 = std::max(y1, t.y_lo + t.n_rows);
+                    }
+                }
+                if (y1 <= y0 || alive.empty()) continue;
+                const long long lines = (long long)(y1 - y0) * lpr, first = (long long)y0 * lpr;
+                for (size_t a = 0; a < alive.size(); a++) {
+                    const long long b = lines * (long long)a / (long long)alive.size(), e = lines * (long long)(a + 1) / (long long)alive.size();
+                    Tile &t = g.tiles[g.wg_tiles[alive[a]] + k];
+                    t.pf_line = (int32_t)(first + b);
+                    t.pf_count = (int32_t)std::min<long long>(e - b, 256); // one step per thread of the workgroup
+                }
+            }
+        }
     }
     {
         const size_t cells_target = (size_t)(tp.batch_share_tiles > 0 ? tp.batch_share_tiles : 4) * cells_per_tile;

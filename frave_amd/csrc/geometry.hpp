@@ -40,6 +40,10 @@ struct Tile {
     int32_t x_lo, y_lo;     // top-left pixel of the staged rectangle (already clipped to the image)
     int32_t width_px, n_rows;
     int32_t cell_begin, cell_count; // range in tile_cells
+    // Forward kernel, interleaved shares only (build_prefetch_schedule): the slice of image "lines" (128-byte steps along whole pixel rows: line i = step
+    // i % lines_per_row of row i / lines_per_row) this workgroup pulls into its XCD's L2 while it works on the tile BEFORE this one - the rows the XCD's
+    // workgroups will stage one round later. pf_count = 0: nothing.
+    int32_t pf_line = 0, pf_count = 0;
 };
 
 // Write-out lists of the inverse kernel (geometry only). A tile's pixels are staged in LDS as rows of 16-byte quads; image row
@@ -88,6 +92,7 @@ struct Geometry {
     std::vector<uint16_t> inv_quads, inv_dwords;
     std::vector<uint32_t> inv_parts;
     int32_t inv_rect_bytes = 0; // largest n_rows * quads-per-row * 16 over all tiles
+    int32_t pf_lines_per_row = 0; // forward prefetch: 128-byte steps per pixel row (0 = no schedule in the tiles)
     int32_t lds_pitch = 0;   // bytes per staged row (multiple of 16)
     int32_t lds_rows = 0;    // max rows per tile
     int32_t band_rows = 0, cells_per_tile = 0, cells_per_wg = 0;
@@ -119,6 +124,9 @@ struct TilingParams {
     // instead of sizing every buffer for them. 0 = no cap.
     int tile_buffer_bytes = 0;
     int batch_share_tiles = 0; // tiles' worth of cells per merged batch share (0 = 4)
+    // Row-run prefetch for the forward kernel (needs strided_shares): see Tile::pf_line. 0 = off; d >= 1: the slice issued with tile k of a share covers the
+    // rows round k + d of the share's XCD stages (d = 1: the next round's, issued one tile iteration ahead of the demand loads).
+    int prefetch = 0;
     bool strided_shares = false; // deal the tiles to the shares round-robin (the resident set works on one sliding window of the image) instead of one contiguous run each
 };
 

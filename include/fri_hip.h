@@ -261,7 +261,9 @@ int fri_hip_encode_image_dev(fri_hip_plan *plan, const uint8_t *d_pixels, const 
 
 /* The same for n_images images with everything - parameters included - in DEVICE memory: K1 over all images, then (fit != 0) the device-side fit of
  * fri_hip_fit_params_batch_dev over all n_images * channels planes, then K2 over all planes; no host round trip and no synchronisation anywhere
- * (the call only enqueues; after a first call of the same batch size - the plan's scratch grows on demand - the sequence is HIP-graph capturable).
+ * (the call only enqueues). NOT HIP-graph capturable: the scan's histogram hand-over numbers its launches on the host, a replayed launch would reuse a
+ * number - every entry point that launches the scan returns FRI_HIP_ERR_INVALID_ARGUMENT on a stream that is being captured, instead of recording a graph
+ * whose replays could lose or double counts. (The forward and inverse kernels alone - fri_hip_transform_quant*_dev, fri_hip_inverse_transform*_dev - can be captured.)
  * Image k: pixels at d_pixels + k * pixel_stride (bytes), coefficients at d_coefs + k * coef_stride (int32 elements, [C][F][512] inside), bucket /
  * prediction at + k * out_stride (elements; either may be NULL), d_hist[k][C][10][1024], d_n_out_of_alphabet[k][C], d_params[k][C][2][3][6]
  * (in when fit == 0, out when fit != 0), d_fit_out_of_range[k][C] (may be NULL). With channels == 3 and n_images > 1 the images must lie back to
