@@ -593,9 +593,12 @@ class Plan:
         """fri_hip_plan_tune_forward: measure candidate tilings of the forward kernel on this device and keep the fastest. Returns the report (dict)."""
         import json
 
-        buf = C.create_string_buffer(4096)
+        buf = C.create_string_buffer(16384)
         _check(load_library().fri_hip_plan_tune_forward(self._h, launches, buf, len(buf)), "fri_hip_plan_tune_forward", self.ctx)
-        return json.loads(buf.value.decode() or "{}")
+        try:
+            return json.loads(buf.value.decode() or "{}")
+        except ValueError:  # a report cut short by the buffer
+            return {"raw": buf.value.decode(errors="replace")}
 
     def time_transform_quant_streams_dev(self, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, iters, n_streams, qmatrix=None):
         q = _q(qmatrix)

@@ -1758,6 +1758,7 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
     const uint32_t co_slots = (uint32_t)std::min<size_t>(px_slots, std::max<size_t>(2, ((size_t)512 << 20) / co_bytes + 1));
     uint8_t *d_px = nullptr;
     int32_t *d_co = nullptr;
+    unsigned long long *d_stat = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t stream = nullptr;
     int rc = FRI_HIP_OK;
@@ -1765,6 +1766,7 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
         (void)hipDeviceSynchronize();
         for (auto &t : cand)
             for (void *b : t->bufs) (void)hipFree(b);
+        if (d_stat) (void)hipFree(d_stat);
         if (d_px) (void)hipFree(d_px);
         if (d_co) (void)hipFree(d_co);
         if (e0) (void)hipEventDestroy(e0);
@@ -1790,34 +1792,88 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
     QMatrix q;
     for (int i = 0; i < 32; i++) q.q[i] = 1;
     constexpr int kRounds = 5;
-    std::vector<std::vector<double>> times(cand.size());
     uint32_t it = 0;
     auto run = [&](const FwdTiling &t, uint32_t n) -> hipError_t {
         for (uint32_t i = 0; i < n; i++, it++)
             if (hipError_t e = launch_fwd_transform_quant(t.dev, 1, d_px + (size_t)(it % px_slots) * px_bytes, 0, d_co + (size_t)(it % co_slots) * (co_bytes / 4), 0, q, stream)) return e;
         return hipSuccess;
     };
-    TRY_OR_CLEAN(run(*cand[0], 4 * launches)); // clocks and translations up before anything is compared
-    for (int r = 0; r < kRounds; r++)
-        for (size_t k = 0; k < cand.size(); k++) { // interleaved rounds: a drift of the clocks hits every candidate alike
-            TRY_OR_CLEAN(run(*cand[k], 8));
-            TRY_OR_CLEAN(hipEventRecord(e0, stream));
-            TRY_OR_CLEAN(run(*cand[k], launches));
-            TRY_OR_CLEAN(hipEventRecord(e1, stream));
-            TRY_OR_CLEAN(hipEventSynchronize(e1));
-            float ms = 0.f;
-            TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
-            times[k].push_back((double)ms * 1000.0 / launches);
+    // median microseconds per launch of the candidates `idx`, in interleaved rounds: a drift of the clocks hits every candidate alike
+    auto measure = [&](const std::vector<size_t> &idx) -> hipError_t {
+        std::vector<std::vector<double>> times(idx.size());
+        for (int r = 0; r < kRounds; r++)
+            for (size_t k = 0; k < idx.size(); k++) {
+                if (hipError_t e = run(*cand[idx[k]], 8)) return e;
+                if (hipError_t e = hipEventRecord(e0, stream)) return e;
+                if (hipError_t e = run(*cand[idx[k]], launches)) return e;
+                if (hipError_t e = hipEventRecord(e1, stream)) return e;
+                if (hipError_t e = hipEventSynchronize(e1)) return e;
+                float ms = 0.f;
+                if (hipError_t e = hipEventElapsedTime(&ms, e0, e1)) return e;
+                times[k].push_back((double)ms * 1000.0 / launches);
+            }
+        for (size_t k = 0; k < idx.size(); k++) {
+            std::sort(times[k].begin(), times[k].end());
+            cand[idx[k]]->us = times[k][times[k].size() / 2];
         }
-#undef TRY_OR_CLEAN
+        return hipSuccess;
+    };
+    TRY_OR_CLEAN(run(*cand[0], 4 * launches)); // clocks and translations up before anything is compared
+    std::vector<size_t> all(cand.size());
+    for (size_t k = 0; k < cand.size(); k++) all[k] = k;
+    TRY_OR_CLEAN(measure(all));
     size_t best = 0;
-    for (size_t k = 0; k < cand.size(); k++) {
-        std::sort(times[k].begin(), times[k].end());
-        cand[k]->us = times[k][times[k].size() / 2];
+    for (size_t k = 0; k < cand.size(); k++)
         if (cand[k]->us < cand[best]->us) best = k;
-    }
     // the default stays unless a candidate beats it by more than the noise between rounds (1.5 %)
     if (cand[best]->us > cand[0]->us * 0.985) best = 0;
+    const size_t n_first = cand.size();
+    // Second phase: the XCDs. A launch ends with its slowest XCD, and the eight XCDs of a part do not run this kernel equally fast (TilingParams::xcd_weight). The
+    // kernel reports how long each XCD's workgroups lived (FwdArgs::xcd_stat, measuring launches only); shares are re-cut in proportion and the new cut is kept
+    // if it is measurably faster; up to three rounds, each starting from the last cut kept.
+    std::string xcd_note;
+    if (c->cu_count % 8 == 0 && cand[best]->dev.n_wg >= 64 && hipMalloc((void **)&d_stat, 16 * sizeof(unsigned long long)) == hipSuccess) {
+        for (int round = 0; round < 3; round++) {
+            FwdTiling &cur = *cand[best];
+            unsigned long long h_stat[16];
+            TRY_OR_CLEAN(hipMemsetAsync(d_stat, 0, sizeof h_stat, stream));
+            cur.dev.k1_xcd_stat = d_stat;
+            const hipError_t e_run = run(cur, 2 * launches);
+            cur.dev.k1_xcd_stat = nullptr;
+            TRY_OR_CLEAN(e_run);
+            TRY_OR_CLEAN(hipStreamSynchronize(stream));
+            TRY_OR_CLEAN(hipMemcpy(h_stat, d_stat, sizeof h_stat, hipMemcpyDeviceToHost));
+            double life[8], mean = 0, lo = 1e30, hi = 0;
+            bool ok = true;
+            for (int x = 0; x < 8; x++) {
+                ok = ok && h_stat[2 * x + 1] > 0;
+                life[x] = ok ? (double)h_stat[2 * x] / (double)h_stat[2 * x + 1] : 0;
+                mean += life[x] / 8, lo = std::min(lo, life[x]), hi = std::max(hi, life[x]);
+            }
+            char b[200];
+            std::snprintf(b, sizeof b, "%s[%.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f]", round ? ", " : "", life[0] / 100, life[1] / 100, life[2] / 100, life[3] / 100, life[4] / 100,
+                          life[5] / 100, life[6] / 100, life[7] / 100);
+            xcd_note += b;
+            if (!ok || hi < lo * 1.02) break; // balanced within 2 %
+            auto t = std::make_unique<FwdTiling>();
+            t->tp = cur.tp;
+            double norm = 0;
+            for (int x = 0; x < 8; x++) {
+                const double w0 = cur.tp.xcd_weight[x] > 0 ? cur.tp.xcd_weight[x] : 1.0;
+                t->tp.xcd_weight[x] = (float)(w0 * mean / life[x]);
+                norm += t->tp.xcd_weight[x] / 8;
+            }
+            for (int x = 0; x < 8; x++) t->tp.xcd_weight[x] = (float)(t->tp.xcd_weight[x] / norm);
+            if (!build_forward_candidate(p, *t)) break;
+            t->label = tiling_label(t->tp, t->geo) + "/xcd-balanced" + (round ? std::to_string(round + 1) : std::string());
+            TRY_OR_CLEAN(upload_forward_candidate(p, *t));
+            cand.push_back(std::move(t));
+            TRY_OR_CLEAN(measure({best, cand.size() - 1}));
+            if (cand.back()->us > cand[best]->us * 0.995) break; // not measurably faster: keep what we have
+            best = cand.size() - 1;
+        }
+    }
+#undef TRY_OR_CLEAN
     char b[160];
     rep = "{\"tuned\": true, \"launches\": " + std::to_string(launches) + ", \"rounds\": " + std::to_string(kRounds) + ", \"pixel_slots\": " + std::to_string(px_slots) +
           ", \"coef_slots\": " + std::to_string(co_slots) + ", \"winner\": \"" + cand[best]->label + "\", \"candidates_us\": {";
@@ -1825,7 +1881,8 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
         std::snprintf(b, sizeof b, "%s\"%s\": %.3f", k ? ", " : "", cand[k]->label.c_str(), cand[k]->us);
         rep += b;
     }
-    rep += "}}";
+    rep += "}, \"xcd_workgroup_lifetimes_us\": \"" + xcd_note + "\"}";
+    (void)n_first;
     (void)hipDeviceSynchronize();
     if (best != 0) adopt_forward_tiling(p, *cand[best]);
     else p->fwd_tiling_note = cand[0]->label + " (measured: the default won)";

@@ -429,7 +429,7 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
             const size_t n_x = q + (x < r ? 1 : 0);
             for (size_t idx = 0; idx < n_x; idx++, sh++) {
                 const size_t b = idx * 8 + x;
-                cum[sh + 1] = cum[sh] + (weighted ? (double)tp.rank_weight[std::min<size_t>(b / per_rank, ranks - 1)] : 1.0);
+                cum[sh + 1] = cum[sh] + (weighted ? (double)tp.rank_weight[std::min<size_t>(b / per_rank, ranks - 1)] : 1.0) * (tp.xcd_weight[x] > 0 ? (double)tp.xcd_weight[x] : 1.0);
             }
         }
         g.wg_tiles.assign(n_wg + 1, 0);

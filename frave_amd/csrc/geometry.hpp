@@ -120,6 +120,10 @@ struct TilingParams {
     // {0,..} = equal shares.
     float rank_weight[4] = {0, 0, 0, 0};
     int ranks = 4; // resident workgroups per CU (<= 4)
+    // Relative share size by XCD (the shares of XCD x, device_common.hpp: xcd_contiguous_share, are scaled by xcd_weight[x]; 0 = 1). The eight XCDs of one
+    // MI355X do not run the same kernel equally fast - on one box the workgroups of XCDs 0, 1 and 7 lived 7-15 % longer than those of XCDs 2-6, on another
+    // it was XCDs 4-7 - and a launch ends with its slowest XCD. fri_hip_plan_tune_forward measures the XCDs' workgroup lifetimes and sets these.
+    float xcd_weight[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // Bytes one LDS tile buffer may take (rows * pitch); tiles of sparse bands (the image's last rows) are cut narrower
     // instead of sizing every buffer for them. 0 = no cap.
     int tile_buffer_bytes = 0;

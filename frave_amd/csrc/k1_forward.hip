@@ -32,6 +32,7 @@ struct FwdArgs {
     uint32_t pf_lpr, pf_magic; // row-run prefetch (geometry.cpp, Tile::pf_line): 128-byte steps per pixel row and the magic of the division by it; pf_lpr = 0: off
     int32_t ablate; // timing-only ablation (FRI_HIP_K1_ABLATE): 1 = skip staging, 2 = skip the cell loop, 4 = skip stores, 8 = return at entry. 0 in production.
     unsigned long long *trace; // diagnostic timeline, null in production
+    unsigned long long *xcd_stat; // fri_hip_plan_tune_forward only (null otherwise): [8][2] = per XCD {sum of workgroup lifetimes in 100 MHz ticks, workgroups}
     QMatrix q;
 };
 
@@ -398,6 +399,7 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
     const uint32_t wg = xcd_contiguous_share(blockIdx.x, a.n_wg);
     const int tb = a.wg_tiles[wg], te = a.wg_tiles[wg + 1];
     trace_stamp(a.trace, wg, 0, tid);
+    const unsigned long long t_entry = a.xcd_stat ? wall_clock64() : 0ull;
     // The share's tile descriptors go to LDS once, before any store is issued: fetching them inside the loop would be a
     // vector load behind s_waitcnt vmcnt(0) per tile (scalar loads are off the table once the kernel has stored), and that
     // wait would also drain the previous tile's coefficient stores.
@@ -550,6 +552,11 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
         t = tn;
     }
     trace_exit(a.trace, wg, tid);
+    if (a.xcd_stat && tid == 0) { // how long this XCD's workgroups live: what the tuner balances the XCDs' shares by (two fire-and-forget atomics, tuning launches only)
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; // XCC_ID[3:0]
+        (void)__hip_atomic_fetch_add(a.xcd_stat + 2 * xcc, wall_clock64() - t_entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_add(a.xcd_stat + 2 * xcc + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     asm volatile("; pf_keep %0" ::"v"(pf_keep)); // the prefetch register stays allocated to the end (see pf_issue)
 }
 
@@ -607,6 +614,7 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
     for (int i = 0; i <= 9; i++) a.q_identity &= (q.q[i] == 1); // layers 0..9 are the only ones a 512-node cell uses
     a.ablate = p.k1_ablate;
     a.trace = p.trace;
+    a.xcd_stat = p.k1_xcd_stat;
     const size_t lds = fwd_lds_bytes(p);
     const dim3 grid(a.n_wg, n_images), block(kFwdThreads);
     // EDGE variant only when a 16-byte chunk could straddle the ends of one of the caller's image buffers

@@ -81,7 +81,7 @@ def test_k1_scan_finds_a_planted_hazard(tmp_path):
     lines = open(tool.make_assembly()).read().splitlines()
     i = next(k for k, l in enumerate(lines) if re.match(r"\s*global_load_ubyte v\d+, v\d+, s\[", l) and any("fwd_transform_quant_kernel" in p for p in lines[max(0, k - 400):k]))
     reg = lines[i].split()[1].rstrip(",")
-    lines.insert(i + 3, f"\tv_add_u32_e32 v0, {reg}, v0")
+    lines.insert(i + 3, f"\tv_add_u32_e32 {reg}, v0, v0")
     bad = tmp_path / "planted.s"
     bad.write_text("\n".join(lines))
     _, _, problems = tool.scan(str(bad))

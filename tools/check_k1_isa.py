@@ -5,9 +5,9 @@ The prefetch is an inline-asm `global_load_ubyte` whose completion the compiler 
 staging loads to waits for data nobody uses). Its destination register must therefore never be read or written by any other instruction while a load may
 be in flight - which is the whole kernel. The kernel keeps ONE register for it (`pf_keep`, read-write in every issue, named by a marker comment at the
 kernel's end); this script scans every instantiation of fwd_transform_quant_kernel and fails if that register appears anywhere else than
-  * as the destination of the kernel's prefetch loads,
-  * in a `v_mov_b32 vN, 0` (its initialisation, on paths that issue nothing before), or
-  * in the marker.
+  * the prefetch loads themselves and the register's initialisation (`v_mov_b32 vN, 0`, inline asm too)
+are the only instructions that WRITE it (a compiler-made read can only be a don't-care operand, e.g. the unused high half of a 64-bit addend: the
+program never uses the loaded byte), and that all prefetch loads of a kernel land in ONE register (a split live range would free one of them early).
 The Makefile runs it on the assembly made with the object's exact flags before it links libfri_hip.so; tests/test_k2_isa.py runs it in the CPU suite.
 
     python tools/check_k1_isa.py                 # make the assembly (csrc/build/k1_forward.s), then scan it; exit code 0 = clean
@@ -38,8 +38,26 @@ def regs_of(text):
     return out
 
 
+# registers an instruction WRITES: the first operand of vector ALU / load instructions (stores and compares into SGPRs write no VGPR), both operands of the swaps
+def written(code):
+    m = re.match(r"(\S+)\s+(.*)$", code)
+    if not m:
+        return set()
+    op, rest = m.group(1), m.group(2)
+    if op.startswith(("global_store", "buffer_store", "ds_write", "scratch_store", "s_", "v_cmp", "v_readfirstlane", "v_readlane", "global_atomic", "buffer_atomic")) and "_rtn" not in op and " glc" not in rest:
+        return set()
+    if not op.startswith(("v_", "ds_", "global_", "buffer_", "scratch_", "flat_")):
+        return set()
+    ops = [o.strip() for o in rest.split(",")]
+    w = regs_of(ops[0]) if ops else set()
+    if op.startswith(("v_swap", "v_permlane16_swap", "v_permlane32_swap")) and len(ops) > 1:
+        w |= regs_of(ops[1])
+    return w
+
+
 def scan(asm):
-    """(kernels scanned, prefetch loads seen, problems)"""
+    """(kernels scanned, prefetch loads seen, problems). Per kernel: K = the destination registers of the inline-asm prefetch loads; nothing else may WRITE a
+    register of K (a read can only be a don't-care operand - the high half of a 64-bit addend, say: the program never uses the loaded byte)."""
     kernels, loads, problems = 0, 0, []
     name, body = None, []
 
@@ -51,28 +69,42 @@ def scan(asm):
         if len(marks) != 1:
             problems.append(f"{name}: {len(marks)} pf_keep markers (expected 1)")
             return
-        keep = regs_of(marks[0].split("pf_keep", 1)[1])
-        if len(keep) != 1:
-            problems.append(f"{name}: marker names {sorted(keep)}")
-            return
-        (k,) = keep
-        kernels += 1
-        n = 0
-        for no, line in body:
-            code = line.split(";", 1)[0].strip() if "pf_keep" not in line else ""
-            if not code or code.endswith(":") or code.startswith("."):
-                continue
-            if k not in regs_of(code):
-                continue
-            if re.match(rf"global_load_ubyte v{k}, v\d+, s\[\d+:\d+\]$", code):
-                n += 1
-            elif re.match(rf"v_mov_b32(_e32)? v{k}, 0$", code):
-                pass
-            else:
-                problems.append(f"{name}: line {no}: `{code}` touches the prefetch register v{k}")
+        keep = set(regs_of(marks[0].split("pf_keep", 1)[1]))
+        in_asm, n = False, 0
+        for _, line in body:  # pass 1: every register an asm-block prefetch load lands in
+            if "#ASMSTART" in line:
+                in_asm = True
+            elif "#ASMEND" in line:
+                in_asm = False
+            elif in_asm:
+                m = re.match(r"\s*global_load_ubyte (v\d+), v\d+, s\[\d+:\d+\]\s*$", line.split(";", 1)[0])
+                if m:
+                    keep |= regs_of(m.group(1))
+                    n += 1
         if n == 0:
             problems.append(f"{name}: no prefetch load found")
+            return
+        if len(keep) != 1:
+            problems.append(f"{name}: the prefetch loads land in {sorted(keep)}: the register was split")
+        kernels += 1
         loads += n
+        in_asm = False
+        for no, line in body:  # pass 2: who else writes them?
+            if "#ASMSTART" in line:
+                in_asm = True
+                continue
+            if "#ASMEND" in line:
+                in_asm = False
+                continue
+            code = line.split(";", 1)[0].strip()
+            if not code or code.endswith(":") or code.startswith("."):
+                continue
+            hit = written(code) & keep
+            if not hit:
+                continue
+            if in_asm and (re.match(r"global_load_ubyte v\d+, v\d+, s\[\d+:\d+\]$", code) or re.match(r"v_mov_b32(_e32)? v\d+, 0$", code)):
+                continue
+            problems.append(f"{name}: line {no}: `{code}` writes the prefetch register v{sorted(hit)[0]}")
 
     with open(asm) as f:
         for no, line in enumerate(f, 1):
