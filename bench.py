@@ -28,14 +28,16 @@ SPIN_UP_LAUNCHES = 4000  # ~70 ms of untimed work before the warm-up steps, see 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def measured_traffic():
-    """HBM bytes per K1 launch from the committed rocprofv3 PMC pass (profiles/), or None. bench.py cannot collect
-    hardware counters itself; the number is tied to the kernel named in the file."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r04_k1_traffic.json")) as f:
-            return int(json.load(f)["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+def measured_traffic(name="k1_traffic"):
+    """HBM bytes per K1 launch (per image for the batch form) from the committed rocprofv3 PMC pass (profiles/), or None. bench.py cannot collect
+    hardware counters itself; the number is tied to the kernel and tiling named in the file (newest round first)."""
+    for rnd in ("r05", "r04"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as f:
+                return int(json.load(f)["hbm_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
 
 
 def _cpu_info():
@@ -224,6 +226,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)  # on top of the untimed spin-up, see SPIN_UP_LAUNCHES
     ap.add_argument("--slots", type=int, default=24, help="distinct image/coefficient buffer pairs the steps rotate over (>= 24: neither pixels nor coefficients can come from the 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tune", action="store_true", help="keep fri_hip_plan_create's default forward tiling instead of measuring (fri_hip_plan_tune_forward)")
     ap.add_argument("--no-extras", action="store_true", help="leave the event-timed figures of K2 / K3 / K4 / K1-RGB / the chain out of the line")
     ap.add_argument("--extras", action="store_true", help="(kept for older command lines: the extras are in the default line now; adds the PCIe byte counts)")
     args = ap.parse_args()
@@ -270,6 +273,10 @@ def main():
 
     ctx = frave_amd.Context(local_rank)  # raises if the HIP library or a gfx950 GPU is missing: no fallback
     plan = frave_amd.Plan(ctx, W, H, CHANNELS)
+    # The plan measures its forward tiling on THIS device (fri_hip_plan_tune_forward, like an FFT plan made with MEASURE): a handful of candidate cuts of the
+    # cell lattice into tiles / shares, then the eight XCDs' shares balanced by their measured workgroup lifetimes - tens of milliseconds on scratch buffers of
+    # the call's own, once, before anything is timed. Results do not depend on the tiling (every parity test runs on tuned and untuned plans alike).
+    tuning = None if args.no_tune else plan.tune_forward()
     F = plan.num_cells
     alg_bytes = plan.pixel_bytes + plan.coef_count * 4  # u8 read once + int32 coefficient write
 
@@ -343,6 +350,7 @@ def main():
                         f"F={F} cells, {args.slots} rotating HBM-resident slots",
             "channels": CHANNELS,
             "spin_up_launches": SPIN_UP_LAUNCHES,
+            "forward_tiling": tuning if tuning is not None else "default (not measured: --no-tune)",
             "parallelism": f"batch sharded by image, image i -> GPU i mod {world} (fri_hip_shard_image), no collective",
         },
         "roofline": {
@@ -352,7 +360,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": measured_traffic(),
-            "kernel": "fwd_transform_quant_kernel<1,false,true,4,true>",
+            "kernel": "fwd_transform_quant_kernel<1,false,true,4,true,true>",
             "kernel_us": round(kernel_us, 3),
             "algorithmic_bytes_per_launch": alg_bytes,
         },
@@ -366,6 +374,31 @@ def main():
             "after_call_us": round(elapsed * 1e6 - timed["call_us"], 1),
         },
     }
+
+    if rank == 0:
+        # The batch form of the same kernel (fri_hip_transform_quant_batch_dev: BASELINE config 4 runs like this): `nb` DISTINCT images in one launch, per image.
+        # One launch's ramp and tail are paid once per nb images: the steady state of the kernel. Its own PMC traffic pass: profiles/r05_k1_batch_traffic.json.
+        nb = min(args.slots, 24)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        batch = lambda: plan.transform_quant_dev(px0, co0, stream=stream, n_images=nb, pixel_stride=pstride, coef_stride=cstride)
+        batch()
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(4):
+            batch()
+        ev1.record()
+        torch.cuda.synchronize()
+        us_img = ev0.elapsed_time(ev1) * 1e3 / 4 / nb
+        out["roofline_batch"] = {
+            "bound": "hbm", "images_per_launch": nb, "kernel_us_per_image": round(us_img, 3), "achieved": round(alg_bytes / us_img / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg_bytes / us_img / 1e3 / HBM_PEAK_GBS, 4), "traffic": measured_traffic("k1_batch_traffic"),
+            "note": f"one launch over {nb} distinct images (grid.y = {nb}), HIP events around 4 launches; traffic per image from its own PMC pass",
+        }
+        # ... and single-image launches dealt over two streams of the library (fri_hip_time_transform_quant_streams_dev): launch i + 1 fills the CUs launch i's
+        # early finishers leave. A launch PERIOD (first begin to last end over the launches), never a kernel duration; never part of `value` or `roofline`.
+        period = plan.time_transform_quant_streams_dev(args.slots, px0, pstride, co0, cstride, max(args.steps, 200), 2)
+        out["two_stream_launch_period"] = {"us": round(period, 3), "frac_of_roofline_by_period": round(alg_bytes / period / 1e3 / HBM_PEAK_GBS, 4), "streams": 2,
+                                          "note": "independent images, launches alternate over two streams; period, not kernel time"}
 
     # The rest of the path north_star names (K2 = predict + histogram) and of the encode chain, in the same line: every figure is the mean
     # period of back-to-back launches between two HIP events on the launch stream, with its fraction of the 8 TB/s roofline for the

@@ -354,7 +354,6 @@ void fill_forward_tiling(DevicePlan &d, const Geometry &g) {
     d.n_wg_batch = (uint32_t)g.wg_tiles_batch.size() - 1;
     d.max_wg_cells = g.max_wg_cells;
     d.n_wg = (uint32_t)g.wg_tiles.size() - 1;
-    d.pf_lines_per_row = g.pf_lines_per_row;
 }
 
 template <typename T>
@@ -399,7 +398,6 @@ hipError_t upload_forward_candidate(const fri_hip_plan *p, FwdTiling &c) {
 void adopt_forward_tiling(fri_hip_plan *p, FwdTiling &c) {
     Geometry &g = p->geo;
     g.tiles.swap(c.geo.tiles), g.tile_cells.swap(c.geo.tile_cells), g.tile_meta.swap(c.geo.tile_meta), g.wg_tiles.swap(c.geo.wg_tiles), g.wg_tiles_batch.swap(c.geo.wg_tiles_batch);
-    g.pf_lines_per_row = c.geo.pf_lines_per_row;
     g.max_wg_tiles_batch = c.geo.max_wg_tiles_batch, g.lds_pitch = c.geo.lds_pitch, g.lds_rows = c.geo.lds_rows, g.band_rows = c.geo.band_rows, g.cells_per_tile = c.geo.cells_per_tile;
     g.cells_per_wg = c.geo.cells_per_wg, g.max_tile_cells = c.geo.max_tile_cells, g.max_wg_tiles = c.geo.max_wg_tiles, g.max_wg_cells = c.geo.max_wg_cells;
     DevicePlan &d = p->dev;
@@ -414,9 +412,15 @@ void adopt_forward_tiling(fri_hip_plan *p, FwdTiling &c) {
 
 std::string tiling_label(const TilingParams &tp, const Geometry &g) {
     char b[96];
-    std::snprintf(b, sizeof b, "%s/band%d/cells%d%s", tp.strided_shares ? "interleaved" : "contiguous", g.band_rows, g.cells_per_tile,
-                  g.pf_lines_per_row ? (tp.prefetch > 1 ? "/prefetch2" : "/prefetch") : "");
-    return b;
+    std::snprintf(b, sizeof b, "%s/band%d/cells%d", tp.strided_shares ? "interleaved" : "contiguous", g.band_rows, g.cells_per_tile);
+    std::string l = b;
+    if (!tp.strided_shares && tp.xcd_group_tiles > 0) l += "/xcd-groups" + std::to_string(tp.xcd_group_tiles);
+    if (tp.tail_wgs > 0 && tp.tail_percent > 0) l += "/tail" + std::to_string(tp.tail_wgs) + "x" + std::to_string(tp.tail_percent) + "%";
+    if (tp.rank_weight[0] > 0) {
+        std::snprintf(b, sizeof b, "/w%.2f-%.2f", tp.rank_weight[0], tp.rank_weight[std::max(0, std::min(tp.ranks, 4) - 1)]);
+        l += b;
+    }
+    return l;
 }
 
 // winners of this process, per (device, width, height, channels): later plans of the same shape start from them without measuring again
@@ -509,7 +513,8 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
     tp.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
     tp.cells_per_wg = env_int("FRI_HIP_CELLS_PER_WG");
     tp.batch_share_tiles = env_int("FRI_HIP_BATCH_SHARE_TILES");
-    tp.prefetch = env_str("FRI_HIP_K1_PREFETCH") ? env_int("FRI_HIP_K1_PREFETCH") : 0; // row-run prefetch distance in rounds (geometry.cpp); 0 = off
+    tp.tail_wgs = env_int("FRI_HIP_TAIL_WGS"), tp.tail_percent = env_int("FRI_HIP_TAIL_PERCENT");
+    tp.xcd_group_tiles = env_int("FRI_HIP_XCD_GROUP_TILES");
     // Interleaved shares (geometry.cpp): the resident workgroups work on one window sliding over the image. Default since round 4 (4096^2 from HBM: planes
     // 20.3 -> 19.1 us, RGB 55.5 -> 51.9 us, the inverse 29.6 -> 27.8 / 86 -> 72 us); FRI_HIP_STRIDED_SHARES=0 (tuning) restores one contiguous run per share.
     // Up to ~200 000 cells, that is: at 12000^2 and 16384^2 (282 K / 526 K cells, many short shares dispatched in order: the resident set slides already) the
@@ -605,7 +610,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         ti.band_rows = env_int("FRI_HIP_INV_BAND_ROWS") > 0 ? env_int("FRI_HIP_INV_BAND_ROWS") : (channels == 1 ? 32 : 16);
         ti.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
         ti.cells_per_wg = 0;
-        ti.prefetch = 0; // (the inverse kernel reads coefficients, one contiguous 2 KiB piece per cell: nothing to gather into runs)
+        ti.tail_wgs = ti.tail_percent = ti.xcd_group_tiles = 0;
         ti.target_wgs = ctx_wgs(ctx, tp.ranks);
         ti.strided_shares = env_str("FRI_HIP_INV_STRIDED_SHARES") ? env_int("FRI_HIP_INV_STRIDED_SHARES") > 0 : (strided_env ? tp.strided_shares : true); // interleaved at every size it is built for
         bool ok = false;
@@ -671,8 +676,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         d.channels = (int32_t)g.channels;
         d.lds_pitch = g.lds_pitch;
         d.lds_rows = g.lds_rows;
-        d.pf_lines_per_row = g.pf_lines_per_row;
-        d.cells_per_tile = g.cells_per_tile;
+            d.cells_per_tile = g.cells_per_tile;
         d.max_tile_cells = g.max_tile_cells;
         d.covers_image = g.n_valid_leaves == (uint64_t)g.width * g.height;
         d.max_wg_tiles = std::max(g.max_wg_tiles, g.max_wg_tiles_batch);
@@ -854,9 +858,8 @@ int fri_hip_plan_read_trace(fri_hip_plan *p, uint64_t *out) {
 int fri_hip_plan_tile_table(const fri_hip_plan *p, int32_t *tiles, int32_t *tile_cells, int32_t *wg_tiles) {
     if (!p) return FRI_HIP_ERR_INVALID_ARGUMENT;
     const Geometry &g = p->geo;
-    static_assert(sizeof(Tile) == 8 * sizeof(int32_t), "Tile layout");
-    if (tiles)
-        for (size_t t = 0; t < g.tiles.size(); t++) std::memcpy(tiles + 6 * t, &g.tiles[t], 6 * sizeof(int32_t)); // the ABI's six fields; the prefetch slice stays inside
+    static_assert(sizeof(Tile) == 6 * sizeof(int32_t), "Tile layout");
+    if (tiles) std::memcpy(tiles, g.tiles.data(), g.tiles.size() * sizeof(Tile));
 
     if (tile_cells) std::memcpy(tile_cells, g.tile_cells.data(), g.tile_cells.size() * sizeof(int32_t));
     if (wg_tiles) std::memcpy(wg_tiles, g.wg_tiles.data(), g.wg_tiles.size() * sizeof(int32_t));
@@ -1726,30 +1729,32 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
     const bool rgb = g0.channels != 1;
     // candidates: the plan's tiling first, then the settings that won somewhere in round 4's sweeps (tools/r4_k1_hbm*.sh, r4_cells.sh)
     std::vector<std::unique_ptr<FwdTiling>> cand;
-    auto add = [&](int strided, int band, int cells_delta, int prefetch = 0) {
+    auto add_tp = [&](const TilingParams &tp) {
         auto t = std::make_unique<FwdTiling>();
-        t->tp = p->fwd_tp;
-        t->tp.prefetch = prefetch;
-        if (strided >= 0) t->tp.strided_shares = strided != 0;
-        if (band > 0) t->tp.band_rows = band;
-        if (cells_delta) t->tp.cells_per_tile = g0.cells_per_tile + cells_delta;
-        if (t->tp.cells_per_tile < 0) return;
+        t->tp = tp;
+        if (t->tp.cells_per_tile < 0 || t->tp.band_rows < 0) return;
         if (!build_forward_candidate(p, *t)) return;
         t->label = tiling_label(t->tp, t->geo);
         for (const auto &o : cand)
             if (o->label == t->label) return; // the builder clamped it to something already there
         cand.push_back(std::move(t));
     };
-    add(-1, 0, 0, p->fwd_tp.prefetch);
+    auto add = [&](int strided, int band, int cells_delta, int xcd_groups = 0) {
+        TilingParams tp = p->fwd_tp;
+        if (strided >= 0) tp.strided_shares = strided != 0;
+        if (band > 0) tp.band_rows = band;
+        if (cells_delta) tp.cells_per_tile = g0.cells_per_tile + cells_delta;
+        tp.xcd_group_tiles = xcd_groups;
+        add_tp(tp);
+    };
+    add(-1, 0, 0);
     if (cand.empty()) {
         rep = "{\"tuned\": false, \"why\": \"the plan's own tiling could not be rebuilt\"}";
         return finish(FRI_HIP_OK);
     }
     if (!rgb) {
-        add(1, 16, 0, 1), add(1, 16, 0, 2), add(1, 8, 0, 1), add(1, 32, 0, 1), add(1, 16, 1, 1);
-        add(0, 72, 0), add(1, 16, 1), add(1, 32, 0), add(1, 8, 0), add(0, 8, 0), add(1, 24, 0), add(0, 48, 0), add(1, 16, -1);
+        add(0, 72, 0), add(0, 72, 0, 32), add(1, 16, 1), add(1, 32, 0), add(1, 8, 0), add(0, 8, 0), add(1, 24, 0), add(0, 48, 0), add(0, 16, 0, 32);
     } else {
-        add(1, 16, 0, 1), add(1, 16, 0, 2), add(1, 12, 0, 1), add(1, 24, 0, 1);
         add(1, 12, 0), add(1, 24, 0), add(0, 16, 0), add(1, 8, 0), add(0, 32, 0);
     }
     // scratch: enough distinct images that the pixels cannot come from the 256 MiB Infinity Cache, and coefficient slots whose rewrites are > 512 MB apart
@@ -1827,50 +1832,72 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
         if (cand[k]->us < cand[best]->us) best = k;
     // the default stays unless a candidate beats it by more than the noise between rounds (1.5 %)
     if (cand[best]->us > cand[0]->us * 0.985) best = 0;
-    const size_t n_first = cand.size();
-    // Second phase: the XCDs. A launch ends with its slowest XCD, and the eight XCDs of a part do not run this kernel equally fast (TilingParams::xcd_weight). The
-    // kernel reports how long each XCD's workgroups lived (FwdArgs::xcd_stat, measuring launches only); shares are re-cut in proportion and the new cut is kept
-    // if it is measurably faster; up to three rounds, each starting from the last cut kept.
+    // Second phase: around the winner - its neighbours in band height and tile size, for contiguous shares the XCDs taking turns over groups of tiles, flatter and
+    // steeper share sizes by dispatch rank - measured together with it, interleaved like the first phase.
+    {
+        const TilingParams w = cand[best]->tp;
+        const Geometry &gw = cand[best]->geo;
+        std::vector<size_t> round2{best};
+        const size_t n0 = cand.size();
+        auto also = [&](TilingParams tp) { add_tp(tp); };
+        for (int d : {-8, 8}) {
+            TilingParams tp = w;
+            tp.band_rows = gw.band_rows + d;
+            if (tp.band_rows >= 8) also(tp);
+        }
+        for (int d : {-1, 1}) {
+            TilingParams tp = w;
+            tp.cells_per_tile = gw.cells_per_tile + d;
+            if (tp.cells_per_tile >= 2) also(tp);
+        }
+        if (!w.strided_shares)
+            for (int grp : {16, 32, 64, 128}) {
+                TilingParams tp = w;
+                tp.xcd_group_tiles = grp;
+                also(tp);
+            }
+        for (int pct : {8, 15, 25})
+            for (int n : {256, 512}) {
+                TilingParams tp = w;
+                tp.tail_wgs = n, tp.tail_percent = pct;
+                also(tp);
+            }
+        if (w.ranks == 4 && w.rank_weight[0] > 0) {
+            static const float flat[4] = {1.2f, 1.05f, 0.95f, 0.8f}, steep[4] = {1.4f, 1.15f, 0.85f, 0.6f};
+            for (const float *v : {flat, steep}) {
+                TilingParams tp = w;
+                for (int i = 0; i < 4; i++) tp.rank_weight[i] = v[i];
+                also(tp);
+            }
+        }
+        for (size_t k = n0; k < cand.size(); k++) {
+            TRY_OR_CLEAN(upload_forward_candidate(p, *cand[k]));
+            round2.push_back(k);
+        }
+        if (round2.size() > 1) {
+            TRY_OR_CLEAN(measure(round2));
+            size_t b2 = best;
+            for (size_t k : round2)
+                if (cand[k]->us < cand[b2]->us) b2 = k;
+            if (cand[b2]->us < cand[best]->us * 0.99) best = b2; // (1 %: the winner of phase one was measured again in this phase, side by side)
+        }
+    }
+    // How long each XCD's workgroups live under the winner (FwdArgs::xcd_stat; a diagnostic for the report: re-cutting the XCDs' shares in proportion was tried and
+    // does not transfer from the tuner's scratch buffers to the caller's - which XCD is slow changes with the buffers' placement).
     std::string xcd_note;
-    if (c->cu_count % 8 == 0 && cand[best]->dev.n_wg >= 64 && hipMalloc((void **)&d_stat, 16 * sizeof(unsigned long long)) == hipSuccess) {
-        for (int round = 0; round < 3; round++) {
-            FwdTiling &cur = *cand[best];
-            unsigned long long h_stat[16];
-            TRY_OR_CLEAN(hipMemsetAsync(d_stat, 0, sizeof h_stat, stream));
-            cur.dev.k1_xcd_stat = d_stat;
-            const hipError_t e_run = run(cur, 2 * launches);
-            cur.dev.k1_xcd_stat = nullptr;
-            TRY_OR_CLEAN(e_run);
-            TRY_OR_CLEAN(hipStreamSynchronize(stream));
-            TRY_OR_CLEAN(hipMemcpy(h_stat, d_stat, sizeof h_stat, hipMemcpyDeviceToHost));
-            double life[8], mean = 0, lo = 1e30, hi = 0;
-            bool ok = true;
-            for (int x = 0; x < 8; x++) {
-                ok = ok && h_stat[2 * x + 1] > 0;
-                life[x] = ok ? (double)h_stat[2 * x] / (double)h_stat[2 * x + 1] : 0;
-                mean += life[x] / 8, lo = std::min(lo, life[x]), hi = std::max(hi, life[x]);
-            }
-            char b[200];
-            std::snprintf(b, sizeof b, "%s[%.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f]", round ? ", " : "", life[0] / 100, life[1] / 100, life[2] / 100, life[3] / 100, life[4] / 100,
-                          life[5] / 100, life[6] / 100, life[7] / 100);
+    if (hipMalloc((void **)&d_stat, 16 * sizeof(unsigned long long)) == hipSuccess) {
+        unsigned long long h_stat[16];
+        TRY_OR_CLEAN(hipMemsetAsync(d_stat, 0, sizeof h_stat, stream));
+        cand[best]->dev.k1_xcd_stat = d_stat;
+        const hipError_t e_run = run(*cand[best], launches);
+        cand[best]->dev.k1_xcd_stat = nullptr;
+        TRY_OR_CLEAN(e_run);
+        TRY_OR_CLEAN(hipStreamSynchronize(stream));
+        TRY_OR_CLEAN(hipMemcpy(h_stat, d_stat, sizeof h_stat, hipMemcpyDeviceToHost));
+        for (int x = 0; x < 8; x++) {
+            char b[32];
+            std::snprintf(b, sizeof b, "%s%.2f", x ? " " : "", h_stat[2 * x + 1] ? (double)h_stat[2 * x] / (double)h_stat[2 * x + 1] / 100.0 : 0.0);
             xcd_note += b;
-            if (!ok || hi < lo * 1.02) break; // balanced within 2 %
-            auto t = std::make_unique<FwdTiling>();
-            t->tp = cur.tp;
-            double norm = 0;
-            for (int x = 0; x < 8; x++) {
-                const double w0 = cur.tp.xcd_weight[x] > 0 ? cur.tp.xcd_weight[x] : 1.0;
-                t->tp.xcd_weight[x] = (float)(w0 * mean / life[x]);
-                norm += t->tp.xcd_weight[x] / 8;
-            }
-            for (int x = 0; x < 8; x++) t->tp.xcd_weight[x] = (float)(t->tp.xcd_weight[x] / norm);
-            if (!build_forward_candidate(p, *t)) break;
-            t->label = tiling_label(t->tp, t->geo) + "/xcd-balanced" + (round ? std::to_string(round + 1) : std::string());
-            TRY_OR_CLEAN(upload_forward_candidate(p, *t));
-            cand.push_back(std::move(t));
-            TRY_OR_CLEAN(measure({best, cand.size() - 1}));
-            if (cand.back()->us > cand[best]->us * 0.995) break; // not measurably faster: keep what we have
-            best = cand.size() - 1;
         }
     }
 #undef TRY_OR_CLEAN
@@ -1882,7 +1909,6 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
         rep += b;
     }
     rep += "}, \"xcd_workgroup_lifetimes_us\": \"" + xcd_note + "\"}";
-    (void)n_first;
     (void)hipDeviceSynchronize();
     if (best != 0) adopt_forward_tiling(p, *cand[best]);
     else p->fwd_tiling_note = cand[0]->label + " (measured: the default won)";

@@ -372,7 +372,7 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         y0 = std::max(y0, 0);
         x1 = std::min(x1, W - 1);
         y1 = std::min(y1, H - 1);
-        Tile t{x0, y0, x1 - x0 + 1, y1 - y0 + 1, (int32_t)i, (int32_t)(j - i), 0, 0};
+        Tile t{x0, y0, x1 - x0 + 1, y1 - y0 + 1, (int32_t)i, (int32_t)(j - i)};
         max_w = std::max(max_w, t.width_px);
         max_r = std::max(max_r, t.n_rows);
         g.max_tile_cells = std::max(g.max_tile_cells, t.cell_count);
@@ -417,6 +417,11 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
     // inverse of the kernels' XCD-contiguous block -> share map), whose dispatch rank is b / (target_wgs / ranks).
     const size_t T = g.tiles.size();
     if (tp.cells_per_wg <= 0) n_wg = (size_t)target_wgs; // one share per resident workgroup, or one per tile if there are fewer tiles
+    // Tail shares: tail_wgs extra, short shares behind the resident round, together tail_percent % of the tiles. The hardware hands them to whichever CU of their
+    // XCD frees a slot first: the CUs that got through their resident shares early take more of them - dynamic balance without an atomic.
+    const size_t tail_wgs = tp.cells_per_wg <= 0 && tp.tail_wgs > 0 && tp.tail_percent > 0 && tp.tail_percent < 60 && T >= 2 * ((size_t)target_wgs + (size_t)tp.tail_wgs)
+                                ? (size_t)tp.tail_wgs : 0;
+    n_wg += tail_wgs;
     n_wg = std::max<size_t>(1, std::min(n_wg, T));
     g.cells_per_wg = (int32_t)((F + n_wg - 1) / n_wg);
     {
@@ -425,11 +430,18 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         for (int i = 0; i < ranks; i++) weighted = weighted && tp.rank_weight[i] > 0;
         std::vector<double> cum(n_wg + 1, 0.0);
         const size_t q = n_wg >> 3, r = n_wg & 7, per_rank = std::max<size_t>(1, (size_t)target_wgs / ranks);
+        auto weight_of = [&](size_t b) { return weighted ? (double)tp.rank_weight[std::min<size_t>(b / per_rank, ranks - 1)] : 1.0; };
+        double w_tail = 0;
+        if (tail_wgs) { // blocks >= target_wgs are the tail: each weighs so that all of them together hold tail_percent % of the total
+            double main_sum = 0;
+            for (size_t b = 0; b < n_wg - tail_wgs; b++) main_sum += weight_of(b);
+            w_tail = main_sum * tp.tail_percent / (100.0 - tp.tail_percent) / (double)tail_wgs;
+        }
         for (size_t x = 0, sh = 0; x < 8; x++) {
             const size_t n_x = q + (x < r ? 1 : 0);
             for (size_t idx = 0; idx < n_x; idx++, sh++) {
                 const size_t b = idx * 8 + x;
-                cum[sh + 1] = cum[sh] + (weighted ? (double)tp.rank_weight[std::min<size_t>(b / per_rank, ranks - 1)] : 1.0) * (tp.xcd_weight[x] > 0 ? (double)tp.xcd_weight[x] : 1.0);
+                cum[sh + 1] = cum[sh] + (tail_wgs && b >= n_wg - tail_wgs ? w_tail : weight_of(b));
             }
         }
         g.wg_tiles.assign(n_wg + 1, 0);
@@ -444,7 +456,8 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
             g.max_wg_tiles = std::max(g.max_wg_tiles, g.wg_tiles[sh + 1] - g.wg_tiles[sh]);
         }
     }
-    if (tp.strided_shares && n_wg > 1) {
+    const bool xcd_groups = !tp.strided_shares && tp.xcd_group_tiles > 0 && n_wg >= 8;
+    if ((tp.strided_shares || xcd_groups) && n_wg > 1) {
         // Interleaved shares: the tiles are dealt to the shares like cards, round after round in share order, instead of giving every share one contiguous
         // run. At any moment of a one-round launch the resident workgroups then work on ONE window of consecutive tiles that slides over the image - the
         // pixel rows they read and the coefficient range they write are a compact, moving region of memory, not n_wg fronts spread over all of it - and
@@ -452,6 +465,21 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         // contiguous in the arrays (the kernels walk [wg_tiles[sh], wg_tiles[sh + 1]) and load a share's cell records as one range): the arrays are permuted.
         std::vector<std::vector<int32_t>> dealt(n_wg);
         size_t next = 0;
+        if (xcd_groups) {
+            // Contiguous shares, but the XCDs take turns over the image: the band-major tile sequence is cut into groups of xcd_group_tiles tiles and XCD x (the
+            // shares [x n/8, (x + 1) n/8): xcd_contiguous_share) walks groups x, x + 8, x + 16, ... - with one contiguous eighth of the image per XCD the eight
+            // XCDs move through eight regions 8.5 MB apart in lockstep, and which of them the memory system serves slowest decides when the launch ends
+            // (per-XCD workgroup lifetimes 11.4 ... 16.1 us in one launch). A share is still a run of neighbouring tiles of one band.
+            std::vector<int32_t> perm;
+            perm.reserve(T);
+            const size_t gsz = (size_t)tp.xcd_group_tiles, n_groups = (T + gsz - 1) / gsz;
+            for (size_t x = 0; x < 8; x++)
+                for (size_t grp = x; grp < n_groups; grp += 8)
+                    for (size_t t = grp * gsz; t < std::min(T, (grp + 1) * gsz); t++) perm.push_back((int32_t)t);
+            for (size_t sh = 0; sh < n_wg; sh++)
+                for (int32_t t = g.wg_tiles[sh]; t < g.wg_tiles[sh + 1]; t++) dealt[sh].push_back(perm[(size_t)t]);
+            next = T;
+        }
         for (bool any = true; any && next < T;) {
             any = false;
             for (size_t sh = 0; sh < n_wg && next < T; sh++)
@@ -483,43 +511,6 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         g.tiles.swap(tiles2);
         g.tile_meta.swap(meta2);
         g.tile_cells.swap(cells2);
-    }
-    if (tp.strided_shares && tp.prefetch > 0 && n_wg >= 8) {
-        // Row-run prefetch (round 5). A tile's staging loads are a 170-byte piece of each of ~50 image rows: every piece opens another DRAM page, and with
-        // a thousand workgroups asking at once the memory controller cannot put the pieces of one row together again - the 21 MB of pixel reads cost a
-        // 4096^2 launch 4-5 us, as much as a third of its 68 MB of stores (timing-only ablations). But WHICH rows an XCD's
-        // workgroups stage in round k + 1 is known: with interleaved shares it is one horizontal stripe of the image (the XCD's ~128 consecutive tiles of
-        // that round). So while a workgroup works on tile k it pulls its slice of that stripe - whole rows, 128-byte steps handed to consecutive lanes,
-        // consecutive slices to consecutive shares - into its XCD's L2, and the staging loads of round k + 1 hit there. Same bytes from HBM, read as
-        // long runs. The slices ride in the tile descriptors (Tile::pf_line / pf_count), one per tile.
-        const int row_bytes = W * (int)channels;
-        const int lpr = (row_bytes + 127) / 128 + 1; // steps of 128 bytes from the 128-byte boundary below a row's first byte cover it whatever the alignment
-        g.pf_lines_per_row = lpr;
-        const size_t q = n_wg >> 3, r = n_wg & 7;
-        for (size_t x = 0; x < 8; x++) {
-            const size_t s0 = x * q + std::min(x, r), s1 = s0 + q + (x < r ? 1 : 0); // the shares of XCD x (device_common.hpp: xcd_contiguous_share)
-            for (int k = 0; k < g.max_wg_tiles; k++) {
-                // rows the XCD stages in round k + d, and the shares that are still running tile k (they do the pulling)
-                int y0 = INT_MAX, y1 = INT_MIN;
-                std::vector<size_t> alive;
-                for (size_t sh = s0; sh < s1; sh++) {
-                    const int n = g.wg_tiles[sh + 1] - g.wg_tiles[sh];
-                    if (k < n) alive.push_back(sh);
-                    if (k + tp.prefetch < n) {
-                        const Tile &t = g.tiles[g.wg_tiles[sh] + k + tp.prefetch];
-                        y0 = std::min(y0, t.y_lo), y1 = std::max(y1, t.y_lo + t.n_rows);
-                    }
-                }
-                if (y1 <= y0 || alive.empty()) continue;
-                const long long lines = (long long)(y1 - y0) * lpr, first = (long long)y0 * lpr;
-                for (size_t a = 0; a < alive.size(); a++) {
-                    const long long b = lines * (long long)a / (long long)alive.size(), e = lines * (long long)(a + 1) / (long long)alive.size();
-                    Tile &t = g.tiles[g.wg_tiles[alive[a]] + k];
-                    t.pf_line = (int32_t)(first + b);
-                    t.pf_count = (int32_t)std::min<long long>(e - b, 256); // one step per thread of the workgroup
-                }
-            }
-        }
     }
     {
         const size_t cells_target = (size_t)(tp.batch_share_tiles > 0 ? tp.batch_share_tiles : 4) * cells_per_tile;

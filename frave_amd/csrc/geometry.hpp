@@ -40,10 +40,6 @@ struct Tile {
     int32_t x_lo, y_lo;     // top-left pixel of the staged rectangle (already clipped to the image)
     int32_t width_px, n_rows;
     int32_t cell_begin, cell_count; // range in tile_cells
-    // Forward kernel, interleaved shares only (build_prefetch_schedule): the slice of image "lines" (128-byte steps along whole pixel rows: line i = step
-    // i % lines_per_row of row i / lines_per_row) this workgroup pulls into its XCD's L2 while it works on the tile BEFORE this one - the rows the XCD's
-    // workgroups will stage one round later. pf_count = 0: nothing.
-    int32_t pf_line = 0, pf_count = 0;
 };
 
 // Write-out lists of the inverse kernel (geometry only). A tile's pixels are staged in LDS as rows of 16-byte quads; image row
@@ -92,7 +88,6 @@ struct Geometry {
     std::vector<uint16_t> inv_quads, inv_dwords;
     std::vector<uint32_t> inv_parts;
     int32_t inv_rect_bytes = 0; // largest n_rows * quads-per-row * 16 over all tiles
-    int32_t pf_lines_per_row = 0; // forward prefetch: 128-byte steps per pixel row (0 = no schedule in the tiles)
     int32_t lds_pitch = 0;   // bytes per staged row (multiple of 16)
     int32_t lds_rows = 0;    // max rows per tile
     int32_t band_rows = 0, cells_per_tile = 0, cells_per_wg = 0;
@@ -120,17 +115,12 @@ struct TilingParams {
     // {0,..} = equal shares.
     float rank_weight[4] = {0, 0, 0, 0};
     int ranks = 4; // resident workgroups per CU (<= 4)
-    // Relative share size by XCD (the shares of XCD x, device_common.hpp: xcd_contiguous_share, are scaled by xcd_weight[x]; 0 = 1). The eight XCDs of one
-    // MI355X do not run the same kernel equally fast - on one box the workgroups of XCDs 0, 1 and 7 lived 7-15 % longer than those of XCDs 2-6, on another
-    // it was XCDs 4-7 - and a launch ends with its slowest XCD. fri_hip_plan_tune_forward measures the XCDs' workgroup lifetimes and sets these.
-    float xcd_weight[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // Bytes one LDS tile buffer may take (rows * pitch); tiles of sparse bands (the image's last rows) are cut narrower
     // instead of sizing every buffer for them. 0 = no cap.
     int tile_buffer_bytes = 0;
     int batch_share_tiles = 0; // tiles' worth of cells per merged batch share (0 = 4)
-    // Row-run prefetch for the forward kernel (needs strided_shares): see Tile::pf_line. 0 = off; d >= 1: the slice issued with tile k of a share covers the
-    // rows round k + d of the share's XCD stages (d = 1: the next round's, issued one tile iteration ahead of the demand loads).
-    int prefetch = 0;
+    int tail_wgs = 0, tail_percent = 0; // > 0: tail_wgs extra short shares behind the target_wgs resident ones, holding tail_percent % of the tiles together (geometry.cpp)
+    int xcd_group_tiles = 0; // contiguous shares only: > 0 = the XCDs take turns over groups of this many consecutive tiles (geometry.cpp) instead of one contiguous eighth of the image each
     bool strided_shares = false; // deal the tiles to the shares round-robin (the resident set works on one sliding window of the image) instead of one contiguous run each
 };
 

@@ -29,7 +29,6 @@ struct FwdArgs {
     int32_t buf_bytes; // bytes of one LDS buffer (pixel rows + cell records)
     uint32_t cpr, cpr_magic;
     int32_t q_identity;
-    uint32_t pf_lpr, pf_magic; // row-run prefetch (geometry.cpp, Tile::pf_line): 128-byte steps per pixel row and the magic of the division by it; pf_lpr = 0: off
     int32_t ablate; // timing-only ablation (FRI_HIP_K1_ABLATE): 1 = skip staging, 2 = skip the cell loop, 4 = skip stores, 8 = return at entry. 0 in production.
     unsigned long long *trace; // diagnostic timeline, null in production
     unsigned long long *xcd_stat; // fri_hip_plan_tune_forward only (null otherwise): [8][2] = per XCD {sum of workgroup lifetimes in 100 MHz ticks, workgroups}
@@ -370,21 +369,6 @@ __device__ __forceinline__ ItemAddr item_addr(const FwdArgs &a, const Tile &t, c
     return r;
 }
 
-// Row-run prefetch: thread t < count touches one byte of line first + t (line i = 128-byte step i % lpr of pixel row i / lpr), which pulls the 128-byte
-// line into this XCD's L2; threads beyond the slice re-request its first line (branch-free: a conditional definition of `keep` would let the register
-// allocator split it). The byte itself is never used. The destination register must not be touched while the load is in flight and the compiler does not
-// know there is a load (inline asm: a load it tracked would put the coefficient stores and the staging loads behind waits for THIS data): `keep` is
-// one register, read-write in every issue and kept alive to the kernel's last instruction; the Makefile's scan of the generated code (tools/check_k1_isa.py)
-// fails the build if any other instruction names it. vmcnt is in-order, so the compiler's own waits - counted for its own loads, all younger or older
-// than this one in program order - stay correct: they can only wait longer, never too short.
-__device__ __forceinline__ void pf_issue(const FwdArgs &a, const uint8_t *img, uint32_t img_bytes, uint32_t row_bytes, int tid, int32_t first, int32_t count, uint32_t &keep) {
-    const uint32_t i = (uint32_t)first + ((uint32_t)tid < (uint32_t)count ? (uint32_t)tid : 0u);
-    const uint32_t y = __umulhi(i, a.pf_magic);
-    const uint32_t col = i - y * a.pf_lpr;
-    const uint32_t off = min(((y * row_bytes) & ~127u) + col * 128u, img_bytes - 1u);
-    asm volatile("global_load_ubyte %0, %1, %2" : "+v"(keep) : "v"(off), "s"(img));
-}
-
 // K1. grid = (workgroup shares, images), block = 256 (4 waves). Each workgroup walks the tiles of its share:
 // while tile i is being transformed out of one LDS buffer (and its coefficient stores drain), the pixel
 // rectangle of tile i+1 is already in flight from HBM/L2 into registers and is committed to the other buffer.
@@ -425,11 +409,6 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
 
     u32x4 st[NCH + 1]; // one tile's worth of in-flight 16-byte chunks of this thread (+ its cell record)
     Tile t = a.tiles[tb];
-    const bool pf_on = a.pf_lpr != 0; // (uniform)
-    const uint32_t img_bytes = (uint32_t)a.width * (uint32_t)a.height * C;
-    uint32_t pf_keep;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(pf_keep)); // (opaque: a register the compiler knows to hold 0 it would also lend out as a zero offset)
-    if (pf_on) pf_issue(a, img, img_bytes, wc, tid, t.pf_line, t.pf_count, pf_keep); // the rows this XCD stages in round 1, ahead of tile 0's own loads
     stage_issue<C, EDGE, FAST, NCH>(a, t, img, tid, cm, st);
     stage_commit<NCH>(a, t, lds, junk, tid, st);
     __syncthreads();
@@ -450,7 +429,6 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
             tn.cell_begin = __builtin_amdgcn_readfirstlane(l.cell_begin);
             tn.cell_count = __builtin_amdgcn_readfirstlane(l.cell_count);
             stage_issue<C, EDGE, FAST, NCH>(a, tn, img, tid, cm, st); // loads stay in flight across the transform below
-            if (pf_on) pf_issue(a, img, img_bytes, wc, tid, __builtin_amdgcn_readfirstlane(l.pf_line), __builtin_amdgcn_readfirstlane(l.pf_count), pf_keep);
         }
 
         // Issue priority falls with a wave's progress through the tile (3 -> 2 -> 1, 0 for the stores), so that at every conflict the wave that is furthest
@@ -557,7 +535,6 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
         (void)__hip_atomic_fetch_add(a.xcd_stat + 2 * xcc, wall_clock64() - t_entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         (void)__hip_atomic_fetch_add(a.xcd_stat + 2 * xcc + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("; pf_keep %0" ::"v"(pf_keep)); // the prefetch register stays allocated to the end (see pf_issue)
 }
 
 
@@ -606,9 +583,6 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
     a.buf_bytes = (int32_t)fwd_buf_bytes(p);
     a.cpr = (uint32_t)p.lds_pitch / 16u;
     a.cpr_magic = (uint32_t)(((1ull << 32) + a.cpr - 1) / a.cpr);
-    // row-run prefetch: one-round launches on the plan's own (unmerged) interleaved shares; images below 4 GiB (32-bit offsets, like the staging)
-    a.pf_lpr = !batch && p.pf_lines_per_row > 1 ? (uint32_t)p.pf_lines_per_row : 0u;
-    a.pf_magic = a.pf_lpr ? (uint32_t)(((1ull << 32) + a.pf_lpr - 1) / a.pf_lpr) : 0u;
     a.q = q;
     a.q_identity = 1;
     for (int i = 0; i <= 9; i++) a.q_identity &= (q.q[i] == 1); // layers 0..9 are the only ones a 512-node cell uses

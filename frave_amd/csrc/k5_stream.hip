@@ -67,7 +67,10 @@ struct GatherArgs {
 };
 constexpr int kGatherThreads = 256;
 
-constexpr int kGatherChunks = 2; // 512-symbol chunks per wave: all their order loads, then all their gathers, are in flight together
+#ifndef FRI_K5_CHUNKS
+#define FRI_K5_CHUNKS 2
+#endif
+constexpr int kGatherChunks = FRI_K5_CHUNKS; // 512-symbol chunks per wave: all their order loads, then all their gathers, are in flight together
 __global__ void __launch_bounds__(kGatherThreads) symbol_gather_kernel(const GatherArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t s_t[kGatherThreads * 8 * kGatherChunks];
     const uint32_t plane = blockIdx.y;

@@ -45,7 +45,6 @@ struct DevicePlan {
     uint32_t F = 0;
     int32_t width = 0, height = 0, channels = 0;
     int32_t lds_pitch = 0, lds_rows = 0, cells_per_tile = 0;
-    int32_t pf_lines_per_row = 0; // forward kernel's row-run prefetch (Tile::pf_line): 128-byte steps per pixel row; 0 = the tiles carry no schedule
     bool k1_batch_shares = true; // FRI_HIP_K1_BATCH_SHARES=0 disables the merged shares (A/B)
     int k1_cached_stores = -1; // tuning (FRI_HIP_K1_CACHED_STORES=0 / 1): force nontemporal / plain coefficient stores; -1: the caller of the launch decides
     int32_t k1_ablate = 0; // timing-only ablation flags, see FwdArgs::ablate

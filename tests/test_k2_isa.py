@@ -58,31 +58,3 @@ def test_the_scan_refuses_control_flow_under_a_gather_in_flight(tmp_path):
     _, errors = tool.scan(str(bad))
     assert errors and "control flow" in errors[0]
 
-
-# ---- K1's row-run prefetch (k1_forward.hip, pf_issue): the same kind of untracked inline-asm load, the same kind of gate -------------------------------
-def _tool1():
-    spec = importlib.util.spec_from_file_location("check_k1_isa", os.path.join(ROOT, "tools", "check_k1_isa.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod
-
-
-def test_k1_prefetch_register_is_touched_by_nothing_else():
-    tool = _tool1()
-    kernels, loads, problems = tool.scan(tool.make_assembly())
-    assert kernels >= 8 and loads >= 2 * kernels, (kernels, loads)
-    assert problems == [], "\n".join(problems[:10])
-
-
-def test_k1_scan_finds_a_planted_hazard(tmp_path):
-    import re
-
-    tool = _tool1()
-    lines = open(tool.make_assembly()).read().splitlines()
-    i = next(k for k, l in enumerate(lines) if re.match(r"\s*global_load_ubyte v\d+, v\d+, s\[", l) and any("fwd_transform_quant_kernel" in p for p in lines[max(0, k - 400):k]))
-    reg = lines[i].split()[1].rstrip(",")
-    lines.insert(i + 3, f"\tv_add_u32_e32 {reg}, v0, v0")
-    bad = tmp_path / "planted.s"
-    bad.write_text("\n".join(lines))
-    _, _, problems = tool.scan(str(bad))
-    assert problems
