@@ -415,7 +415,6 @@ std::string tiling_label(const TilingParams &tp, const Geometry &g) {
     std::snprintf(b, sizeof b, "%s/band%d/cells%d", tp.strided_shares ? "interleaved" : "contiguous", g.band_rows, g.cells_per_tile);
     std::string l = b;
     if (!tp.strided_shares && tp.xcd_group_tiles > 0) l += "/xcd-groups" + std::to_string(tp.xcd_group_tiles);
-    if (tp.tail_wgs > 0 && tp.tail_percent > 0) l += "/tail" + std::to_string(tp.tail_wgs) + "x" + std::to_string(tp.tail_percent) + "%";
     if (tp.rank_weight[0] > 0) {
         std::snprintf(b, sizeof b, "/w%.2f-%.2f", tp.rank_weight[0], tp.rank_weight[std::max(0, std::min(tp.ranks, 4) - 1)]);
         l += b;
@@ -513,7 +512,6 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
     tp.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
     tp.cells_per_wg = env_int("FRI_HIP_CELLS_PER_WG");
     tp.batch_share_tiles = env_int("FRI_HIP_BATCH_SHARE_TILES");
-    tp.tail_wgs = env_int("FRI_HIP_TAIL_WGS"), tp.tail_percent = env_int("FRI_HIP_TAIL_PERCENT");
     tp.xcd_group_tiles = env_int("FRI_HIP_XCD_GROUP_TILES");
     // Interleaved shares (geometry.cpp): the resident workgroups work on one window sliding over the image. Default since round 4 (4096^2 from HBM: planes
     // 20.3 -> 19.1 us, RGB 55.5 -> 51.9 us, the inverse 29.6 -> 27.8 / 86 -> 72 us); FRI_HIP_STRIDED_SHARES=0 (tuning) restores one contiguous run per share.
@@ -610,7 +608,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         ti.band_rows = env_int("FRI_HIP_INV_BAND_ROWS") > 0 ? env_int("FRI_HIP_INV_BAND_ROWS") : (channels == 1 ? 32 : 16);
         ti.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
         ti.cells_per_wg = 0;
-        ti.tail_wgs = ti.tail_percent = ti.xcd_group_tiles = 0;
+        ti.xcd_group_tiles = 0;
         ti.target_wgs = ctx_wgs(ctx, tp.ranks);
         ti.strided_shares = env_str("FRI_HIP_INV_STRIDED_SHARES") ? env_int("FRI_HIP_INV_STRIDED_SHARES") > 0 : (strided_env ? tp.strided_shares : true); // interleaved at every size it is built for
         bool ok = false;
@@ -622,7 +620,9 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
             probe.lds_rows = p->geo_inv.lds_rows;
             probe.max_tile_cells = p->geo_inv.max_tile_cells;
             probe.max_wg_tiles = std::max(p->geo_inv.max_wg_tiles, p->geo_inv.max_wg_tiles_batch);
-            if (fwd_plan_fits(probe)) {
+            probe.inv_max_wg_tiles = p->geo_inv.max_wg_tiles, probe.inv_max_wg_cells = p->geo_inv.max_wg_cells;
+            // the inverse kernel's OWN limits (the forward kernel's budget said nothing about them); the lists' rectangle is checked once they are built
+            if (fwd_plan_fits(probe) && inv_plan_fits(probe, false)) { // (the forward budget too, as through round 4: it keeps the tiles at the size the kernel was tuned for)
                 ok = true;
                 break;
             }
@@ -638,6 +638,17 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         if (!ok) p->geo_inv = Geometry{};
     }
     build_inverse_lists(p->own_inverse_tiling ? p->geo_inv : p->geo, (size_t)256 << 20); // 6 MB at 4096^2; beyond 256 MB the inverse kernel scans the rectangle instead
+    if (p->own_inverse_tiling) { // with the lists built their LDS rectangle is known: a tiling whose lists kernel would not fit falls back to the shared (forward) tiling
+        DevicePlan probe;
+        probe.channels = (int32_t)channels;
+        probe.lds_pitch = p->geo_inv.lds_pitch, probe.lds_rows = p->geo_inv.lds_rows, probe.max_tile_cells = p->geo_inv.max_tile_cells;
+        probe.inv_max_wg_tiles = p->geo_inv.max_wg_tiles, probe.inv_max_wg_cells = p->geo_inv.max_wg_cells, probe.inv_rect_bytes = p->geo_inv.inv_rect_bytes;
+        if (!p->geo_inv.inv_lists.empty() && !inv_plan_fits(probe, true)) {
+            p->own_inverse_tiling = false;
+            p->geo_inv = Geometry{};
+            build_inverse_lists(p->geo, (size_t)256 << 20);
+        }
+    }
     if (ctx) {
         if (hipSetDevice(ctx->device) != hipSuccess) {
             delete p;
@@ -704,6 +715,7 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         }
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
+        d.k1_stagger = env_int("FRI_HIP_K1_STAGGER");
         if (env_str("FRI_HIP_K1_CACHED_STORES")) d.k1_cached_stores = env_int("FRI_HIP_K1_CACHED_STORES") > 0 ? 1 : 0; // tuning: force plain (1) / nontemporal (0) coefficient stores everywhere
         d.k2_ablate = env_int("FRI_HIP_K2_ABLATE");
         if (const char *e = env_str("FRI_HIP_K1_BATCH_SHARES")) d.k1_batch_shares = std::atoi(e) != 0;
@@ -1854,12 +1866,6 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
             for (int grp : {16, 32, 64, 128}) {
                 TilingParams tp = w;
                 tp.xcd_group_tiles = grp;
-                also(tp);
-            }
-        for (int pct : {8, 15, 25})
-            for (int n : {256, 512}) {
-                TilingParams tp = w;
-                tp.tail_wgs = n, tp.tail_percent = pct;
                 also(tp);
             }
         if (w.ranks == 4 && w.rank_weight[0] > 0) {

@@ -417,11 +417,6 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
     // inverse of the kernels' XCD-contiguous block -> share map), whose dispatch rank is b / (target_wgs / ranks).
     const size_t T = g.tiles.size();
     if (tp.cells_per_wg <= 0) n_wg = (size_t)target_wgs; // one share per resident workgroup, or one per tile if there are fewer tiles
-    // Tail shares: tail_wgs extra, short shares behind the resident round, together tail_percent % of the tiles. The hardware hands them to whichever CU of their
-    // XCD frees a slot first: the CUs that got through their resident shares early take more of them - dynamic balance without an atomic.
-    const size_t tail_wgs = tp.cells_per_wg <= 0 && tp.tail_wgs > 0 && tp.tail_percent > 0 && tp.tail_percent < 60 && T >= 2 * ((size_t)target_wgs + (size_t)tp.tail_wgs)
-                                ? (size_t)tp.tail_wgs : 0;
-    n_wg += tail_wgs;
     n_wg = std::max<size_t>(1, std::min(n_wg, T));
     g.cells_per_wg = (int32_t)((F + n_wg - 1) / n_wg);
     {
@@ -430,18 +425,11 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         for (int i = 0; i < ranks; i++) weighted = weighted && tp.rank_weight[i] > 0;
         std::vector<double> cum(n_wg + 1, 0.0);
         const size_t q = n_wg >> 3, r = n_wg & 7, per_rank = std::max<size_t>(1, (size_t)target_wgs / ranks);
-        auto weight_of = [&](size_t b) { return weighted ? (double)tp.rank_weight[std::min<size_t>(b / per_rank, ranks - 1)] : 1.0; };
-        double w_tail = 0;
-        if (tail_wgs) { // blocks >= target_wgs are the tail: each weighs so that all of them together hold tail_percent % of the total
-            double main_sum = 0;
-            for (size_t b = 0; b < n_wg - tail_wgs; b++) main_sum += weight_of(b);
-            w_tail = main_sum * tp.tail_percent / (100.0 - tp.tail_percent) / (double)tail_wgs;
-        }
         for (size_t x = 0, sh = 0; x < 8; x++) {
             const size_t n_x = q + (x < r ? 1 : 0);
             for (size_t idx = 0; idx < n_x; idx++, sh++) {
                 const size_t b = idx * 8 + x;
-                cum[sh + 1] = cum[sh] + (tail_wgs && b >= n_wg - tail_wgs ? w_tail : weight_of(b));
+                cum[sh + 1] = cum[sh] + (weighted ? (double)tp.rank_weight[std::min<size_t>(b / per_rank, ranks - 1)] : 1.0);
             }
         }
         g.wg_tiles.assign(n_wg + 1, 0);

@@ -441,6 +441,16 @@ static size_t inv_queue_bytes(const DevicePlan &p) {
     return (((quads + kInvThreads - 1) / kInvThreads) * 64 * 2 + 15) & ~(size_t)15;
 }
 size_t inv_lds_bytes(const DevicePlan &p) { return inv_buf_bytes(p) + kInvWaves * inv_queue_bytes(p) + (size_t)p.inv_max_wg_tiles * sizeof(Tile) + (size_t)p.inv_max_wg_cells * sizeof(TileCell); }
+// Does a tiling fit the inverse kernels (what launch_inverse_transform would otherwise refuse with hipErrorInvalidConfiguration)? The static limits of both
+// kernels and the LDS of the scanning kernel (always available); with_lists: also the lists kernel's LDS (inv_rect_bytes is known once the lists are built).
+bool inv_plan_fits(const DevicePlan &p, bool with_lists) {
+    const int items_per_wave = (p.max_tile_cells * p.channels + kInvWaves - 1) / kInvWaves;
+    if (items_per_wave > kInvMaxItemsPerWave || p.inv_max_wg_tiles > kInvThreads || p.lds_rows > 256 || p.lds_pitch / 16 > 256) return false;
+    if (inv_lds_bytes(p) > 160 * 1024) return false;
+    if (with_lists && (size_t)p.inv_rect_bytes + (size_t)p.inv_max_wg_tiles * (sizeof(Tile) + sizeof(InvTileLists)) + (size_t)p.inv_max_wg_cells * sizeof(TileCell) > 160 * 1024) return false;
+    return true;
+}
+
 hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, const int32_t *coefs, size_t coef_stride, const QMatrix &q, uint8_t *pixels, size_t pixel_stride,
                                     hipStream_t stream) {
     if (!n_images || n_images > 65535u) return hipErrorInvalidValue;
@@ -476,9 +486,9 @@ hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, cons
     a.q_multiply = p.k3_multiply ? 1 : 0;
     a.queue_bytes = (int32_t)inv_queue_bytes(p);
     const int items_per_wave = (p.max_tile_cells * p.channels + kInvWaves - 1) / kInvWaves;
-    if (items_per_wave > kInvMaxItemsPerWave || p.inv_max_wg_tiles > kInvThreads || p.lds_rows > 256 || p.lds_pitch / 16 > 256) return hipErrorInvalidConfiguration;
-    // static write-out lists when every image row starts 16-byte aligned
-    const bool lists = p.inv_lists && !p.k3_scan && (reinterpret_cast<uintptr_t>(pixels) & 15) == 0 && (((size_t)p.width * p.channels) & 15) == 0 &&
+    if (!inv_plan_fits(p, false)) return hipErrorInvalidConfiguration;
+    // static write-out lists when every image row starts 16-byte aligned (and their rectangle fits: fri_hip_plan_create checks that for the tilings it builds)
+    const bool lists = p.inv_lists && !p.k3_scan && inv_plan_fits(p, true) && (reinterpret_cast<uintptr_t>(pixels) & 15) == 0 && (((size_t)p.width * p.channels) & 15) == 0 &&
                        (n_images == 1 || (pixel_stride & 15) == 0);
     if (lists) {
         a.lists = p.inv_lists;

@@ -322,11 +322,16 @@ __device__ __forceinline__ void fit2_wave_sums(int (&acc)[28], int group, int la
 // (>= 0, < 2^24: features <= 511, residuals of fitted parameters <= ~1024, sixteen of them) becomes a 64-bit fixed-point number with kFitFixBits fraction bits
 // by a function of the value alone (truncation below 2^-20: < 1e-6 per value), and integer adds commute. So the total does not depend on which workgroup walks which tile, on how many planes a launch
 // holds or on who finishes when: the same bits from every entry point and every run, hence the same f32 parameters, buckets and bytes. (Rounds 1-3 added
-// doubles in arrival order) A value of 2^24 or more - parameters from nowhere - saturates.
+// doubles in arrival order) A value of 2^24 or more - parameters from nowhere - is clamped to 2^24 and counted (below). 2^24 x 2^20 = 2^44 per partial sum:
+// the 64-bit total cannot wrap below 2^19 saturated partial sums, and a single one already makes the call report out-of-range.
 constexpr int kFitFixBits = 20; // a plane's total stays below 2^63 up to sums of 8.8e12 (a 16384^2 noise plane: ~1.6e12)
-__device__ __forceinline__ unsigned long long fit_f32_to_fixed(float v) {
+// `saturated` is raised for a value that does not fit (>= 2^24, infinite or NaN: value parameters from nowhere); it enters as 2^24 and the plane's out-of-range count
+// reports it (FRI_HIP_ERR_OUT_OF_RANGE from the host forms), so a wrapped or meaningless W^T r never leaves silently.
+__device__ __forceinline__ unsigned long long fit_f32_to_fixed(float v0, bool &saturated) {
+    saturated = saturated || !(v0 < 16777216.0f);
+    const float v = fminf(v0, 16777216.0f);                      // v_min_f32: NaN -> 2^24
     const float t = __builtin_truncf(v);                         // v >= 0
-    const uint32_t hi = f32_to_u32_sat(t);                       // saturating (v_cvt_u32_f32): NaN -> 0
+    const uint32_t hi = f32_to_u32_sat(t);                       // <= 2^24: a plane's 2 M partial sums stay below 2^45 before the fraction bits, 2^65 is never reached... see kFitFixBits
     const uint32_t lo = f32_to_u32_sat((v - t) * (float)(1u << kFitFixBits)); // exact difference, exact scaling, truncation below 2^-20 (only values < 16 have such bits)
     return ((unsigned long long)hi << kFitFixBits) + lo;
 }
@@ -461,6 +466,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
     for (int k = 0; k < 28; k++) acc[k] = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) fx[k] = 0ull;
+    bool fx_saturated = false; // a W^T r partial sum of this lane did not fit the fixed-point format (fit_f32_to_fixed)
     int tiles_since_flush = 0, trace_it = 0;
     const int block_a = fit2_block_slot(wave, 0), block_b = fit2_block_slot(wave, 1);
 
@@ -500,7 +506,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             fit2_halo_commit<MODE == 1>(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e1);                                                                     \
         }                                                                                                                                        \
         if (MODE == 1) {                                                                                                                         \
-            _Pragma("unroll") for (int k = 0; k < 6; k++) fx[k] += fit_f32_to_fixed(facc[k]);                                                    \
+            _Pragma("unroll") for (int k = 0; k < 6; k++) fx[k] += fit_f32_to_fixed(facc[k], fx_saturated);                                     \
         }                                                                                                                                        \
         if (++tiles_since_flush >= 16) { /* 16 nodes x 256^2 x 2 per tile and lane: a row of 16 lanes stays below 2^31 for 16 tiles */            \
             fit2_wave_sums<NI>(acc, group, lane, s_int);                                                                                         \
@@ -541,6 +547,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         unsigned long long *const mine = &s_fix[(lane & 15) * 3 + group][0];
 #pragma unroll
         for (int k = 0; k < 6; k++) atomicAdd(mine + k, fx[k]);
+        if (__any(fx_saturated) && lane == 0) atomicAdd(&s_range, 1u); // counted with the staging's out-of-range values: the sums are not to be trusted
     }
     __syncthreads();
     // hand-over: add into this workgroup's copy of the plane's accumulator, draw a ticket, the last workgroup sums the copies, moves the totals out
@@ -585,7 +592,7 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
             total += part[sh];
             __hip_atomic_store(accp + sh * kFitAccWords + kFitAccDbl + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const double sum = (double)(long long)total * (1.0 / (double)(1ull << kFitFixBits));
+        const double sum = (double)total * (1.0 / (double)(1ull << kFitFixBits)); // (unsigned: a sum of non-negative terms)
         a0.wtr[(size_t)plane * 18 + tid] = sum;
         (&s_dbl[0][0])[tid] = sum;
     }

@@ -428,6 +428,24 @@ Result<std::vector<std::vector<uint8_t>>> encode_batch_bytes(const std::vector<c
         r.error = "encode_batch_bytes: no device / no emitter thread";
         return r;
     }
+    // One producer thread per entry drives that Device's plan and staging buffers: a Device listed twice would put two threads on one plan (a plan is
+    // single-threaded, include/fri_hip.h), a null entry or a null image pointer would go straight into the C ABI. Refused up front.
+    for (uint32_t d = 0; d < n_dev; d++) {
+        if (!devices[d]) {
+            r.error = "encode_batch_bytes: null Device";
+            return r;
+        }
+        for (uint32_t e = 0; e < d; e++)
+            if (devices[e] == devices[d]) {
+                r.error = "encode_batch_bytes: the same Device is listed twice (one producer thread per entry: a plan is single-threaded)";
+                return r;
+            }
+    }
+    for (size_t i = 0; i < n_images; i++)
+        if (!images[i]) {
+            r.error = "encode_batch_bytes: null image pointer";
+            return r;
+        }
     r.value.assign(n_images, {});
     std::mutex mu;
     std::condition_variable have_work, have_room;
@@ -442,7 +460,7 @@ Result<std::vector<std::vector<uint8_t>>> encode_batch_bytes(const std::vector<c
         have_work.notify_all(), have_room.notify_all();
     };
     const auto t_begin = std::chrono::steady_clock::now();
-    uint64_t n_some = 0;
+    std::atomic<uint64_t> n_some{0}; // symbols per channel: a geometry fact, published by whichever producer has its plan first (every plan of the shape gives the same number)
     std::vector<std::thread> producers, emitters;
     for (uint32_t d = 0; d < n_dev; d++)
         producers.emplace_back([&, d]() {
@@ -452,10 +470,7 @@ Result<std::vector<std::vector<uint8_t>>> encode_batch_bytes(const std::vector<c
             if (!plan && err.empty()) err = dev.error();
             if (!err.empty()) fail(err);
             const uint64_t n = plan ? fri_hip_plan_num_some(plan) : 0;
-            if (d == 0) {
-                std::lock_guard<std::mutex> lk(mu);
-                n_some = n;
-            }
+            if (n) n_some.store(n, std::memory_order_relaxed);
             for (size_t k = 0; err.empty() && k < fri_hip_shard_size(n_images, d, n_dev); k++) {
                 const size_t i = fri_hip_shard_image(k, d, n_dev); // image i -> device i mod n_dev: the library's partition
                 StreamedImage im;
@@ -499,11 +514,7 @@ Result<std::vector<std::vector<uint8_t>>> encode_batch_bytes(const std::vector<c
                     have_room.notify_one();
                 }
                 const auto t0 = std::chrono::steady_clock::now();
-                uint64_t n;
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    n = n_some;
-                }
+                uint64_t n = n_some.load(std::memory_order_relaxed); // (set before the first image was queued: the queue's mutex orders it)
                 if (!n) n = im.symbols.size() / c;
                 const std::string e = emit_streamed(im, c, n, height, width, colorspace, r.value[im.index]);
                 emit_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();

@@ -203,7 +203,9 @@ int fri_hip_fit_value_sums_dev(fri_hip_plan *plan, const int32_t *d_coefs, uint3
  * beyond that is integer addition - far inside the reference's own fit, whose matrices and SVD are f32 throughout (context_modeling.rs:144-173), and
  * REPRODUCIBLE: integer adds commute, so the sums (hence the fitted parameters, the buckets and the encoder's bytes) are the same bits in every
  * run, from every entry point and for any number of planes per launch (through round 3 they were f64 atomics in arrival order). Valid while a
- * plane's sum stays below 8.8e12 (a 16384 x 16384 noise plane: ~1.6e12). rows[g] = height of the reference's matrix (F*256, F*128, F*128): its
+ * plane's sum stays below 8.8e12 (a 16384 x 16384 noise plane: ~1.6e12) and every partial sum below 2^24: a partial sum that is not (value parameters
+ * that are huge, infinite or NaN) is clamped and COUNTED with the out-of-range coefficients - the host forms return FRI_HIP_ERR_OUT_OF_RANGE, the
+ * device forms report the count - so a meaningless W^T r never leaves silently. rows[g] = height of the reference's matrix (F*256, F*128, F*128): its
  * all-zero rows still carry the constant feature 1 with residual 0, so add rows[g] - wtw[g][0] to entry (0,0). */
 int fri_hip_fit_width_sums(fri_hip_plan *plan, const int32_t *coefs, uint32_t channel, const float value_params[3][6], int64_t wtw[3][21],
                            double wtr[3][6], uint64_t rows[3]);

@@ -165,6 +165,26 @@ def test_fit_reports_coefficients_outside_its_range(ctx, oracle):
     assert np.array_equal(P.fit_value_sums(co, 0), good)  # and the accumulators were left clean
 
 
+def test_width_sums_report_value_parameters_from_nowhere(ctx):
+    """W^T r travels as 64-bit fixed point; a partial sum of 2^24 or more (value parameters that are huge, infinite or NaN) does not fit and used to
+    wrap or turn negative without a word. It is clamped and counted with the out-of-range values: the host form reports FRI_HIP_ERR_OUT_OF_RANGE, sane
+    parameters right afterwards give the sums they always gave."""
+    import frave_amd as fa
+
+    w, h, c = 320, 200, 1
+    P = fa.Plan(ctx, w, h, c)
+    co = P.transform_quant(gen_image("noise", w, h, c, 6))
+    good = P.fit_width_sums(co, 0, KAT_VALUE_PARAMS)
+    for bad_value in (1e30, float("inf"), float("nan"), -3e12):
+        vp = np.array(KAT_VALUE_PARAMS, np.float32).copy()
+        vp[:, 2] = bad_value
+        with pytest.raises(fa.FriHipError) as e:
+            P.fit_width_sums(co, 0, vp)
+        assert e.value.code == -7, bad_value
+    again = P.fit_width_sums(co, 0, KAT_VALUE_PARAMS)
+    assert all(np.array_equal(a, b) for a, b in zip(again, good))
+
+
 def test_device_solves_return_the_bits_of_the_host_solves(ctx):
     """The 6 x 6 solves of the asynchronous chain run on the device (fit_solve_kernel) from the source the host functions are built from
     (csrc/solve6.hpp): for the same sums the same parameters, bit for bit - on the LDL^T route (textured data), on the eigen-decomposition
