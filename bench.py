@@ -201,6 +201,7 @@ def extras(plan, ctx, torch, np, d_px, d_co, slots, alg_bytes, stream, full=Fals
     del d_words, d_sym
     # K1 on RGB, the colour space libfri really encodes (wavelet_transform.rs:191, 415-416)
     plan3 = frave_amd.Plan(ctx, W, H, 3)
+    tuned3 = plan3.tune_forward()  # like the headline's plan
     n3 = 12  # rotating slots: 604 MB of pixels (6 slots: 302 MB, part of which still came out of the 256 MiB Infinity Cache: 52.8 against 53.7 us)
     d_px3 = torch.randint(0, 256, (n3, plan3.pixel_bytes), dtype=torch.uint8, device="cuda")
     d_co3 = torch.empty((n3, plan3.coef_count), dtype=torch.int32, device="cuda")
@@ -208,6 +209,7 @@ def extras(plan, ctx, torch, np, d_px, d_co, slots, alg_bytes, stream, full=Fals
     rgb = lambda n: plan3.time_transform_quant_dev(n3, d_px3.data_ptr(), plan3.pixel_bytes, d_co3.data_ptr(), plan3.coef_count, n, stream=stream)
     rgb(5 * n3)  # this plan's first launches: tables and buffers are cold
     res["k1_rgb"] = entry(rgb(10 * n3), plan3.pixel_bytes + plan3.coef_count * 4)
+    res["k1_rgb"]["forward_tiling"] = tuned3.get("winner", "default")
     del d_px3, d_co3
     plan3.close()
     # K1 with many images per launch (the batch entry point; BASELINE config 4 runs like this), over the same slots: distinct images, every byte from and to HBM

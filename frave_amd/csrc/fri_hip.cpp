@@ -715,7 +715,6 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         }
         d.hist_blocks = 2u * (uint32_t)ctx->cu_count; // two resident 512-thread workgroups per CU (LDS: 2 x 78 KiB)
         d.k1_ablate = env_int("FRI_HIP_K1_ABLATE");
-        d.k1_stagger = env_int("FRI_HIP_K1_STAGGER");
         if (env_str("FRI_HIP_K1_CACHED_STORES")) d.k1_cached_stores = env_int("FRI_HIP_K1_CACHED_STORES") > 0 ? 1 : 0; // tuning: force plain (1) / nontemporal (0) coefficient stores everywhere
         d.k2_ablate = env_int("FRI_HIP_K2_ABLATE");
         if (const char *e = env_str("FRI_HIP_K1_BATCH_SHARES")) d.k1_batch_shares = std::atoi(e) != 0;

@@ -29,7 +29,6 @@ struct FwdArgs {
     int32_t buf_bytes; // bytes of one LDS buffer (pixel rows + cell records)
     uint32_t cpr, cpr_magic;
     int32_t q_identity;
-    int32_t stagger; // experiment: entry delay per dispatch rank, in s_sleep units of 64 clocks
     int32_t ablate; // timing-only ablation (FRI_HIP_K1_ABLATE): 1 = skip staging, 2 = skip the cell loop, 4 = skip stores, 8 = return at entry. 0 in production.
     unsigned long long *trace; // diagnostic timeline, null in production
     unsigned long long *xcd_stat; // fri_hip_plan_tune_forward only (null otherwise): [8][2] = per XCD {sum of workgroup lifetimes in 100 MHz ticks, workgroups}
@@ -385,10 +384,6 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
     const int tb = a.wg_tiles[wg], te = a.wg_tiles[wg + 1];
     trace_stamp(a.trace, wg, 0, tid);
     const unsigned long long t_entry = a.xcd_stat ? wall_clock64() : 0ull;
-    if (a.stagger > 0) { // (uniform) later dispatch ranks start later: the first tiles' load bursts and the compute / store phases of a CU's four workgroups fall out of step
-        const int rank = (int)(blockIdx.x / max(1u, gridDim.x / 4u));
-        for (int k = 0; k < rank * a.stagger; k += 8) __builtin_amdgcn_s_sleep(8);
-    }
     // The share's tile descriptors go to LDS once, before any store is issued: fetching them inside the loop would be a
     // vector load behind s_waitcnt vmcnt(0) per tile (scalar loads are off the table once the kernel has stored), and that
     // wait would also drain the previous tile's coefficient stores.
@@ -592,7 +587,6 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
     a.q_identity = 1;
     for (int i = 0; i <= 9; i++) a.q_identity &= (q.q[i] == 1); // layers 0..9 are the only ones a 512-node cell uses
     a.ablate = p.k1_ablate;
-    a.stagger = p.k1_stagger;
     a.trace = p.trace;
     a.xcd_stat = p.k1_xcd_stat;
     const size_t lds = fwd_lds_bytes(p);

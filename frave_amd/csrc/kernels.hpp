@@ -48,7 +48,6 @@ struct DevicePlan {
     bool k1_batch_shares = true; // FRI_HIP_K1_BATCH_SHARES=0 disables the merged shares (A/B)
     int k1_cached_stores = -1; // tuning (FRI_HIP_K1_CACHED_STORES=0 / 1): force nontemporal / plain coefficient stores; -1: the caller of the launch decides
     int32_t k1_ablate = 0; // timing-only ablation flags, see FwdArgs::ablate
-    int32_t k1_stagger = 0; // experiment (FRI_HIP_K1_STAGGER): workgroups of dispatch rank r sleep r x this many x 64 clocks at entry
     int32_t k2_ablate = 0; // the same for K2, see PredArgs::ablate
     bool k3_multiply = false; // fri_hip_plan_set_dequantiser: the inverse kernel multiplies by the quantiser instead of reproducing the reference's division
     unsigned long long *trace = nullptr; // [n_wg][16] diagnostic timeline (FRI_HIP_TRACE=1), else null

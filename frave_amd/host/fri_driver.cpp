@@ -317,6 +317,7 @@ int main(int argc, char **argv) {
         std::vector<libfri::Device *> devices;
         for (uint32_t d = 0; d < gpus; d++) {
             owned.emplace_back(new libfri::Device(same_device ? 0 : (int)d));
+            owned.back()->measure_forward_tiling(true); // a service's plans are made once: they measure their forward tiling (fri_hip_plan_tune_forward)
             devices.push_back(owned.back().get());
         }
         const uint32_t distinct = n < 4 ? n : 4;

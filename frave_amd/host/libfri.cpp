@@ -44,6 +44,7 @@ fri_hip_plan *Device::plan(uint32_t width, uint32_t height, uint32_t channels, s
         err = describe(rc);
         return nullptr;
     }
+    if (tune_) (void)fri_hip_plan_tune_forward(p, 0, nullptr, 0); // (a failed measurement leaves the default tiling: not an error of the encode)
     plans_[key] = p;
     return p;
 }

@@ -89,6 +89,9 @@ class Device {
     bool ok() const { return ctx_ != nullptr; }
     const std::string &error() const { return error_; }
     fri_hip_plan *plan(uint32_t width, uint32_t height, uint32_t channels, std::string &err);
+    // Plans of this device measure their forward tiling when they are made (fri_hip_plan_tune_forward: tens of milliseconds and ~1 GB of scratch memory per
+    // new shape, remembered per shape for the process) - what a batch driver wants; off by default, so that a one-image call costs what it did.
+    void measure_forward_tiling(bool on) { tune_ = on; }
     // the plan of that shape with the emitter's symbol order installed (fri_hip_plan_set_stream_order; geometry only: computed and uploaded once per plan)
     fri_hip_plan *stream_plan(uint32_t width, uint32_t height, uint32_t channels, std::string &err);
     std::string describe(int code) const;
@@ -96,6 +99,7 @@ class Device {
   private:
     fri_hip_ctx *ctx_ = nullptr;
     std::string error_;
+    bool tune_ = false;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, fri_hip_plan *> plans_;
     std::vector<fri_hip_plan *> ordered_; // plans whose stream order is installed
 };

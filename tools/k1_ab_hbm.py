@@ -17,7 +17,9 @@ for r in range(rounds):
         path, _, extra = lib.partition(":")
         if path != "-":
             env["FRI_HIP_LIBRARY"] = os.path.abspath(path)
-        for kv in filter(None, extra.split(",")):
+        import re
+
+        for kv in filter(None, re.split(r",(?=[A-Z][A-Z0-9_]*=)", extra)):  # (a value may hold commas: FRI_HIP_RANK_WEIGHTS=1.4,1.15,0.85,0.6)
             k, v = kv.split("=", 1)
             env[k] = v
             if k.startswith("FRI_HIP_"):

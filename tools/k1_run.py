@@ -17,6 +17,24 @@ slots = int(os.environ.get("K1_SLOTS", "8" if SIZE <= 4096 else "1"))
 d_px = torch.randint(0, 256, (slots, plan.pixel_bytes), dtype=torch.uint8, device="cuda")
 d_co = torch.empty((slots, plan.coef_count), dtype=torch.int32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
+if os.environ.get("K1_TUNE") == "1":  # the plan measures its forward tiling like bench.py does (without it: fri_hip_plan_create's default, or what the FRI_HIP_* knobs pin)
+    print("tune:", plan.tune_forward())
+nb = int(os.environ.get("K1_BATCH", "0"))
+if nb > 1:  # the batch form: nb distinct images per launch (grid.y = nb), n launches
+    nb = min(nb, slots)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    go = lambda: plan.transform_quant_dev(d_px.data_ptr(), d_co.data_ptr(), stream=s, n_images=nb, pixel_stride=plan.pixel_bytes, coef_stride=plan.coef_count)
+    for _ in range(3):
+        go()
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(n):
+        go()
+    ev1.record()
+    torch.cuda.synchronize()
+    us = ev0.elapsed_time(ev1) * 1e3 / n
+    print(f"K1 batch {SIZE}x{SIZE}x{C}: {us:.2f} us/launch = {us / nb:.2f} us/image over {n} launches of {nb} distinct images, {plan.tiling()['n_wg']} shares")
+    sys.exit(0)
 spin = int(os.environ.get("K1_SPIN_UP", "3000"))  # untimed: a fresh GPU needs tens of ms of work to reach steady clocks (bench.py does the same)
 if spin:
     plan.time_transform_quant_dev(slots, d_px.data_ptr(), plan.pixel_bytes, d_co.data_ptr(), plan.coef_count, spin, stream=s)

@@ -8,4 +8,3 @@ C72=FRI_HIP_STRIDED_SHARES=0,FRI_HIP_BAND_ROWS=72
 AB_BATCH=24 python3 tools/k1_ab_hbm.py 3 -:$C72 -:$C72,FRI_HIP_K1_STAGGER=8 -:$C72,FRI_HIP_K1_STAGGER=16 -:$C72,FRI_HIP_K1_STAGGER=32 -:$C72,FRI_HIP_K1_STAGGER=16,FRI_HIP_RANK_WEIGHTS=1.4,1.15,0.85,0.6 \
    - -:FRI_HIP_K1_STAGGER=8 -:FRI_HIP_K1_STAGGER=16 -:FRI_HIP_K1_STAGGER=32 > $OUT/ab_stagger.log 2>&1
 cat $OUT/ab_stagger.log
-bash tools/r5_k2_pmc.sh $1/pmc
