@@ -433,7 +433,20 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
             }
         }
         g.wg_tiles.assign(n_wg + 1, 0);
-        for (size_t sh = 0; sh <= n_wg; sh++) g.wg_tiles[sh] = (int32_t)((double)T * cum[sh] / cum[n_wg] + 0.5);
+        // What a tile costs: 1, plus rim_cost_percent / 100 for the share of its cells that lie on the image's rim (a boundary cell takes the masked path: leaf
+        // masks, the validity tree, None selects - about twice the vector instructions of an interior cell). With contiguous shares the first and the last
+        // shares of the image ARE the rim (every cell of the top and bottom rows of tiles), and the launch ended with them: shares are cut by cost, not by count.
+        std::vector<double> cost_cum(T + 1, 0.0);
+        for (size_t t = 0; t < T; t++) {
+            int rim = 0;
+            for (int32_t k = 0; k < g.tiles[t].cell_count; k++) rim += g.tile_meta[(size_t)g.tiles[t].cell_begin + k].interior ? 0 : 1;
+            cost_cum[t + 1] = cost_cum[t] + 1.0 + (tp.strided_shares ? 0.0 : tp.rim_cost_percent * 0.01 * rim / std::max(1, g.tiles[t].cell_count));
+        }
+        for (size_t sh = 0, t = 0; sh <= n_wg; sh++) {
+            const double want = cost_cum[T] * cum[sh] / cum[n_wg];
+            while (t < T && cost_cum[t + 1] - want <= want - cost_cum[t]) t++; // the boundary whose cumulative cost is nearest
+            g.wg_tiles[sh] = (int32_t)t;
+        }
         g.wg_tiles[0] = 0;
         g.wg_tiles[n_wg] = (int32_t)T;
         for (size_t sh = 1; sh <= n_wg; sh++) // every share keeps at least one tile (n_wg <= T)
