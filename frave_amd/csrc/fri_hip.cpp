@@ -414,8 +414,6 @@ std::string tiling_label(const TilingParams &tp, const Geometry &g) {
     char b[96];
     std::snprintf(b, sizeof b, "%s/band%d/cells%d", tp.strided_shares ? "interleaved" : "contiguous", g.band_rows, g.cells_per_tile);
     std::string l = b;
-    if (!tp.strided_shares && tp.xcd_group_tiles > 0) l += "/xcd-groups" + std::to_string(tp.xcd_group_tiles);
-    if (!tp.strided_shares && tp.rim_cost_percent > 0) l += "/rim+" + std::to_string(tp.rim_cost_percent) + "%";
     if (tp.rank_weight[0] > 0) {
         std::snprintf(b, sizeof b, "/w%.2f-%.2f", tp.rank_weight[0], tp.rank_weight[std::max(0, std::min(tp.ranks, 4) - 1)]);
         l += b;
@@ -513,8 +511,6 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
     tp.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
     tp.cells_per_wg = env_int("FRI_HIP_CELLS_PER_WG");
     tp.batch_share_tiles = env_int("FRI_HIP_BATCH_SHARE_TILES");
-    tp.xcd_group_tiles = env_int("FRI_HIP_XCD_GROUP_TILES");
-    tp.rim_cost_percent = env_int("FRI_HIP_RIM_COST");
     // Interleaved shares (geometry.cpp): the resident workgroups work on one window sliding over the image. Default since round 4 (4096^2 from HBM: planes
     // 20.3 -> 19.1 us, RGB 55.5 -> 51.9 us, the inverse 29.6 -> 27.8 / 86 -> 72 us); FRI_HIP_STRIDED_SHARES=0 (tuning) restores one contiguous run per share.
     // Up to ~200 000 cells, that is: at 12000^2 and 16384^2 (282 K / 526 K cells, many short shares dispatched in order: the resident set slides already) the
@@ -610,7 +606,6 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         ti.band_rows = env_int("FRI_HIP_INV_BAND_ROWS") > 0 ? env_int("FRI_HIP_INV_BAND_ROWS") : (channels == 1 ? 32 : 16);
         ti.cells_per_tile = env_int("FRI_HIP_CELLS_PER_TILE");
         ti.cells_per_wg = 0;
-        ti.xcd_group_tiles = ti.rim_cost_percent = 0;
         ti.target_wgs = ctx_wgs(ctx, tp.ranks);
         ti.strided_shares = env_str("FRI_HIP_INV_STRIDED_SHARES") ? env_int("FRI_HIP_INV_STRIDED_SHARES") > 0 : (strided_env ? tp.strided_shares : true); // interleaved at every size it is built for
         bool ok = false;
@@ -1752,12 +1747,11 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
             if (o->label == t->label) return; // the builder clamped it to something already there
         cand.push_back(std::move(t));
     };
-    auto add = [&](int strided, int band, int cells_delta, int xcd_groups = 0) {
+    auto add = [&](int strided, int band, int cells_delta) {
         TilingParams tp = p->fwd_tp;
         if (strided >= 0) tp.strided_shares = strided != 0;
         if (band > 0) tp.band_rows = band;
         if (cells_delta) tp.cells_per_tile = g0.cells_per_tile + cells_delta;
-        tp.xcd_group_tiles = xcd_groups;
         add_tp(tp);
     };
     add(-1, 0, 0);
@@ -1766,7 +1760,7 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
         return finish(FRI_HIP_OK);
     }
     if (!rgb) {
-        add(0, 72, 0), add(0, 72, 0, 32), add(1, 16, 1), add(1, 32, 0), add(1, 8, 0), add(0, 8, 0), add(1, 24, 0), add(0, 48, 0), add(0, 16, 0, 32);
+        add(0, 72, 0), add(1, 16, 1), add(1, 32, 0), add(1, 8, 0), add(0, 8, 0), add(1, 24, 0), add(0, 48, 0), add(0, 96, 0);
     } else {
         add(1, 12, 0), add(1, 24, 0), add(0, 16, 0), add(1, 8, 0), add(0, 32, 0);
     }
@@ -1863,12 +1857,6 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
             tp.cells_per_tile = gw.cells_per_tile + d;
             if (tp.cells_per_tile >= 2) also(tp);
         }
-        if (!w.strided_shares)
-            for (int rim : {50, 100, 150}) {
-                TilingParams tp = w;
-                tp.rim_cost_percent = rim;
-                also(tp);
-            }
         if (w.ranks == 4 && w.rank_weight[0] > 0) {
             static const float flat[4] = {1.2f, 1.05f, 0.95f, 0.8f}, steep[4] = {1.4f, 1.15f, 0.85f, 0.6f};
             for (const float *v : {flat, steep}) {

@@ -433,20 +433,7 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
             }
         }
         g.wg_tiles.assign(n_wg + 1, 0);
-        // What a tile costs: 1, plus rim_cost_percent / 100 for the share of its cells that lie on the image's rim (a boundary cell takes the masked path: leaf
-        // masks, the validity tree, None selects - about twice the vector instructions of an interior cell). With contiguous shares the first and the last
-        // shares of the image ARE the rim (every cell of the top and bottom rows of tiles), and the launch ended with them: shares are cut by cost, not by count.
-        std::vector<double> cost_cum(T + 1, 0.0);
-        for (size_t t = 0; t < T; t++) {
-            int rim = 0;
-            for (int32_t k = 0; k < g.tiles[t].cell_count; k++) rim += g.tile_meta[(size_t)g.tiles[t].cell_begin + k].interior ? 0 : 1;
-            cost_cum[t + 1] = cost_cum[t] + 1.0 + (tp.strided_shares ? 0.0 : tp.rim_cost_percent * 0.01 * rim / std::max(1, g.tiles[t].cell_count));
-        }
-        for (size_t sh = 0, t = 0; sh <= n_wg; sh++) {
-            const double want = cost_cum[T] * cum[sh] / cum[n_wg];
-            while (t < T && cost_cum[t + 1] - want <= want - cost_cum[t]) t++; // the boundary whose cumulative cost is nearest
-            g.wg_tiles[sh] = (int32_t)t;
-        }
+        for (size_t sh = 0; sh <= n_wg; sh++) g.wg_tiles[sh] = (int32_t)((double)T * cum[sh] / cum[n_wg] + 0.5);
         g.wg_tiles[0] = 0;
         g.wg_tiles[n_wg] = (int32_t)T;
         for (size_t sh = 1; sh <= n_wg; sh++) // every share keeps at least one tile (n_wg <= T)
@@ -457,8 +444,7 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
             g.max_wg_tiles = std::max(g.max_wg_tiles, g.wg_tiles[sh + 1] - g.wg_tiles[sh]);
         }
     }
-    const bool xcd_groups = !tp.strided_shares && tp.xcd_group_tiles > 0 && n_wg >= 8;
-    if ((tp.strided_shares || xcd_groups) && n_wg > 1) {
+    if (tp.strided_shares && n_wg > 1) {
         // Interleaved shares: the tiles are dealt to the shares like cards, round after round in share order, instead of giving every share one contiguous
         // run. At any moment of a one-round launch the resident workgroups then work on ONE window of consecutive tiles that slides over the image - the
         // pixel rows they read and the coefficient range they write are a compact, moving region of memory, not n_wg fronts spread over all of it - and
@@ -466,21 +452,6 @@ std::string build_geometry(uint32_t width, uint32_t height, uint32_t channels, c
         // contiguous in the arrays (the kernels walk [wg_tiles[sh], wg_tiles[sh + 1]) and load a share's cell records as one range): the arrays are permuted.
         std::vector<std::vector<int32_t>> dealt(n_wg);
         size_t next = 0;
-        if (xcd_groups) {
-            // Contiguous shares, but the XCDs take turns over the image: the band-major tile sequence is cut into groups of xcd_group_tiles tiles and XCD x (the
-            // shares [x n/8, (x + 1) n/8): xcd_contiguous_share) walks groups x, x + 8, x + 16, ... - with one contiguous eighth of the image per XCD the eight
-            // XCDs move through eight regions 8.5 MB apart in lockstep, and which of them the memory system serves slowest decides when the launch ends
-            // (per-XCD workgroup lifetimes 11.4 ... 16.1 us in one launch). A share is still a run of neighbouring tiles of one band.
-            std::vector<int32_t> perm;
-            perm.reserve(T);
-            const size_t gsz = (size_t)tp.xcd_group_tiles, n_groups = (T + gsz - 1) / gsz;
-            for (size_t x = 0; x < 8; x++)
-                for (size_t grp = x; grp < n_groups; grp += 8)
-                    for (size_t t = grp * gsz; t < std::min(T, (grp + 1) * gsz); t++) perm.push_back((int32_t)t);
-            for (size_t sh = 0; sh < n_wg; sh++)
-                for (int32_t t = g.wg_tiles[sh]; t < g.wg_tiles[sh + 1]; t++) dealt[sh].push_back(perm[(size_t)t]);
-            next = T;
-        }
         for (bool any = true; any && next < T;) {
             any = false;
             for (size_t sh = 0; sh < n_wg && next < T; sh++)

@@ -119,8 +119,6 @@ struct TilingParams {
     // instead of sizing every buffer for them. 0 = no cap.
     int tile_buffer_bytes = 0;
     int batch_share_tiles = 0; // tiles' worth of cells per merged batch share (0 = 4)
-    int rim_cost_percent = 0; // contiguous shares: extra cost of a tile made of boundary cells, in percent of an interior tile's (geometry.cpp: shares are cut by cost)
-    int xcd_group_tiles = 0; // contiguous shares only: > 0 = the XCDs take turns over groups of this many consecutive tiles (geometry.cpp) instead of one contiguous eighth of the image each
     bool strided_shares = false; // deal the tiles to the shares round-robin (the resident set works on one sliding window of the image) instead of one contiguous run each
 };
 

@@ -63,11 +63,11 @@ def test_every_candidate_tiling_gives_the_same_coefficients(ctx, oracle):
     w, h, c = 1280, 720, 1
     img = gen_image("noise", w, h, c, 5)
     want = oracle.Wavelet(img, h, w, c).coefficients()
-    keys = ("FRI_HIP_TUNING", "FRI_HIP_STRIDED_SHARES", "FRI_HIP_BAND_ROWS", "FRI_HIP_CELLS_PER_TILE", "FRI_HIP_XCD_GROUP_TILES", "FRI_HIP_RANK_WEIGHTS")
+    keys = ("FRI_HIP_TUNING", "FRI_HIP_STRIDED_SHARES", "FRI_HIP_BAND_ROWS", "FRI_HIP_CELLS_PER_TILE", "FRI_HIP_RANK_WEIGHTS")
     saved = {k: os.environ.get(k) for k in keys}
     try:
         os.environ["FRI_HIP_TUNING"] = "1"
-        for spec in ({"FRI_HIP_STRIDED_SHARES": "0", "FRI_HIP_BAND_ROWS": "72"}, {"FRI_HIP_STRIDED_SHARES": "0", "FRI_HIP_BAND_ROWS": "80", "FRI_HIP_XCD_GROUP_TILES": "32"},
+        for spec in ({"FRI_HIP_STRIDED_SHARES": "0", "FRI_HIP_BAND_ROWS": "72"}, {"FRI_HIP_STRIDED_SHARES": "0", "FRI_HIP_BAND_ROWS": "80"},
                      {"FRI_HIP_STRIDED_SHARES": "1", "FRI_HIP_BAND_ROWS": "16", "FRI_HIP_CELLS_PER_TILE": "9"}, {"FRI_HIP_STRIDED_SHARES": "0", "FRI_HIP_BAND_ROWS": "8"},
                      {"FRI_HIP_STRIDED_SHARES": "1", "FRI_HIP_BAND_ROWS": "24", "FRI_HIP_RANK_WEIGHTS": "1.4,1.15,0.85,0.6"}):
             for k in keys[1:]:

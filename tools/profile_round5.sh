@@ -26,8 +26,6 @@ m = re.match(r"(interleaved|contiguous)/band(\d+)/cells(\d+)", w)
 e = []
 if m:
     e = [f"FRI_HIP_STRIDED_SHARES={1 if m.group(1) == 'interleaved' else 0}", f"FRI_HIP_BAND_ROWS={m.group(2)}", f"FRI_HIP_CELLS_PER_TILE={m.group(3)}"]
-    g = re.search(r"xcd-groups(\d+)", w)
-    if g: e.append(f"FRI_HIP_XCD_GROUP_TILES={g.group(1)}")
     r = re.search(r"/w([\d.]+)-([\d.]+)", w)
     if r and (r.group(1), r.group(2)) == ("1.40", "0.60"): e.append("FRI_HIP_RANK_WEIGHTS=1.4,1.15,0.85,0.6")
     if r and (r.group(1), r.group(2)) == ("1.20", "0.80"): e.append("FRI_HIP_RANK_WEIGHTS=1.2,1.05,0.95,0.8")
