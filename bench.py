@@ -271,6 +271,11 @@ def main():
 
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        # (RCCL prints a version banner on file descriptor 1 when the communicator is built - here and at the first barriers below; the contract is ONE JSON line
+        # on stdout, so stdout points at stderr until the communicator exists)
+        sys.stdout.flush()
+        _saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = frave_amd.Context(local_rank)  # raises if the HIP library or a gfx950 GPU is missing: no fallback
@@ -315,6 +320,9 @@ def main():
         for _ in range(3):
             dist.barrier()
         torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(_saved_stdout, 1)  # the communicator exists: stdout is stdout again
+        os.close(_saved_stdout)
 
     timed = {}
 
@@ -362,7 +370,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": measured_traffic(),
-            "kernel": "fwd_transform_quant_kernel<1,false,true,4,true,true>",
+            "kernel": "fwd_transform_quant_kernel<1,false,true,4,true,true,false>",
             "kernel_us": round(kernel_us, 3),
             "algorithmic_bytes_per_launch": alg_bytes,
         },

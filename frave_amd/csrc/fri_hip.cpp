@@ -386,6 +386,7 @@ bool build_forward_candidate(const fri_hip_plan *p, FwdTiling &c) {
 
 hipError_t upload_forward_candidate(const fri_hip_plan *p, FwdTiling &c) {
     c.dev = p->dev;
+    c.dev.k1_measuring = true; // (adopt_forward_tiling copies the tables into the plan's own DevicePlan, not this flag)
     hipError_t e;
     if ((e = upload_raw(c.geo.tiles, c.dev.tiles, c.bufs)) || (e = upload_raw(c.geo.tile_cells, c.dev.tile_cells, c.bufs)) || (e = upload_raw(c.geo.tile_meta, c.dev.tile_meta, c.bufs)) ||
         (e = upload_raw(c.geo.wg_tiles, c.dev.wg_tiles, c.bufs)) || (e = upload_raw(c.geo.wg_tiles_batch, c.dev.wg_tiles_batch, c.bufs)))

@@ -372,7 +372,9 @@ __device__ __forceinline__ ItemAddr item_addr(const FwdArgs &a, const Tile &t, c
 // K1. grid = (workgroup shares, images), block = 256 (4 waves). Each workgroup walks the tiles of its share:
 // while tile i is being transformed out of one LDS buffer (and its coefficient stores drain), the pixel
 // rectangle of tile i+1 is already in flight from HBM/L2 into registers and is committed to the other buffer.
-template <int C, bool EDGE, bool FAST, int NCH, bool QID, bool NT>
+// MEASURE: the same kernel under another name - the launches fri_hip_plan_tune_forward times on its scratch buffers (candidate tilings, most of them slower than
+// the one kept) must not sit in the same row of a kernel trace's statistics as the caller's launches.
+template <int C, bool EDGE, bool FAST, int NCH, bool QID, bool NT, bool MEASURE = false>
 __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if (ablate_flags(a.ablate) & 8) return; // timing only: what dispatching the grid alone costs
@@ -602,6 +604,12 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
 #define FRI_PICK_N(CH, E, FA) (small ? FRI_PICK_Q(CH, E, FA, 4) : FRI_PICK_Q(CH, E, FA, kMaxChunksPerThread))
 #define FRI_PICK(CH) (edge ? FRI_PICK_N(CH, true, false) : fast ? FRI_PICK_N(CH, false, true) : FRI_PICK_N(CH, false, false))
     kern = p.channels == 1 ? FRI_PICK(1) : FRI_PICK(3);
+    if (p.k1_measuring && !edge && !plain && a.q_identity) { // the tuner's launches (aligned scratch, all-ones matrix, nontemporal stores): the MEASURE instance
+#define FRI_PICK_M(CH) (fast ? (small ? fwd_transform_quant_kernel<CH, false, true, 4, true, true, true> : fwd_transform_quant_kernel<CH, false, true, kMaxChunksPerThread, true, true, true>) \
+                             : (small ? fwd_transform_quant_kernel<CH, false, false, 4, true, true, true> : fwd_transform_quant_kernel<CH, false, false, kMaxChunksPerThread, true, true, true>))
+        kern = p.channels == 1 ? FRI_PICK_M(1) : FRI_PICK_M(3);
+#undef FRI_PICK_M
+    }
 #undef FRI_PICK
 #undef FRI_PICK_N
 #undef FRI_PICK_Q

@@ -51,6 +51,7 @@ struct DevicePlan {
     int32_t k2_ablate = 0; // the same for K2, see PredArgs::ablate
     bool k3_multiply = false; // fri_hip_plan_set_dequantiser: the inverse kernel multiplies by the quantiser instead of reproducing the reference's division
     unsigned long long *trace = nullptr; // [n_wg][16] diagnostic timeline (FRI_HIP_TRACE=1), else null
+    bool k1_measuring = false; // fri_hip_plan_tune_forward's measuring copies: their forward launches run the kernel's MEASURE instance (a name of its own in traces)
     unsigned long long *k1_xcd_stat = nullptr; // [8][2] per-XCD workgroup lifetimes of the forward kernel: set by fri_hip_plan_tune_forward on its measuring copies only
     // K3's static write-out lists (null = not built: the kernel scans the rectangle)
     const InvTileLists *inv_lists = nullptr;
