@@ -66,19 +66,8 @@ pass rgb_fetch "k1_run.py 48" FETCH_SIZE GRBM_GUI_ACTIVE
 pass rgb_write "k1_run.py 48" WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 unset SWEEP_C K1_SLOTS
 cd $R
-python3 - <<PY
-import csv, glob
-out = open("$OUT/kernel_stats_round5.csv", "w")
-w = csv.writer(out)
-w.writerow(["run", "Name", "Calls", "AverageNs", "MinNs", "MaxNs", "StdDev"])
-for run in ("trace_bench", "trace_bench_extras", "trace_k1_batch", "trace_k1_c3", "trace_k1_16k", "trace_k2k3k4", "trace_k2k3k4_c3", "trace_k2k3k4_16k", "trace_chain"):
-    for f in glob.glob("$OUT/" + run + "/**/*kernel_stats.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "fri::" in r["Name"]:
-                w.writerow([run, r["Name"][:120], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-out.close()
-print(open("$OUT/kernel_stats_round5.csv").read())
-PY
+python3 tools/kernel_stats_from_traces.py $OUT > $OUT/kernel_stats_round5.csv
+cat $OUT/kernel_stats_round5.csv
 for needle in "predict_histogram_kernel3<true, false>" "predict_histogram_kernel3<false, false>" "predict_histogram_kernel3<false, true>" "fit_accumulate_kernel2<0" "fit_accumulate_kernel2<1" inverse_transform symbol_gather symbol_stream; do
   echo "== $needle: mean per launch (FETCH_SIZE / WRITE_SIZE in KiB) =="
   for p in sq1 sq2 tcc1 tcc2 ic1; do python3 tools/pmc_summary.py $OUT/$p "$needle"; done
