@@ -28,9 +28,20 @@ SPIN_UP_LAUNCHES = 4000  # ~70 ms of untimed work before the warm-up steps, see 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def measured_traffic(name="k1_traffic"):
-    """HBM bytes per K1 launch (per image for the batch form) from the committed rocprofv3 PMC pass (profiles/), or None. bench.py cannot collect
-    hardware counters itself; the number is tied to the kernel and tiling named in the file (newest round first)."""
+def measured_traffic(name="k1_traffic", tiling=None):
+    """HBM bytes per K1 launch (per image for the batch form) from the committed rocprofv3 PMC passes (profiles/), or None. bench.py cannot collect
+    hardware counters itself; the number is tied to the kernel and tiling named in the file (newest round first). `tiling`: the label of the forward
+    tiling the plan measured for itself ("contiguous/band72/cells8/..."): the single-launch figure is then the one of THAT tiling, if it was profiled
+    (profiles/r05_k1_traffic_by_tiling.json: 1.017x on the contiguous 72-row tiling, 1.047-1.054x on the interleaved 16-row ones)."""
+    if tiling and name == "k1_traffic":
+        try:
+            with open(os.path.join(ROOT, "profiles", "r05_k1_traffic_by_tiling.json")) as f:
+                by = json.load(f)["by_tiling"]
+            key = "/".join(tiling.split("/")[:3])
+            if key in by:
+                return int(by[key]["hbm_bytes_per_launch"])
+        except Exception:
+            pass
     for rnd in ("r05", "r04"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as f:
@@ -369,7 +380,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": measured_traffic(),
+            "traffic": measured_traffic(tiling=(tuning or {}).get("winner") or "interleaved/band16/cells8"),
             "kernel": "fwd_transform_quant_kernel<1,false,true,4,true,true,false>",
             "kernel_us": round(kernel_us, 3),
             "algorithmic_bytes_per_launch": alg_bytes,
