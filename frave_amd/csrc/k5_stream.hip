@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(kStreamThreads) symbol_stream_kernel(const Str
 #pragma unroll
     for (int k = 0; k < kStreamPerThread; k++) {
         const uint64_t i = base + (uint64_t)k * kStreamThreads;
-        node[k] = i < a.n_symbols ? __builtin_nontemporal_load(a.order + i) : 0u;
+        node[k] = i < a.n_symbols ? a.order[i] : 0u; // (plain loads: see symbol_gather_kernel)
     }
     int v[kStreamPerThread], p[kStreamPerThread];
     uint32_t b[kStreamPerThread];
@@ -90,7 +90,9 @@ __global__ void __launch_bounds__(kGatherThreads) symbol_gather_kernel(const Gat
     if (wave_first >= 0 && wave_first + kPerWave <= n) {
         uint32_t o[8 * kGatherChunks];
 #pragma unroll
-        for (int k = 0; k < 8 * kGatherChunks; k++) o[k] = __builtin_nontemporal_load(a.order + wave_first + 64 * k + lane);
+        // plain loads: as nontemporal loads (through round 4) the order's 67 MB cost 4.3 us more - 41.2 against 36.9 us per 4096^2 plane, same box, same call
+        // (gpurun_out/r5_k5; the floor without order and gather - words copied in stream order - is 15.7 us, with the order loads but no gather 25.2 us)
+        for (int k = 0; k < 8 * kGatherChunks; k++) o[k] = a.order[wave_first + 64 * k + lane];
         uint16_t w[8 * kGatherChunks];
 #pragma unroll
         for (int k = 0; k < 8 * kGatherChunks; k++) w[k] = words[o[k]];
