@@ -33,15 +33,14 @@ def measured_traffic(name="k1_traffic", tiling=None):
     hardware counters itself; the number is tied to the kernel and tiling named in the file (newest round first). `tiling`: the label of the forward
     tiling the plan measured for itself ("contiguous/band72/cells8/..."): the single-launch figure is then the one of THAT tiling, if it was profiled
     (profiles/r05_k1_traffic_by_tiling.json: 1.017x on the contiguous 72-row tiling, 1.047-1.054x on the interleaved 16-row ones)."""
-    if tiling and name == "k1_traffic":
+    if tiling:  # a tiling that was not profiled has no measured traffic: null, never another tiling's number
         try:
             with open(os.path.join(ROOT, "profiles", "r05_k1_traffic_by_tiling.json")) as f:
-                by = json.load(f)["by_tiling"]
+                by = json.load(f)["by_tiling" if name == "k1_traffic" else "batch_form_by_tiling"]
             key = "/".join(tiling.split("/")[:3])
-            if key in by:
-                return int(by[key]["hbm_bytes_per_launch"])
+            return int(by[key]["hbm_bytes_per_launch"]) if key in by else None
         except Exception:
-            pass
+            return None
     for rnd in ("r05", "r04"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as f:
@@ -412,8 +411,8 @@ def main():
         us_img = ev0.elapsed_time(ev1) * 1e3 / 4 / nb
         out["roofline_batch"] = {
             "bound": "hbm", "images_per_launch": nb, "kernel_us_per_image": round(us_img, 3), "achieved": round(alg_bytes / us_img / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(alg_bytes / us_img / 1e3 / HBM_PEAK_GBS, 4), "traffic": measured_traffic("k1_batch_traffic"),
-            "note": f"one launch over {nb} distinct images (grid.y = {nb}), HIP events around 4 launches; traffic per image from its own PMC pass",
+            "frac": round(alg_bytes / us_img / 1e3 / HBM_PEAK_GBS, 4), "traffic": measured_traffic("k1_batch_traffic", tiling=(tuning or {}).get("winner") or "interleaved/band16/cells8"),
+            "note": f"one launch over {nb} distinct images (grid.y = {nb}), HIP events around 4 launches; traffic per image from the batch form's own PMC pass on this tiling (null: this tiling's batch form was not profiled)",
         }
         # ... and single-image launches dealt over two streams of the library (fri_hip_time_transform_quant_streams_dev): launch i + 1 fills the CUs launch i's
         # early finishers leave. A launch PERIOD (first begin to last end over the launches), never a kernel duration; never part of `value` or `roofline`.
