@@ -139,12 +139,13 @@ int fail_hip(fri_hip_ctx *ctx, hipError_t e, const char *what) {
     } while (0)
 
 template <typename T>
-int upload(fri_hip_plan *p, const std::vector<T> &v, const T *&out) {
+int upload(fri_hip_plan *p, const std::vector<T> &v, const T *&out, size_t pad = 0) { // pad: zeroed elements behind the array
     void *d = nullptr;
-    size_t bytes = v.size() * sizeof(T);
+    size_t bytes = (v.size() + pad) * sizeof(T);
     if (!bytes) bytes = sizeof(T);
     HIP_TRY(p->ctx, hipMalloc(&d, bytes));
     p->owned.push_back(d);
+    if (pad) HIP_TRY(p->ctx, hipMemset(static_cast<T *>(d) + v.size(), 0, pad * sizeof(T)));
     if (!v.empty()) HIP_TRY(p->ctx, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     out = static_cast<const T *>(d);
     return FRI_HIP_OK;
@@ -723,8 +724,8 @@ int fri_hip_plan_create(fri_hip_ctx *ctx, uint32_t width, uint32_t height, uint3
         {
             const Geometry &gi = p->inv_geo();
             if (!gi.inv_lists.empty()) {
-                if ((rc = upload(p, gi.inv_lists, d.inv_lists)) || (rc = upload(p, gi.inv_quads, d.inv_quads)) || (rc = upload(p, gi.inv_dwords, d.inv_dwords)) ||
-                    (rc = upload(p, gi.inv_parts, d.inv_parts))) {
+                if ((rc = upload(p, gi.inv_lists, d.inv_lists)) || (rc = upload(p, gi.inv_quads, d.inv_quads, kInvListPad)) || (rc = upload(p, gi.inv_dwords, d.inv_dwords, kInvListPad)) ||
+                    (rc = upload(p, gi.inv_parts, d.inv_parts, kInvListPad))) {
                     fri_hip_plan_destroy(p);
                     return rc;
                 }

@@ -16,7 +16,10 @@ namespace {
 // (a store instruction costs the same with 2 or 64 active lanes). Every pixel has exactly one owning cell, so no
 // byte is written twice and none is skipped. The coefficients of tile i + 1 are loaded while tile i is processed.
 // ------------------------------------------------------------------------------------------------
-constexpr int kInvThreads = 256;
+#ifndef FRI_K3_THREADS
+#define FRI_K3_THREADS 256
+#endif
+constexpr int kInvThreads = FRI_K3_THREADS;
 constexpr int kInvWaves = kInvThreads / 64;
 constexpr int kInvMaxItemsPerWave = 4; // (cell, channel) items of one tile per transform wave
 
@@ -35,7 +38,7 @@ struct InvArgs {
     int32_t max_wg_tiles;
     int32_t q_identity;
     int32_t q_multiply; // 0: the reference's quantization::decode, which divides (quantization.rs:37); 1: the inverse of the quantiser (wrapping multiply)
-    int32_t ablate; // timing experiments only (FRI_HIP_K3_ABLATE): 1 = no global stores, 2 = no LDS scatter
+    int32_t ablate; // timing experiments only (FRI_HIP_K3_ABLATE): 1 = no global stores, 2 = no LDS scatter, 4 = no transform, 8 = coefficient loads for the first tile only (lists kernel)
     unsigned long long *trace; // diagnostic timeline, null in production
     // static write-out lists (geometry.hpp: InvTileLists), used by inverse_transform_lists_kernel
     const InvTileLists *lists;
@@ -111,6 +114,24 @@ __device__ __forceinline__ void inv_wave(InvRegs c, int lane, const InvArgs &a, 
 #pragma unroll
     for (int i = 0; i < 4; i++) unpair_t<SOME>(s8[i], c.d8[i], leaf[2 * i], leaf[2 * i + 1]);
 }
+// item = cell of the tile x channels + channel. libfri's images have one or three channels (images.rs: Luma, RGB, YCbCr): a division by a run-time C is ~25 scalar
+// instructions per item in front of the item's loads.
+__device__ __forceinline__ void inv_item_split(int item, int C, int &cl, int &ch) {
+    if (C == 1) {
+        cl = item, ch = 0;
+    } else if (C == 3) {
+        cl = item / 3, ch = item - 3 * cl;
+    } else {
+        cl = item / C, ch = item - cl * C;
+    }
+}
+// Touch the registers of prefetched items: the compiler places its wait for their loads in front of this, i.e. where the caller wants it.
+template <int NI>
+__device__ __forceinline__ void inv_land(InvRegs (&r)[NI]) {
+#pragma unroll
+    for (int s = 0; s < NI; s++)
+        asm volatile("" : "+v"(r[s].d8[0]), "+v"(r[s].d8[1]), "+v"(r[s].d8[2]), "+v"(r[s].d8[3]), "+v"(r[s].d7[0]), "+v"(r[s].d7[1]), "+v"(r[s].d6), "+v"(r[s].low));
+}
 __device__ __forceinline__ bool inv_has_none(const InvRegs &c) {
     const bool n = c.d8[0] == kNone || c.d8[1] == kNone || c.d8[2] == kNone || c.d8[3] == kNone || c.d7[0] == kNone || c.d7[1] == kNone ||
                    c.d6 == kNone || c.low == kNone;
@@ -125,7 +146,8 @@ __device__ __forceinline__ void inv_prefetch(const InvArgs &a, const int32_t *im
 #pragma unroll
     for (int s = 0; s < NI; s++) {
         const int item = min(wave + kInvWaves * s, n_items - 1);
-        const int cl = item / C, ch = item - cl * C;
+        int cl, ch;
+        inv_item_split(item, C, cl, ch);
         r[s] = inv_load(img_coefs + ((size_t)ch * a.F + (uint32_t)cells[cl].cell) * kCell, lane);
     }
 }
@@ -311,6 +333,7 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_kernel(const In
 // of the (55 % empty) rectangle, no zeroing, no queue. Needs every image row to start 16-byte aligned (base pointer and
 // width * channels multiples of 16): the launcher falls back to inverse_transform_kernel otherwise.
 constexpr int kInvListPre = 3; // list entries a thread holds in flight per list and tile (more are loaded on demand)
+static_assert((size_t)kInvListPre * kInvThreads <= kInvListPad, "the lists' pad covers a thread's unconditional loads");
 template <int NI>
 __global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(const InvArgs a) {
     const int32_t *const img_coefs = a.coefs + blockIdx.y * a.coef_stride; // this image of the batch, see inverse_transform_kernel
@@ -353,33 +376,57 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(co
         for (int s = 0; s < NI; s++) cur[s] = pre[s];
         {
             const Tile tn = scalar_tile(lds_tiles[min(ti + 1, te - 1) - tb]);
-            inv_prefetch<NI>(a, img_coefs, tn, lds_cells + (tn.cell_begin - cell0), wave, lane, pre);
+            if (!(ablate_flags(a.ablate) & 8)) inv_prefetch<NI>(a, img_coefs, tn, lds_cells + (tn.cell_begin - cell0), wave, lane, pre); // (8: timing only, the first tile's coefficients for every tile)
         }
         // this thread's first entries of the three lists, in flight across the transform (indices clamped: the loads must be
         // unconditional; a tile without entries of one kind re-reads entry 0 of the array, which always exists)
-        auto clamp_idx = [](uint32_t begin, uint32_t count, uint32_t i) { return count ? begin + min(i, count - 1u) : 0u; };
+        // (round 5: no clamping - the arrays are followed by kInvListPad unused entries, a thread past its tile's count loads the next tile's or the pad's and never
+        // looks at them; uniform base + the thread's 32-bit offset, the distance between a thread's entries in the instructions' offset field)
         uint16_t qe[kInvListPre], de[kInvListPre];
         uint32_t pe[kInvListPre];
+        {
+            const uint16_t *qb = a.quads + L.quad_begin, *db = a.dwords + L.dword_begin;
+            const uint32_t *pb = a.parts + L.part_begin;
 #pragma unroll
-        for (int m = 0; m < kInvListPre; m++) {
-            qe[m] = a.quads[clamp_idx(L.quad_begin, L.quad_count, (uint32_t)(tid + kInvThreads * m))];
-            de[m] = a.dwords[clamp_idx(L.dword_begin, L.dword_count, (uint32_t)(tid + kInvThreads * m))];
-            pe[m] = a.parts[clamp_idx(L.part_begin, L.part_count, (uint32_t)(tid + kInvThreads * m))];
+            for (int m = 0; m < kInvListPre; m++) qe[m] = qb[(uint32_t)tid + kInvThreads * m], de[m] = db[(uint32_t)tid + kInvThreads * m], pe[m] = pb[(uint32_t)tid + kInvThreads * m];
         }
         const int n_items = t.cell_count * C;
         const int a0 = (t.x_lo * C) & ~15;                         // first image byte column of the staged rows
         const int pitch = (((t.x_lo + t.width_px) * C - 1 - a0) / 16 + 1) * 16; // LDS bytes per staged row
         int leaf[NI][8];
+        { // one test for the wave's items: the common case (no None anywhere) is ONE basic block in which the items' dependent chains - six LDS round trips each - interleave
+            // (up to two items: four interleaved chains need 150 vector registers, a fourth workgroup per CU no longer fits)
+            if (ablate_flags(a.ablate) & 4) { // (timing only: no transform)
 #pragma unroll
-        for (int s = 0; s < NI; s++) {
-            if (inv_has_none(cur[s])) inv_wave<false>(cur[s], lane, a, leaf[s]);
-            else inv_wave<true>(cur[s], lane, a, leaf[s]);
+                for (int s = 0; s < NI; s++) {
+                    leaf[s][0] = cur[s].d8[0], leaf[s][1] = cur[s].d8[1], leaf[s][2] = cur[s].d8[2], leaf[s][3] = cur[s].d8[3];
+                    leaf[s][4] = cur[s].d7[0], leaf[s][5] = cur[s].d7[1], leaf[s][6] = cur[s].d6, leaf[s][7] = cur[s].low;
+                }
+            } else if (NI <= 2) {
+                bool none = false;
+#pragma unroll
+                for (int s = 0; s < NI; s++) none |= inv_has_none(cur[s]);
+                if (none) {
+#pragma unroll
+                    for (int s = 0; s < NI; s++) inv_wave<false>(cur[s], lane, a, leaf[s]);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NI; s++) inv_wave<true>(cur[s], lane, a, leaf[s]);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < NI; s++) {
+                    if (inv_has_none(cur[s])) inv_wave<false>(cur[s], lane, a, leaf[s]);
+                    else inv_wave<true>(cur[s], lane, a, leaf[s]);
+                }
+            }
         }
 #pragma unroll
         for (int s = 0; s < NI; s++) {
             const int item = wave + kInvWaves * s;
             if (item < n_items && !(ablate_flags(a.ablate) & 2)) {
-                const int cl = item / C, ch = item - cl * C;
+                int cl, ch;
+                inv_item_split(item, C, cl, ch);
                 const TileCell tc = lds_cells[t.cell_begin - cell0 + cl];
                 const int x0 = tc.cx + lane_dx(lane), y0 = tc.cy + lane_dy(lane);
                 // (cell part: scalar) + (lane part): one vector multiply-add per item
@@ -398,25 +445,32 @@ __global__ void __launch_bounds__(kInvThreads) inverse_transform_lists_kernel(co
                 }
             }
         }
+        // The next tile's coefficients have had the transform to arrive: they land HERE, in front of this tile's stores. Loads and stores count in one in-order
+        // counter and the write-out's store count is a run-time number: at the top of the next iteration the compiler's wait for them was a wait for zero, this
+        // tile's stores included. (Measured, round 5: the same 27.3-28.8 us either way; requesting the tile AFTER next here, so that a load has a whole iteration
+        // to arrive, is slower - 30.2-31.5 us: gpurun_out/r5_k3f.)
+        inv_land<NI>(pre);
         lds_barrier(); // the rectangle holds every byte this tile owns
         uint8_t *out0 = img_pixels + (size_t)t.y_lo * wc + (size_t)a0; // quad (r, k) -> out0 + r * wc + 16 k, 16-byte aligned
+        // (a tile's rows x the image's row bytes stay far below 2^32, r < 256 and the row bytes below 2^24: 24-bit multiplies, a 32-bit offset on a uniform base)
+        const uint32_t wc24 = (uint32_t)wc, pitch24 = (uint32_t)pitch;
         for (uint32_t e = tid, m = 0; e < L.quad_count; e += kInvThreads, m++) { // whole quads
             const uint32_t rk = m < kInvListPre ? (m == 0 ? qe[0] : m == 1 ? qe[1] : qe[2]) : a.quads[L.quad_begin + e];
             const uint32_t r = rk >> 8, k = rk & 255u;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(img + r * pitch + 16 * k);
-            if (!(ablate_flags(a.ablate) & 1)) *reinterpret_cast<u32x4 *>(out0 + (size_t)r * wc + 16 * k) = v;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(img + __umul24(r, pitch24) + 16 * k);
+            if (!(ablate_flags(a.ablate) & 1)) *reinterpret_cast<u32x4 *>(out0 + (__umul24(r, wc24) + 16 * k)) = v;
         }
         for (uint32_t e = tid, m = 0; e < L.dword_count; e += kInvThreads, m++) { // whole dwords of partly owned quads
             const uint32_t rd = m < kInvListPre ? (m == 0 ? de[0] : m == 1 ? de[1] : de[2]) : a.dwords[L.dword_begin + e];
             const uint32_t r = rd >> 8, d = rd & 255u;
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(img + r * pitch + 4 * d);
-            if (!(ablate_flags(a.ablate) & 1)) *reinterpret_cast<uint32_t *>(out0 + (size_t)r * wc + 4 * d) = v;
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(img + __umul24(r, pitch24) + 4 * d);
+            if (!(ablate_flags(a.ablate) & 1)) *reinterpret_cast<uint32_t *>(out0 + (__umul24(r, wc24) + 4 * d)) = v;
         }
         for (uint32_t e = tid, m = 0; e < L.part_count; e += kInvThreads, m++) { // the fractal rim proper: byte stores
             const uint32_t ent = m < kInvListPre ? (m == 0 ? pe[0] : m == 1 ? pe[1] : pe[2]) : a.parts[L.part_begin + e];
             const uint32_t r = ent >> 12, d = (ent >> 4) & 255u, nib = ent & 15u;
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(img + r * pitch + 4 * d);
-            uint8_t *p = out0 + (size_t)r * wc + 4 * d;
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(img + __umul24(r, pitch24) + 4 * d);
+            uint8_t *p = out0 + (__umul24(r, wc24) + 4 * d);
             if (!(ablate_flags(a.ablate) & 1)) {
                 if (nib & 1u) p[0] = (uint8_t)v;
                 if (nib & 2u) p[1] = (uint8_t)(v >> 8);

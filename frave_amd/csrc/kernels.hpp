@@ -55,8 +55,8 @@ struct DevicePlan {
     unsigned long long *k1_xcd_stat = nullptr; // [8][2] per-XCD workgroup lifetimes of the forward kernel: set by fri_hip_plan_tune_forward on its measuring copies only
     // K3's static write-out lists (null = not built: the kernel scans the rectangle)
     const InvTileLists *inv_lists = nullptr;
-    const uint16_t *inv_quads = nullptr, *inv_dwords = nullptr;
-    const uint32_t *inv_parts = nullptr;
+    const uint16_t *inv_quads = nullptr, *inv_dwords = nullptr; // each array is followed by kInvListPad entries a thread may load and never uses (the lists kernel
+    const uint32_t *inv_parts = nullptr;                        // requests its first entries of a tile without looking at the tile's counts)
     int32_t inv_rect_bytes = 0;
     bool k3_scan = false; // FRI_HIP_K3_SCAN=1: always use the scanning kernel (A/B)
     int32_t k3_ablate = 0; // same for the inverse kernel, see InvArgs::ablate
@@ -150,6 +150,7 @@ size_t inv_lds_bytes(const DevicePlan &p);
 bool device_footprint_matches(const StaticTables &st);
 // True iff the plan's tiles fit the forward kernel's static register/LDS budget.
 bool fwd_plan_fits(const DevicePlan &p);
+constexpr size_t kInvListPad = 2048; // >= kInvListPre x kInvThreads of k3_inverse.hip
 bool inv_plan_fits(const DevicePlan &p, bool with_lists); // k3_inverse.hip: the inverse kernels' own limits (its tiling is its own since round 4)
 
 } // namespace fri
