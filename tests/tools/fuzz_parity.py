@@ -97,6 +97,8 @@ def run(n_cases, seed, ctx=None):
         if msgs:
             bad += 1
             print(f"case {case}: {w}x{h}x{c} {kind} q={q[:10].tolist()}: MISMATCH in {msgs}", flush=True)
+        if (case + 1) % 250 == 0:  # a sign of life for long runs (a silent command is taken to be hung after a few minutes)
+            print(f"... {case + 1} cases, {bad} mismatching, {time.time() - t0:.0f} s", flush=True)
         P.close()
         W.close()
     print(f"{n_cases} cases ({chains} with the fitted chain and the symbol stream route), {bad} mismatching, {time.time() - t0:.0f} s")
