@@ -1841,6 +1841,14 @@ int fri_hip_plan_tune_forward(fri_hip_plan *p, uint32_t launches, char *report, 
         if (cand[k]->us < cand[best]->us) best = k;
     // the default stays unless a candidate beats it by more than the noise between rounds (1.5 %)
     if (cand[best]->us > cand[0]->us * 0.985) best = 0;
+    // Equal times: contiguous shares. They re-read less halo through HBM at every band height (4096^2, PMC passes over 21 tilings: 1.016-1.018 x the algorithmic bytes
+    // against 1.044-1.056 x for interleaved shares, profiles/r05_k1_traffic_by_tiling.json) - a contiguous candidate within 1 % of an interleaved winner takes its place.
+    if (cand[best]->tp.strided_shares) {
+        size_t c = best;
+        for (size_t k = 0; k < cand.size(); k++)
+            if (!cand[k]->tp.strided_shares && cand[k]->us <= cand[best]->us * 1.01 && (c == best || cand[k]->us < cand[c]->us)) c = k;
+        best = c;
+    }
     // Second phase: around the winner - its neighbours in band height and tile size, for contiguous shares the XCDs taking turns over groups of tiles, flatter and
     // steeper share sizes by dispatch rank - measured together with it, interleaved like the first phase.
     {
