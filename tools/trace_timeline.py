@@ -31,6 +31,8 @@ for rep in range(3 if SLOTS <= 8 else 2):  # the last launch (cold slot) is the 
 torch.cuda.synchronize()
 tr = plan.read_trace().astype(np.int64)
 _, _, wg_tiles = plan.tile_table()
+if os.environ.get("TRACE_DUMP"):  # the raw stamps (slot 14 = HW_ID | XCC_ID << 32: which CU a workgroup ran on) for an analysis off the box
+    np.savez(os.environ["TRACE_DUMP"], trace=tr, wg_tiles=np.asarray(wg_tiles))
 n_tiles = np.diff(wg_tiles)
 t0 = tr[:, 0].min()
 us = lambda a: (a - t0) / 100.0
