@@ -543,7 +543,7 @@ hipError_t launch_inverse_transform(const DevicePlan &p, uint32_t n_images, cons
     if (!inv_plan_fits(p, false)) return hipErrorInvalidConfiguration;
     // static write-out lists when every image row starts 16-byte aligned (and their rectangle fits: fri_hip_plan_create checks that for the tilings it builds)
     const bool lists = p.inv_lists && !p.k3_scan && inv_plan_fits(p, true) && (reinterpret_cast<uintptr_t>(pixels) & 15) == 0 && (((size_t)p.width * p.channels) & 15) == 0 &&
-                       (n_images == 1 || (pixel_stride & 15) == 0);
+                       (n_images == 1 || (pixel_stride & 15) == 0) && (size_t)p.width * p.channels < ((size_t)1 << 24); // (the write-out's 24-bit row-bytes multiply)
     if (lists) {
         a.lists = p.inv_lists;
         a.quads = p.inv_quads;
