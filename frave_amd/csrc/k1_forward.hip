@@ -183,6 +183,18 @@ __device__ __forceinline__ void store_item(int32_t *__restrict__ coefs, uint32_t
     // Streaming (nontemporal) stores: the coefficients are written once and not read back by this kernel. Regular stores leave
     // up to 32 MB of dirty lines in the eight L2s, which the end-of-kernel release then has to write back while nothing else
     // runs. A/B on one box, us per 4096^2 launch: plain 27.5, nt 22.0-23.6, sc1 26.0, sc0 sc1 25.5, sc0 sc1 nt 22.0-23.2.
+#ifdef FRI_K1_I16_EXPERIMENT // (timing only, never in the product: the coefficients leave as int16 - half the store bytes; what a halfword chain would gain)
+    {
+        int16_t *o16 = reinterpret_cast<int16_t *>(coefs) + elem_off;
+        const uint32_t p0 = ((uint32_t)v[0] & 0xFFFFu) | ((uint32_t)v[1] << 16), p1 = ((uint32_t)v[2] & 0xFFFFu) | ((uint32_t)v[3] << 16);
+        const uint32_t p2 = ((uint32_t)v[4] & 0xFFFFu) | ((uint32_t)v[5] << 16);
+        __builtin_nontemporal_store(i32x2{(int)p0, (int)p1}, reinterpret_cast<i32x2 *>(o16 + 256 + 4 * lane));
+        __builtin_nontemporal_store(p2, reinterpret_cast<uint32_t *>(o16 + 128 + 2 * lane));
+        __builtin_nontemporal_store((int16_t)v[6], o16 + 64 + lane);
+        __builtin_nontemporal_store((int16_t)v[7], o16 + lane);
+        return;
+    }
+#endif
     if constexpr (NT) {
         __builtin_nontemporal_store(i32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<i32x4 *>(out + 256 + 4 * lane));
         __builtin_nontemporal_store(i32x2{v[4], v[5]}, reinterpret_cast<i32x2 *>(out + 128 + 2 * lane));
