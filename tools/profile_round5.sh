@@ -5,7 +5,7 @@ export FRI_HIP_TUNING=1  # the library reads its tuning knobs from the environme
 # bench.py (plain, and under rocprofv3 --kernel-trace --stats with its extras: one trace holds K1 and every other kernel / chain of the line), K1 RGB and
 # 16384^2, K2 / K3 / K4 / K5 standalone over rotating planes, and the PMC counters (separate passes, no trace domains mixed in) of K1 (traffic), K1 RGB,
 # K2, K4, K3, K5. All byte counts in the summaries: counter KiB x 1024 (one convention: VERDICT r3).
-# usage: tools/profile_round4.sh <tag>   -> gpurun_out/<tag>/...
+# usage: tools/profile_round5.sh <tag>   -> gpurun_out/<tag>/...   (then: python3 tools/collect_profiles.py <tag> r05)
 set -u
 TAG=$1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
