@@ -24,6 +24,8 @@ def run(n_cases, seed, ctx=None):
             w, h = int(rng.integers(1, 60)), int(rng.integers(1, 900))
             if rng.random() < 0.5:
                 w, h = h, w
+        elif os.environ.get("FUZZ_LARGE") == "1":  # mid-size and large planes (round 5): other share counts, band layouts and list sizes than the small shapes reach
+            w, h = int(rng.integers(1400, 6000)), int(rng.integers(900, 4500))
         else:
             w, h = int(rng.integers(46, 1400)), int(rng.integers(46, 900))
         c = 1 if rng.random() < 0.5 else 3
@@ -97,7 +99,7 @@ def run(n_cases, seed, ctx=None):
         if msgs:
             bad += 1
             print(f"case {case}: {w}x{h}x{c} {kind} q={q[:10].tolist()}: MISMATCH in {msgs}", flush=True)
-        if (case + 1) % 250 == 0:  # a sign of life for long runs (a silent command is taken to be hung after a few minutes)
+        if (case + 1) % (10 if os.environ.get("FUZZ_LARGE") == "1" else 250) == 0:  # a sign of life for long runs (a silent command is taken to be hung after a few minutes)
             print(f"... {case + 1} cases, {bad} mismatching, {time.time() - t0:.0f} s", flush=True)
         P.close()
         W.close()
