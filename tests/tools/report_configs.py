@@ -43,7 +43,11 @@ def line(name, us, pixels, nbytes):
 def kernels(w, h, c, slots, label):
     P = frave_amd.Plan(ctx, w, h, c)
     F = P.num_cells
-    print(f"  {label}: {w}x{h}x{c}, F={F} cells, tiling {P.tiling()}")
+    try:  # like bench.py: the plan measures its forward tiling (later plans of the shape in this process start from the winner)
+        tuned = P.tune_forward()
+    except frave_amd.api.FriHipError as e:
+        tuned = {"tuned": False, "why": str(e)}
+    print(f"  {label}: {w}x{h}x{c}, F={F} cells, forward tiling {tuned.get('winner') or ('default: ' + str(tuned.get('why', 'not tunable')))}, {P.tiling()}")
     d_px = torch.randint(0, 256, (slots, P.pixel_bytes), dtype=torch.uint8, device="cuda")
     d_co = torch.empty((slots, P.coef_count), dtype=torch.int32, device="cuda")
     k1 = P.time_transform_quant_dev(slots, d_px.data_ptr(), P.pixel_bytes, d_co.data_ptr(), P.coef_count, 20, stream=s)
