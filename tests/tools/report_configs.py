@@ -50,8 +50,8 @@ def kernels(w, h, c, slots, label):
     print(f"  {label}: {w}x{h}x{c}, F={F} cells, forward tiling {tuned.get('winner') or ('default: ' + str(tuned.get('why', 'not tunable')))}, {P.tiling()}")
     d_px = torch.randint(0, 256, (slots, P.pixel_bytes), dtype=torch.uint8, device="cuda")
     d_co = torch.empty((slots, P.coef_count), dtype=torch.int32, device="cuda")
-    k1 = P.time_transform_quant_dev(slots, d_px.data_ptr(), P.pixel_bytes, d_co.data_ptr(), P.coef_count, 20, stream=s)
-    k1 = P.time_transform_quant_dev(slots, d_px.data_ptr(), P.pixel_bytes, d_co.data_ptr(), P.coef_count, 100 if w * h < 1e8 else 20, stream=s)
+    k1 = P.time_transform_quant_dev(slots, d_px.data_ptr(), P.pixel_bytes, d_co.data_ptr(), P.coef_count, 2000 if w * h < 1e8 else 40, stream=s)  # untimed: tens of ms of work, like bench.py's spin-up
+    k1 = P.time_transform_quant_dev(slots, d_px.data_ptr(), P.pixel_bytes, d_co.data_ptr(), P.coef_count, 400 if w * h < 1e8 else 40, stream=s)
     alg1 = P.pixel_bytes + P.coef_count * 4
     line("K1 transform+quant (all channels)", k1, w * h, alg1)
     d_b = torch.empty(F * 512, dtype=torch.uint8, device="cuda")
