@@ -208,6 +208,18 @@ def extras(plan, ctx, torch, np, d_px, d_co, slots, alg_bytes, stream, full=Fals
     res["chain_to_symbol_stream_given_params"] = entry(sym, alg_bytes + k2w_bytes + k5_bytes)
     res["k5_symbol_gather"] = entry(sym - given, k5_bytes)
     res["k5_symbol_gather"]["note"] = "difference of the two chains above (the scan's halfword form is ~1.5 us faster than its array form, so this slightly understates K5)"
+    # The same chains with the fit, and with d_coefs = NULL: a caller that wants only the stream (the emitter does) lets the coefficients travel between the kernels as
+    # the plan's compact planes - int16, None as 0 - instead of the ABI's int32 planes: K1 writes 34 instead of 68 MB, the fit and the scan read half (round 5; the
+    # streams, histograms and parameters are the same bits: tests/test_gpu_compact.py). Algorithmic bytes stay SURVEY's int32 figures: the fractions compare like with like.
+    d_rng = torch.zeros(1, dtype=torch.int64, device="cuda")
+    symrun = lambda k, fit, coefs: plan.encode_symbols_batch_dev(1, px(k), pstride, None, fit, d_par.data_ptr(), coefs, cstride, d_words.data_ptr(), plane, d_sym.data_ptr(), n_sym,
+                                                                d_h.data_ptr(), d_o.data_ptr(), d_rng.data_ptr(), stream=stream)
+    res["chain_to_symbol_stream_with_fit"] = entry(timed(lambda k: symrun(k, True, co(k))), alg_bytes + k2w_bytes + k5_bytes + 2 * k4_bytes)
+    d_par.copy_(torch.from_numpy(np.stack([vp, wp]).reshape(-1)))
+    res["chain_to_symbol_stream_given_params_compact"] = entry(timed(lambda k: symrun(k, False, 0)), alg_bytes + k2w_bytes + k5_bytes)
+    res["chain_to_symbol_stream_with_fit_compact"] = entry(timed(lambda k: symrun(k, True, 0)), alg_bytes + k2w_bytes + k5_bytes + 2 * k4_bytes)
+    for key in ("chain_to_symbol_stream_given_params_compact", "chain_to_symbol_stream_with_fit_compact"):
+        res[key]["note"] = "d_coefs = NULL: int16 coefficient planes inside the chain (fri_hip_encode_symbols_batch_dev); same streams, histograms and parameters"
     del d_words, d_sym
     # K1 on RGB, the colour space libfri really encodes (wavelet_transform.rs:191, 415-416)
     plan3 = frave_amd.Plan(ctx, W, H, 3)

@@ -106,6 +106,10 @@ struct fri_hip_plan {
     hipEvent_t ev_fit = nullptr;
     bool assume_forward = false; // fri_hip_plan_assume_forward_coefficients
     uint32_t *d_stream_order = nullptr; // fri_hip_plan_set_stream_order: node index of the i-th symbol of a channel, [geo.n_some]
+    // The symbol-stream chains' compact coefficient planes (round 5): int16, None as 0, [planes][F][512] - between the forward kernel, the fit and the scan when the
+    // caller does not ask for the coefficients (fri_hip_encode_image_symbols; fri_hip_encode_symbols_batch_dev with d_coefs == NULL). Half the bytes written and read three times.
+    int16_t *d_coefs16 = nullptr;
+    size_t coefs16_planes = 0;
     uint16_t *d_symbols = nullptr;      // fri_hip_encode_image_symbols: [C][geo.n_some]
     uint16_t *d_words = nullptr;        // ... and the scan's halfword planes [C][F][512] the stream is gathered from
     uint32_t acc_next = 0;
@@ -794,6 +798,7 @@ int fri_hip_plan_destroy(fri_hip_plan *p) {
         for (void *d : {(void *)p->d_bucket_all, (void *)p->d_prediction_all, (void *)p->d_hist_all, (void *)p->d_oob_all})
             if (d) (void)hipFree(d);
         if (p->d_stream_order) (void)hipFree(p->d_stream_order);
+        if (p->d_coefs16) (void)hipFree(p->d_coefs16);
         if (p->d_symbols) (void)hipFree(p->d_symbols);
         if (p->d_words) (void)hipFree(p->d_words);
         if (p->h_fit) (void)hipHostFree(p->h_fit);
@@ -1202,6 +1207,18 @@ void fri_hip_fit_width_params(const int64_t wtw[3][21], const double wtr[3][6], 
 }
 
 /* ---- the device part of FRIEncoder::encode in one call ------------------------------------------------ */
+// the plan's compact coefficient planes for `planes` planes (grown, never shrunk; a growing call waits for the device: hipFree synchronises)
+static int ensure_coefs16(fri_hip_plan *p, size_t planes) {
+    if (p->coefs16_planes >= planes) return FRI_HIP_OK;
+    fri_hip_ctx *c = p->ctx;
+    if (p->d_coefs16) {
+        HIP_TRY(c, hipFree(p->d_coefs16));
+        p->d_coefs16 = nullptr, p->coefs16_planes = 0;
+    }
+    HIP_TRY(c, hipMalloc((void **)&p->d_coefs16, planes * p->geo.centers.size() * kCell * sizeof(int16_t)));
+    p->coefs16_planes = planes;
+    return FRI_HIP_OK;
+}
 static int ensure_encode_staging(fri_hip_plan *p, bool node_arrays = true) {
     fri_hip_ctx *c = p->ctx;
     const size_t C = p->geo.channels, plane = p->geo.centers.size() * kCell;
@@ -1241,13 +1258,14 @@ static int fit_chain(fri_hip_plan *p, const PredBatch &b, unsigned long long *d_
 // device-side fit above, then the parameters and the range counts come back through pinned memory behind an event the host waits for
 // while the scan kernel, already queued behind them, runs).
 static int predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, float *value_params, float *width_params, uint8_t *d_bucket, int32_t *d_prediction,
-                             uint32_t *d_hist, uint64_t *d_oob, int trust, hipStream_t s, uint16_t *d_words = nullptr) {
+                             uint32_t *d_hist, uint64_t *d_oob, int trust, hipStream_t s, uint16_t *d_words = nullptr, const int16_t *d_coefs16 = nullptr) {
     fri_hip_ctx *c = p->ctx;
     const uint32_t C = p->geo.channels;
     const size_t plane = p->geo.centers.size() * kCell;
     PredBatch b;
     b.n_planes = C;
     b.coefs = d_coefs;
+    b.coefs16 = d_coefs16; // (instead of d_coefs: the plan's compact planes, see fri_hip_encode_image_symbols)
     b.coef_stride = plane;
     b.out_stride = plane;
     b.words = d_words; // (the halfword form of the scan: see fri_hip_encode_image_symbols)
@@ -1345,8 +1363,10 @@ int fri_hip_encode_symbols_batch_dev(fri_hip_plan *p, uint32_t n_images, const u
     if (int rc = need_device(p)) return rc;
     const uint32_t C = p->geo.channels;
     const size_t plane = p->geo.centers.size() * kCell, image = (size_t)C * plane, n = p->geo.n_some;
-    if (!d_pixels || !d_params || !d_coefs || !d_node_words || !d_symbols || !d_hist || !d_n_out_of_alphabet || !n_images || (uint64_t)n_images * C > 65535u || !p->d_stream_order)
+    if (!d_pixels || !d_params || !d_node_words || !d_symbols || !d_hist || !d_n_out_of_alphabet || !n_images || (uint64_t)n_images * C > 65535u || !p->d_stream_order)
         return FRI_HIP_ERR_INVALID_ARGUMENT;
+    const bool compact = d_coefs == nullptr; // the caller does not want the coefficients: they travel between the kernels as the plan's int16 planes
+    if (compact) coef_stride = image;
     if (n_images > 1 && (pixel_stride < fri_hip_plan_pixel_bytes(p) || coef_stride < image || word_stride < image || symbol_stride < (size_t)C * n)) return FRI_HIP_ERR_INVALID_ARGUMENT;
     // evenly spaced planes, as above; a channel's stream follows the previous channel's
     if (C > 1 && n_images > 1 && (coef_stride != image || word_stride != image || symbol_stride != (size_t)C * n)) return FRI_HIP_ERR_INVALID_ARGUMENT;
@@ -1354,11 +1374,15 @@ int fri_hip_encode_symbols_batch_dev(fri_hip_plan *p, uint32_t n_images, const u
     if (int rc = check_q(qmatrix, q)) return rc;
     HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, q, s, chain_wants_cached_coefficients(p, n_images, fit)));
+    if (compact)
+        if (int rc = ensure_coefs16(p, (size_t)n_images * C)) return rc;
+    HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, q, s, chain_wants_cached_coefficients(p, n_images, fit),
+                                               compact ? p->d_coefs16 : nullptr));
     PredBatch b;
     b.n_planes = n_images * C;
     b.coefs = d_coefs;
-    b.coef_stride = C > 1 ? plane : coef_stride;
+    b.coefs16 = compact ? p->d_coefs16 : nullptr;
+    b.coef_stride = C > 1 || compact ? plane : coef_stride;
     b.out_stride = C > 1 ? plane : word_stride;
     b.params = reinterpret_cast<const PredictParams *>(d_params);
     b.words = d_node_words;
@@ -1585,9 +1609,12 @@ int fri_hip_encode_image_symbols(fri_hip_plan *p, const uint8_t *pixels, const i
     QMatrix q;
     if (int rc = check_q(qmatrix, q)) return rc;
     HIP_TRY(c, hipMemcpy(p->d_pixels, pixels, fri_hip_plan_pixel_bytes(p), hipMemcpyHostToDevice));
-    HIP_TRY(c, launch_fwd_transform_quant(p->dev, 1, p->d_pixels, 0, p->d_coefs, 0, q, nullptr));
+    // nobody outside sees the coefficients of this call: compact planes (int16, None as 0) between the forward kernel, the fit and the scan
+    if (int rc = ensure_coefs16(p, C)) return rc;
+    HIP_TRY(c, launch_fwd_transform_quant(p->dev, 1, p->d_pixels, 0, nullptr, 0, q, nullptr, false, p->d_coefs16));
     // the scan in its halfword form (no bucket / prediction arrays are written at all), then the gather into stream order
-    if (int rc = predict_image_dev(p, p->d_coefs, fit, value_params, width_params, nullptr, nullptr, p->d_hist_all, (uint64_t *)p->d_oob_all, kPredForwardOutput, nullptr, p->d_words))
+    if (int rc = predict_image_dev(p, nullptr, fit, value_params, width_params, nullptr, nullptr, p->d_hist_all, (uint64_t *)p->d_oob_all, kPredForwardOutput, nullptr, p->d_words,
+                                   p->d_coefs16))
         return rc;
     HIP_TRY(c, launch_symbol_gather(p->d_stream_order, n, (uint32_t)C, p->d_words, plane, p->d_symbols, n, nullptr));
     HIP_TRY(c, hipMemcpy(symbols, p->d_symbols, C * n * sizeof(uint16_t), hipMemcpyDeviceToHost));

@@ -162,7 +162,10 @@ __device__ __forceinline__ int quant_one(int v, int heap_index, const FwdArgs &a
 
 // One item (HALF = 0: item A, 1: item B of the pair - selects the half of `valid`): applies the None mask and the quantiser, and stores the
 // cell's 512 int32 coefficients as four fully coalesced store instructions (1 KiB + 512 B + 256 B + 256 B).
-template <int HALF, bool MASKED, bool QID, bool NT>
+// C16 (round 5, the chains' compact coefficient planes): the item leaves as 512 int16 - every coefficient of the transform fits nine bits - with None as 0, which is
+// what every reader of such a plane takes a None for (the scan and the fit read neighbours with unwrap_or(0) and know Some from None by the plan's masks); `coefs`
+// is then the int16 plane's base and elem_off counts halfwords. Plain stores: the plane is read back by the next kernels of the chain.
+template <int HALF, bool MASKED, bool QID, bool NT, bool C16 = false>
 __device__ __forceinline__ void store_item(int32_t *__restrict__ coefs, uint32_t elem_off, int lane, const int (&res)[8], uint32_t valid,
                                            const FwdArgs &a) {
     int v[8];
@@ -183,18 +186,20 @@ __device__ __forceinline__ void store_item(int32_t *__restrict__ coefs, uint32_t
     // Streaming (nontemporal) stores: the coefficients are written once and not read back by this kernel. Regular stores leave
     // up to 32 MB of dirty lines in the eight L2s, which the end-of-kernel release then has to write back while nothing else
     // runs. A/B on one box, us per 4096^2 launch: plain 27.5, nt 22.0-23.6, sc1 26.0, sc0 sc1 25.5, sc0 sc1 nt 22.0-23.2.
-#ifdef FRI_K1_I16_EXPERIMENT // (timing only, never in the product: the coefficients leave as int16 - half the store bytes; what a halfword chain would gain)
-    {
+    if constexpr (C16) {
         int16_t *o16 = reinterpret_cast<int16_t *>(coefs) + elem_off;
+        if (MASKED) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = v[i] == kNone ? 0 : v[i]; // (the quantiser leaves a None alone)
+        }
         const uint32_t p0 = ((uint32_t)v[0] & 0xFFFFu) | ((uint32_t)v[1] << 16), p1 = ((uint32_t)v[2] & 0xFFFFu) | ((uint32_t)v[3] << 16);
         const uint32_t p2 = ((uint32_t)v[4] & 0xFFFFu) | ((uint32_t)v[5] << 16);
-        __builtin_nontemporal_store(i32x2{(int)p0, (int)p1}, reinterpret_cast<i32x2 *>(o16 + 256 + 4 * lane));
-        __builtin_nontemporal_store(p2, reinterpret_cast<uint32_t *>(o16 + 128 + 2 * lane));
-        __builtin_nontemporal_store((int16_t)v[6], o16 + 64 + lane);
-        __builtin_nontemporal_store((int16_t)v[7], o16 + lane);
+        *reinterpret_cast<i32x2 *>(o16 + 256 + 4 * lane) = i32x2{(int)p0, (int)p1};
+        *reinterpret_cast<uint32_t *>(o16 + 128 + 2 * lane) = p2;
+        o16[64 + lane] = (int16_t)v[6];
+        o16[lane] = (int16_t)v[7];
         return;
     }
-#endif
     if constexpr (NT) {
         __builtin_nontemporal_store(i32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<i32x4 *>(out + 256 + 4 * lane));
         __builtin_nontemporal_store(i32x2{v[4], v[5]}, reinterpret_cast<i32x2 *>(out + 128 + 2 * lane));
@@ -386,7 +391,7 @@ __device__ __forceinline__ ItemAddr item_addr(const FwdArgs &a, const Tile &t, c
 // rectangle of tile i+1 is already in flight from HBM/L2 into registers and is committed to the other buffer.
 // MEASURE: the same kernel under another name - the launches fri_hip_plan_tune_forward times on its scratch buffers (candidate tilings, most of them slower than
 // the one kept) must not sit in the same row of a kernel trace's statistics as the caller's launches.
-template <int C, bool EDGE, bool FAST, int NCH, bool QID, bool NT, bool MEASURE = false>
+template <int C, bool EDGE, bool FAST, int NCH, bool QID, bool NT, bool MEASURE = false, bool C16 = false>
 __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if (ablate_flags(a.ablate) & 8) return; // timing only: what dispatching the grid alone costs
@@ -405,7 +410,8 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
     Tile *lds_tiles = reinterpret_cast<Tile *>(junk + 16 * kFwdThreads);
     if (tid < te - tb) lds_tiles[tid] = a.tiles[tb + tid];
     const uint8_t *img = a.pixels + (size_t)blockIdx.y * a.pixel_stride;
-    int32_t *coefs = a.coefs + (size_t)blockIdx.y * a.coef_stride;
+    int32_t *coefs = C16 ? reinterpret_cast<int32_t *>(reinterpret_cast<int16_t *>(a.coefs) + (size_t)blockIdx.y * a.coef_stride) // (a compact plane: see store_item)
+                         : a.coefs + (size_t)blockIdx.y * a.coef_stride;
     const int ldx = lane_dx(lane), ldy = lane_dy(lane);
     const int lane_rb = ldy * a.pitch + ldx * C; // the lane's share of a leaf window's LDS offset (item_addr)
     const uint32_t a16 = (uint32_t)reinterpret_cast<uintptr_t>(img);
@@ -530,11 +536,11 @@ __global__ void __launch_bounds__(kFwdThreads) fwd_transform_quant_kernel(const 
                                resB[c][4] ^ resB[c][5] ^ resB[c][6] ^ resB[c][7]) == 0x12345678; // keeps the arithmetic alive
                 if (go) {
                     if (__builtin_amdgcn_readfirstlane(valid[c] == 0xFFFFFFFFu ? 1 : 0) && __all(valid[c] == 0xFFFFFFFFu)) { // no None anywhere in the pair
-                        store_item<0, false, QID, NT>(coefs, offA[c], lane, resA[c], valid[c], a);
-                        if (itA + 1 < n_items) store_item<1, false, QID, NT>(coefs, offB[c], lane, resB[c], valid[c], a);
+                        store_item<0, false, QID, NT, C16>(coefs, offA[c], lane, resA[c], valid[c], a);
+                        if (itA + 1 < n_items) store_item<1, false, QID, NT, C16>(coefs, offB[c], lane, resB[c], valid[c], a);
                     } else {
-                        store_item<0, true, QID, NT>(coefs, offA[c], lane, resA[c], valid[c], a);
-                        if (itA + 1 < n_items) store_item<1, true, QID, NT>(coefs, offB[c], lane, resB[c], valid[c], a);
+                        store_item<0, true, QID, NT, C16>(coefs, offA[c], lane, resA[c], valid[c], a);
+                        if (itA + 1 < n_items) store_item<1, true, QID, NT, C16>(coefs, offB[c], lane, resB[c], valid[c], a);
                     }
                 }
             }
@@ -575,13 +581,13 @@ bool fwd_plan_fits(const DevicePlan &p) {
 }
 
 hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, const uint8_t *pixels, size_t pixel_stride, int32_t *coefs,
-                                      size_t coef_stride, const QMatrix &q, hipStream_t stream, bool cached_stores) {
+                                      size_t coef_stride, const QMatrix &q, hipStream_t stream, bool cached_stores, int16_t *coefs16) {
     if (!fwd_plan_fits(p)) return hipErrorInvalidConfiguration;
     const bool plain = p.k1_cached_stores >= 0 ? p.k1_cached_stores > 0 : cached_stores;
     FwdArgs a{};
     a.pixels = pixels;
     a.pixel_stride = pixel_stride;
-    a.coefs = coefs;
+    a.coefs = coefs16 ? reinterpret_cast<int32_t *>(coefs16) : coefs; // (coefs16: the chains' compact planes - int16, None as 0, coef_stride in halfwords; store_item<.., C16>)
     a.coef_stride = coef_stride;
     a.tiles = p.tiles;
     a.tile_meta = p.tile_meta;
@@ -621,6 +627,15 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
                              : (small ? fwd_transform_quant_kernel<CH, false, false, 4, true, true, true> : fwd_transform_quant_kernel<CH, false, false, kMaxChunksPerThread, true, true, true>))
         kern = p.channels == 1 ? FRI_PICK_M(1) : FRI_PICK_M(3);
 #undef FRI_PICK_M
+    }
+    if (coefs16) { // (plain stores, no MEASURE instance)
+#define FRI_PICK_C(CH, E, FA, N) (a.q_identity ? fwd_transform_quant_kernel<CH, E, FA, N, true, false, false, true> : fwd_transform_quant_kernel<CH, E, FA, N, false, false, false, true>)
+#define FRI_PICK_CN(CH, E, FA) (small ? FRI_PICK_C(CH, E, FA, 4) : FRI_PICK_C(CH, E, FA, kMaxChunksPerThread))
+#define FRI_PICK_CC(CH) (edge ? FRI_PICK_CN(CH, true, false) : fast ? FRI_PICK_CN(CH, false, true) : FRI_PICK_CN(CH, false, false))
+        kern = p.channels == 1 ? FRI_PICK_CC(1) : FRI_PICK_CC(3);
+#undef FRI_PICK_CC
+#undef FRI_PICK_CN
+#undef FRI_PICK_C
     }
 #undef FRI_PICK
 #undef FRI_PICK_N

@@ -420,12 +420,14 @@ struct P3LfValues {
     int v[3], value;
     uint32_t mask0;
 };
+template <bool C16 = false>
 __device__ __forceinline__ void p3_lf_hop_b(const PredArgs &a, const int32_t *plane, const P3LfItem &it, P3LfValues &x) {
     const uint32_t n = (uint32_t)it.node;
+    auto at = [&](int cell) -> int { return C16 ? (int)(reinterpret_cast<const int16_t *>(plane) + (size_t)cell * kCell)[n] : (plane + (size_t)cell * kCell)[n]; };
 #pragma unroll
-    for (int k = 0; k < 3; k++) x.v[k] = (plane + (size_t)max(pred_slot_cell(it.nb[k]), 0) * kCell)[n]; // unconditional loads: an absent neighbour reads cell 0 and is zeroed below
+    for (int k = 0; k < 3; k++) x.v[k] = at(max(pred_slot_cell(it.nb[k]), 0)); // unconditional loads: an absent neighbour reads cell 0 and is zeroed below
     const int cell = max(pred_slot_cell(it.raw), 0);
-    x.value = (plane + (size_t)cell * kCell)[n];
+    x.value = at(cell);
     x.mask0 = a.valid_mask[(size_t)cell * 16];
 }
 template <bool WORDS>
@@ -599,10 +601,16 @@ __device__ __forceinline__ void p3_check(float m, int lane, uint32_t *inexact) {
 struct P3Halo {
     int raw, v;
 };
+// C16 (round 5, here and in p3_load_own / p3_lf_hop_b): `plane` is a chain's compact plane - int16, None as 0 (k1_forward.hip, store_item<.., C16>); the None tests
+// further down never fire on such values and need no second form.
+template <bool C16 = false>
 __device__ __forceinline__ void p3_issue_halo(const int32_t *plane, const int32_t *slots, uint32_t ring_off, uint32_t heap_off, P3Halo &h) {
     h.raw = *reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(slots) + ring_off);
     const uint32_t cell = (uint32_t)max(h.raw, 0) & (uint32_t)(kPredSlotInterior - 1); // a slot without a cell reads cell 0 and is zeroed at the commit
-    h.v = *reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(plane) + ((cell << 11) + heap_off));
+    if (C16)
+        h.v = *reinterpret_cast<const int16_t *>(reinterpret_cast<const uint8_t *>(plane) + ((cell << 10) + (heap_off >> 1)));
+    else
+        h.v = *reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(plane) + ((cell << 11) + heap_off));
 }
 template <bool CHECK>
 __device__ __forceinline__ float p3_commit_halo(const P3Halo &h, uint8_t *image, uint32_t lds_off) {
@@ -625,16 +633,30 @@ struct P3Lane {          // loop invariants of a lane
 
 // what a wave stages of one of its own block cells: its four nodes (role 1: one dwordx4, role 0: two dwordx2). Wave-uniform base
 // + 32-bit lane offset: saddr + voffset addressing, no vector pointer arithmetic.
-template <int ROLE>
-__device__ __forceinline__ i32x4 p3_load_own(const int32_t *cell_base, uint32_t lane) {
+// C16: the four values arrive as two dwords of two int16 each (.x, .y; p3_unpack_own turns them into the four int32 once the loads have landed).
+template <int ROLE, bool C16 = false>
+__device__ __forceinline__ i32x4 p3_load_own(const int32_t *plane, size_t cell, uint32_t lane) {
+    if (C16) {
+        const int16_t *cell_base = reinterpret_cast<const int16_t *>(plane) + cell * kCell;
+        if (ROLE) {
+            const i32x2 d = reinterpret_cast<const i32x2 *>(cell_base + 256)[lane];
+            return i32x4{d.x, d.y, 0, 0};
+        }
+        return i32x4{reinterpret_cast<const int32_t *>(cell_base)[lane], reinterpret_cast<const int32_t *>(cell_base + 128)[lane], 0, 0};
+    }
+    const int32_t *cell_base = plane + cell * kCell;
     if (ROLE) return reinterpret_cast<const i32x4 *>(cell_base + 256)[lane];
     const i32x2 a = reinterpret_cast<const i32x2 *>(cell_base)[lane], b = reinterpret_cast<const i32x2 *>(cell_base + 128)[lane];
     return i32x4{a.x, a.y, b.x, b.y};
 }
+template <bool C16>
+__device__ __forceinline__ void p3_unpack_own(i32x4 &v) {
+    if (C16) v = i32x4{(int)(short)v.x, v.x >> 16, (int)(short)v.y, v.y >> 16};
+}
 
 // OWN_CUR / OWN_NXT: the lane's own values (exact int32, for the residuals) of this tile's two cells and, loaded here, of the next
 // tile's; the two register sets swap roles from tile to tile (IMG), so nothing is copied.
-template <int IMG, int ROLE, bool CHECK, bool WORDS>
+template <int IMG, int ROLE, bool CHECK, bool WORDS, bool C16 = false>
 __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane, P3Lds &lds, int it, bool more, uint32_t next2_tile, int tid, int lane, int wave, int slot_a,
                                         const P3Lane &L, float (&ga)[6], float (&gb)[6], const i32x4 (&own_cur)[2], i32x4 (&own_nxt)[2]) {
     uint32_t *s_hist = lds.hist;
@@ -652,10 +674,10 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
         for (int c = 0; c < 2; c++) {
             raw_own[c] = __builtin_amdgcn_readfirstlane(nxt_slots[slot_a + c]);
             const int cell = max(pred_slot_cell(raw_own[c]), 0);
-            own_nxt[c] = p3_load_own<ROLE>(plane + (size_t)cell * kCell, (uint32_t)lane);
+            own_nxt[c] = p3_load_own<ROLE, C16>(plane, (size_t)cell, (uint32_t)lane);
             if (ROLE == 1) st_own_mask[c] = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u]; // the level-8 waves have registers to spare
         }
-        p3_issue_halo(plane, nxt_slots, L.halo_ring, L.halo_heap, st_halo);
+        p3_issue_halo<C16>(plane, nxt_slots, L.halo_ring, L.halo_heap, st_halo);
     }
 
     // two block cells per wave; every cell issues the same number of stores (without a retained cell at the block slot they go to the
@@ -708,6 +730,7 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
         // The staged registers are consumed from here on, not earlier: left alone, the compiler hoists uses of the next tile's own
         // values to the top of the iteration and waits for the loads there - in front of the arithmetic they are meant to hide behind.
         asm volatile("" : "+v"(own_nxt[0]), "+v"(own_nxt[1]), "+v"(st_halo.v));
+        p3_unpack_own<C16>(own_nxt[0]), p3_unpack_own<C16>(own_nxt[1]);
         // The image the staging writes into is a compile-time constant per unrolled phase, so the nine write addresses of a lane (image + slot +
         // lane position) are loop invariants to the compiler: it hoists them out of the tile loop into registers the loop does not have - and
         // reloads the spilled ones from scratch memory behind an s_waitcnt vmcnt(0), i.e. behind the tile's stores. The image offset is made
@@ -730,7 +753,7 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
     trace_stamp(a.trace, blockIdx.x, 2 + it, tid);
 }
 
-template <int ROLE, bool CHECK, bool WORDS>
+template <int ROLE, bool CHECK, bool WORDS, bool C16 = false>
 __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, int lane, int wave, uint32_t &early_poll) {
     uint8_t *s_cells = lds.cells[0];
     int32_t *s_ring = &lds.ring[0][0];
@@ -789,13 +812,14 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
         for (int c = 0; c < 2; c++) {
             raw_own[c] = __builtin_amdgcn_readfirstlane(s_ring[slot_a + c]);
             const int cell = max(pred_slot_cell(raw_own[c]), 0);
-            own_a[c] = p3_load_own<ROLE>(plane + (size_t)cell * kCell, (uint32_t)lane);
+            own_a[c] = p3_load_own<ROLE, C16>(plane, (size_t)cell, (uint32_t)lane);
             if (ROLE == 1) st_own_mask[c] = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u];
         }
         P3Halo st_halo;
-        p3_issue_halo(plane, s_ring, L.halo_ring, L.halo_heap, st_halo);
+        p3_issue_halo<C16>(plane, s_ring, L.halo_ring, L.halo_heap, st_halo);
         P3LfValues lf_values;
-        if (ROLE == 1) p3_lf_hop_b(a, plane, lf_item, lf_values); // behind the staging loads: one round trip for both
+        if (ROLE == 1) p3_lf_hop_b<C16>(a, plane, lf_item, lf_values); // behind the staging loads: one round trip for both
+        p3_unpack_own<C16>(own_a[0]), p3_unpack_own<C16>(own_a[1]);
         float m = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -812,7 +836,7 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
             P3LfItem it;
             P3LfValues x;
             p3_lf_hop_a(a, walk.first + k * walk.step, k < my_tiles, lf_tid, it);
-            p3_lf_hop_b(a, plane, it, x);
+            p3_lf_hop_b<C16>(a, plane, it, x);
             if (!(ablate_flags(a.ablate) & 1)) p3_lf_finish<WORDS>(a, lds.hist, it, x);
         }
     }
@@ -824,10 +848,10 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
 
     int it = 0;
     for (uint32_t tile = walk.first; tile < walk.end;) { // unrolled by two: the LDS image a tile lives in is a compile-time constant
-        p3_tile<0, ROLE, CHECK, WORDS>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_a, own_b);
+        p3_tile<0, ROLE, CHECK, WORDS, C16>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_a, own_b);
         tile += walk.step, it++;
         if (tile >= walk.end) break;
-        p3_tile<1, ROLE, CHECK, WORDS>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_b, own_a);
+        p3_tile<1, ROLE, CHECK, WORDS, C16>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_b, own_a);
         tile += walk.step, it++;
     }
 }
@@ -860,9 +884,10 @@ __device__ __forceinline__ PredArgs pred_plane_view(const PredArgs &a0, uint32_t
 // <= 255 by construction and the staging does not look (18 max operations per lane and tile). CHECK = true: any int32 array; a value the LDS image
 // cannot hold raises the plane's `inexact` flag (see PredArgs::trusted for what happens then).
 // WORDS: see p3_half (instantiated for the library's own coefficients only).
-template <bool CHECK, bool WORDS>
+template <bool CHECK, bool WORDS, bool C16 = false>
 __global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const PredArgs a0) {
-    const PredArgs a = pred_plane_view(a0, blockIdx.y);
+    PredArgs a = pred_plane_view(a0, blockIdx.y);
+    if (C16) a.coefs = reinterpret_cast<const int32_t *>(reinterpret_cast<const int16_t *>(a0.coefs) + blockIdx.y * a0.coef_stride); // (a compact plane: halfwords)
     __shared__ __attribute__((aligned(16))) P3Lds lds;
     uint32_t *s_hist = lds.hist;
     uint8_t *s_cells = lds.cells[0];
@@ -878,9 +903,9 @@ __global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const Pr
         reinterpret_cast<uint32_t *>(s_cells + (i / ((kP3ImageBytes - kP3ZeroOff) / 4)) * kP3ImageBytes + kP3ZeroOff)[i % ((kP3ImageBytes - kP3ZeroOff) / 4)] = 0;
     uint32_t early_poll = 0;
     if (wave & 1)
-        p3_run<1, CHECK, WORDS>(a, lds, tid, lane, wave, early_poll);
+        p3_run<1, CHECK, WORDS, C16>(a, lds, tid, lane, wave, early_poll);
     else
-        p3_run<0, CHECK, WORDS>(a, lds, tid, lane, wave, early_poll);
+        p3_run<0, CHECK, WORDS, C16>(a, lds, tid, lane, wave, early_poll);
     lds_barrier(); // the table is complete; nobody waits here for the last tile's output stores
     trace_stamp(a.trace, blockIdx.x, 13, tid);
     pred_hand_over<CHECK>(a, s_hist, reinterpret_cast<uint32_t *>(s_ring), tid, kP3Threads, early_poll);
@@ -969,7 +994,8 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, uint32_t
     a.acc = acc;
     a.serial = serial;
     for (int k = 0; k < 8; k++) a.lf_delta[k] = p.lf_delta[k];
-    a.coefs = b.coefs;
+    if (b.coefs16 && !(b.words && trust == kPredForwardOutput)) return hipErrorInvalidValue; // compact planes: inside the symbol-stream chains only
+    a.coefs = b.coefs16 ? reinterpret_cast<const int32_t *>(b.coefs16) : b.coefs;
     a.coef_stride = b.coef_stride;
     a.out_stride = b.out_stride;
     a.params = b.params;
@@ -1004,7 +1030,9 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, uint32_t
     a.halo_list = p.halo_list;
     a.ablate = p.k2_ablate;
     (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
-    if (b.words)
+    if (b.words && b.coefs16)
+        hipLaunchKernelGGL((predict_histogram_kernel3<false, true, true>), dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
+    else if (b.words)
         hipLaunchKernelGGL((predict_histogram_kernel3<false, true>), dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
     else if (trust == kPredForwardOutput)
         hipLaunchKernelGGL((predict_histogram_kernel3<false, false>), dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);

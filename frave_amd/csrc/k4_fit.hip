@@ -201,13 +201,20 @@ __device__ __forceinline__ int fit2_block_slot(int wave, int i) {
     const int c = 2 * wave + i;
     return (1 + c / kPredBlock) * kPredSide + 1 + (c % kPredBlock);
 }
+// C16 (round 5): `coefs` is a chain's compact plane - int16, None as 0 (k1_forward.hip, store_item) - and a lane's eight values are ONE 16-byte load whose four dwords
+// are already the pairs the value pass stages (r.lo; r.hi unused).
+template <bool C16 = false>
 __device__ __forceinline__ void fit2_block_load(Fit2Block &r, const int32_t *__restrict__ coefs, const int32_t *s_slot_cell, int slot, int lane, bool skip) {
     r.lo = make_int4(0, 0, 0, 0), r.hi = r.lo;
     const int cell = skip ? -1 : s_slot_cell[slot];
     if (cell >= 0) {
-        const int4 *src = reinterpret_cast<const int4 *>(coefs + (size_t)cell * kCell + 8 * lane);
-        r.lo = src[0];
-        r.hi = src[1];
+        if (C16) {
+            r.lo = *reinterpret_cast<const int4 *>(reinterpret_cast<const int16_t *>(coefs) + (size_t)cell * kCell + 8 * lane);
+        } else {
+            const int4 *src = reinterpret_cast<const int4 *>(coefs + (size_t)cell * kCell + 8 * lane);
+            r.lo = src[0];
+            r.hi = src[1];
+        }
     }
 }
 // FLOATS = false (value pass): a staged halfword is the value's int16 (the packed operands of v_dot2c_i32_i16). FLOATS = true (width pass): the upper half of
@@ -217,9 +224,19 @@ __device__ __forceinline__ uint32_t fit2_pack(int first, int second) {
     if (!FLOATS) return __builtin_amdgcn_perm((uint32_t)second, (uint32_t)first, 0x05040100u);
     return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, (float)(short)second), __builtin_bit_cast(uint32_t, (float)(short)first), 0x07060302u);
 }
-template <bool CHECK, bool FLOATS>
+template <bool CHECK, bool FLOATS, bool C16 = false>
 __device__ __forceinline__ void fit2_block_commit(const Fit2Block &r, const int32_t *s_slot_cell, uint8_t *image, int slot, int lane, uint32_t stage_pos, uint32_t *range_counter) {
     auto pk = [](int lo16, int hi16) -> uint32_t { return fit2_pack<FLOATS>(lo16, hi16); };
+    if (C16) { // a dword of the compact plane = two int16: the value pass stages it as it is, the width pass as two float halves (fit2_pack reads an operand's low half)
+        static_assert(!(C16 && CHECK), "compact planes come from this library's forward kernel: nothing to check");
+        auto pair = [&](int d) -> uint32_t { return FLOATS ? fit2_pack<true>(d, d >> 16) : (uint32_t)d; };
+        uint8_t *dst = image + slot * kFit2Slot;
+        *reinterpret_cast<uint32_t *>(dst + 4u * (stage_pos & 255u)) = pair(r.lo.x) & (lane == 0 ? 0xFFFF0000u : 0xFFFFFFFFu); // heap node 0: the cell's zero (see kFit2Slot)
+        *reinterpret_cast<uint32_t *>(dst + 4u * ((stage_pos >> 8) & 255u)) = pair(r.lo.y);
+        *reinterpret_cast<uint32_t *>(dst + 4u * ((stage_pos >> 16) & 255u)) = pair(r.lo.z);
+        *reinterpret_cast<uint32_t *>(dst + 4u * (stage_pos >> 24)) = pair(r.lo.w);
+        return;
+    }
     const int4 lo = r.lo, hi = r.hi;
     if (CHECK && s_slot_cell[slot] >= 0) { // a None is 0x80000000: its low half stages as 0, and it is not an outlier
         const int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -235,8 +252,10 @@ __device__ __forceinline__ void fit2_block_commit(const Fit2Block &r, const int3
     *reinterpret_cast<uint32_t *>(dst + 4u * (stage_pos >> 24)) = pk(hi.z, hi.w);
 }
 // one halo value: entry = slot | heap << 8 | byte position inside the cell << 20 (build_halo_list; threads without an entry stage into the unused corner slot 0)
+template <bool C16 = false>
 __device__ __forceinline__ int fit2_halo_load(const int32_t *__restrict__ coefs, const int32_t *s_slot_cell, uint32_t entry, bool skip) {
     const int cell = skip ? -1 : s_slot_cell[entry & 63u];
+    if (C16) return cell >= 0 ? (int)reinterpret_cast<const int16_t *>(coefs)[(size_t)cell * kCell + ((entry >> 8) & 511u)] : 0;
     return cell >= 0 ? coefs[(size_t)cell * kCell + ((entry >> 8) & 511u)] : 0;
 }
 template <bool FLOATS>
@@ -356,11 +375,11 @@ __device__ __attribute__((noinline)) void fit2_tail_solve(const long long *sums_
 
 // CHECK = false: the coefficients were written by this library's forward kernel earlier in the same call (kPredForwardOutput): every magnitude is <= 255 by
 // construction, the staging does not look (40 of a block cell's ~75 vector instructions) and the out-of-range count stays 0.
-template <int MODE, bool CHECK>
+template <int MODE, bool CHECK, bool C16 = false>
 __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const FitArgs a0) {
     constexpr int NI = MODE == 0 ? 28 : 21;
     const uint32_t plane = blockIdx.y;
-    const int32_t *const coefs = a0.coefs + plane * a0.coef_stride;
+    const int32_t *const coefs = C16 ? reinterpret_cast<const int32_t *>(reinterpret_cast<const int16_t *>(a0.coefs) + plane * a0.coef_stride) : a0.coefs + plane * a0.coef_stride;
     unsigned long long *const accp = a0.acc + (size_t)plane * kFitShards * kFitAccWords;           // copy 0: ticket, out-of-range count
     unsigned long long *const accs = accp + (size_t)(blockIdx.x % kFitShards) * kFitAccWords;       // this workgroup's copy of the sums
     PredictParams pp; // static indices only: a dynamic index into the argument struct would keep all of it in scratch memory
@@ -490,19 +509,19 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         const uint32_t interior_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot_bits[IMG][1]) >> slot0;                              \
         {                                                                                                                                        \
             Fit2Block st;                                                                                                                        \
-            fit2_block_load(st, coefs, s_slot_cell[IMG ^ 1], block_a, lane, ablate & 2);                                                         \
-            const int hv = fit2_halo_load(coefs, s_slot_cell[IMG ^ 1], halo_e0, ablate & 2);                                                     \
+            fit2_block_load<C16>(st, coefs, s_slot_cell[IMG ^ 1], block_a, lane, ablate & 2);                                                         \
+            const int hv = fit2_halo_load<C16>(coefs, s_slot_cell[IMG ^ 1], halo_e0, ablate & 2);                                                     \
             if (tid < kPredSlots && tile + 2 * walk.step < walk.end) next_raw = slot_entry(tile + 2 * walk.step);                                 \
             if (!(ablate & 1)) fit2_cells<MODE, IMG, 0>(s_slot_cell[IMG], has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
-            fit2_block_commit<CHECK, MODE == 1>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_a, lane, stage_pos, &s_range);                              \
+            fit2_block_commit<CHECK, MODE == 1, C16>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_a, lane, stage_pos, &s_range);                              \
             fit2_halo_commit<MODE == 1>(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e0);                                                                     \
         }                                                                                                                                        \
         {                                                                                                                                        \
             Fit2Block st;                                                                                                                        \
-            fit2_block_load(st, coefs, s_slot_cell[IMG ^ 1], block_b, lane, ablate & 2);                                                         \
-            const int hv = fit2_halo_load(coefs, s_slot_cell[IMG ^ 1], halo_e1, ablate & 2);                                                     \
+            fit2_block_load<C16>(st, coefs, s_slot_cell[IMG ^ 1], block_b, lane, ablate & 2);                                                         \
+            const int hv = fit2_halo_load<C16>(coefs, s_slot_cell[IMG ^ 1], halo_e1, ablate & 2);                                                     \
             if (!(ablate & 1)) fit2_cells<MODE, IMG, 4>(s_slot_cell[IMG], has_bits, interior_bits, mask_word, mask_shift, keep, slot0, addr, own_addr, vp, acc, facc); \
-            fit2_block_commit<CHECK, MODE == 1>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_b, lane, stage_pos, &s_range);                              \
+            fit2_block_commit<CHECK, MODE == 1, C16>(st, s_slot_cell[IMG ^ 1], s_cells + (IMG ^ 1) * kFit2Image, block_b, lane, stage_pos, &s_range);                              \
             fit2_halo_commit<MODE == 1>(hv, s_cells + (IMG ^ 1) * kFit2Image, halo_e1);                                                                     \
         }                                                                                                                                        \
         if (MODE == 1) {                                                                                                                         \
@@ -521,11 +540,11 @@ __global__ void __launch_bounds__(kPredThreads, 4) fit_accumulate_kernel2(const 
         __syncthreads();
         {
             Fit2Block sa, sb;
-            fit2_block_load(sa, coefs, s_slot_cell[0], block_a, lane, false);
-            fit2_block_load(sb, coefs, s_slot_cell[0], block_b, lane, false);
-            const int h0 = fit2_halo_load(coefs, s_slot_cell[0], halo_e0, false), h1 = fit2_halo_load(coefs, s_slot_cell[0], halo_e1, false);
-            fit2_block_commit<CHECK, MODE == 1>(sa, s_slot_cell[0], s_cells, block_a, lane, stage_pos, &s_range);
-            fit2_block_commit<CHECK, MODE == 1>(sb, s_slot_cell[0], s_cells, block_b, lane, stage_pos, &s_range);
+            fit2_block_load<C16>(sa, coefs, s_slot_cell[0], block_a, lane, false);
+            fit2_block_load<C16>(sb, coefs, s_slot_cell[0], block_b, lane, false);
+            const int h0 = fit2_halo_load<C16>(coefs, s_slot_cell[0], halo_e0, false), h1 = fit2_halo_load<C16>(coefs, s_slot_cell[0], halo_e1, false);
+            fit2_block_commit<CHECK, MODE == 1, C16>(sa, s_slot_cell[0], s_cells, block_a, lane, stage_pos, &s_range);
+            fit2_block_commit<CHECK, MODE == 1, C16>(sb, s_slot_cell[0], s_cells, block_b, lane, stage_pos, &s_range);
             fit2_halo_commit<MODE == 1>(h0, s_cells, halo_e0);
             fit2_halo_commit<MODE == 1>(h1, s_cells, halo_e1);
         }
@@ -684,7 +703,8 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
                                  unsigned long long *out_of_range, hipStream_t stream, const FitSolve *solve, int trust) {
     if (!acc || !b.n_planes || b.n_planes > 65535u) return hipErrorInvalidValue;
     FitArgs a{};
-    a.coefs = b.coefs;
+    if (b.coefs16 && trust != kPredForwardOutput) return hipErrorInvalidValue; // compact planes exist inside this library's chains only
+    a.coefs = b.coefs16 ? reinterpret_cast<const int32_t *>(b.coefs16) : b.coefs;
     a.coef_stride = b.coef_stride;
     a.params = b.params;
     for (int k = 0; k < 3; k++) a.pp3[k] = b.pp[k];
@@ -720,6 +740,7 @@ hipError_t launch_fit_accumulate(const DevicePlan &p, unsigned long long *acc, i
     (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
     const bool check = trust != kPredForwardOutput;
     void (*kern)(const FitArgs) = mode == 0 ? (check ? fit_accumulate_kernel2<0, true> : fit_accumulate_kernel2<0, false>) : (check ? fit_accumulate_kernel2<1, true> : fit_accumulate_kernel2<1, false>);
+    if (b.coefs16) kern = mode == 0 ? fit_accumulate_kernel2<0, false, true> : fit_accumulate_kernel2<1, false, true>;
     hipLaunchKernelGGL(kern, dim3(blocks, b.n_planes), dim3(kPredThreads), 0, stream, a);
     return hipGetLastError();
 }

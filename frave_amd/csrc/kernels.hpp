@@ -85,7 +85,8 @@ struct PredictParams {
 // K1: address-map gather + 9-level residue transform + per-layer quantisation.
 // cached_stores: plain coefficient stores (the next kernel of a chain reads them straight away) instead of nontemporal ones (the default: written once, read later or never)
 hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, const uint8_t *pixels, size_t pixel_stride, int32_t *coefs,
-                                      size_t coef_stride, const QMatrix &q, hipStream_t stream, bool cached_stores = false);
+                                      size_t coef_stride, const QMatrix &q, hipStream_t stream, bool cached_stores = false,
+                                      int16_t *coefs16 = nullptr /* the chains' compact planes instead of `coefs`: int16, None as 0, coef_stride in halfwords */);
 // K2: neighbour gather + bucket/prediction + LDS histogram, then the partial-histogram reduction.
 // acc_slot < kPredAccRing selects the plan accumulator the launch hands its sums over through (one per stream, fri_hip.cpp).
 // The planes (image x channel) one K2 / K4 launch works on: plane k reads coefs + k * coef_stride (int32 elements) and writes its
@@ -93,6 +94,7 @@ hipError_t launch_fwd_transform_quant(const DevicePlan &p, uint32_t n_images, co
 struct PredBatch {
     uint32_t n_planes = 1;
     const int32_t *coefs = nullptr;
+    const int16_t *coefs16 = nullptr; // instead of coefs: a chain's compact planes (int16, None as 0; launch_fwd_transform_quant wrote them), coef_stride in halfwords; kPredForwardOutput only
     size_t coef_stride = 0, out_stride = 0;
     const PredictParams *params = nullptr;
     PredictParams pp[3] = {}; // used when params is NULL: plane k takes pp[min(k, 2)] (one image's channels travel as kernel arguments)

@@ -314,7 +314,13 @@ int fri_hip_symbol_stream_batch_dev(fri_hip_plan *plan, uint32_t n_planes, const
  * n_out_of_alphabet != 0 and must not be emitted), and neither bucket nor prediction arrays: 2 bytes per node of stores instead of 5, and the gather
  * reads 2 bytes per symbol instead of 9. d_symbols[k][C][num_some] as in fri_hip_symbol_stream_batch_dev (image k at k * symbol_stride halfwords, a
  * channel's stream directly behind the previous channel's). With channels == 3 and n_images > 1 the images must lie back to back (coef_stride ==
- * word_stride == 3 * F * 512, symbol_stride == 3 * num_some). Other arguments as in fri_hip_encode_image_batch_dev. Needs fri_hip_plan_set_stream_order. */
+ * word_stride == 3 * F * 512, symbol_stride == 3 * num_some). Other arguments as in fri_hip_encode_image_batch_dev. Needs fri_hip_plan_set_stream_order.
+ * d_coefs == NULL (round 5): the caller does not want the coefficients - the emitter needs the streams, the histograms and the parameters only. They then travel
+ * between the kernels as int16 planes the plan owns (every coefficient of the transform fits nine bits; None as 0, which is what the fit and the scan read a None
+ * neighbour as): the forward kernel writes half the bytes, the fit and the scan read half - 4096 x 4096: 99 -> 90 us with given parameters, 166 -> 154 us with the
+ * fit - and everything that comes back is the same bits (tests/test_gpu_compact.py). coef_stride is ignored then. The planes are sized by the largest call so far (a
+ * growing call allocates, i.e. waits for the device) and shared by the plan's calls: calls with d_coefs == NULL on one plan must be ordered by ONE stream (or by the
+ * caller's events), like every other use of a plan from one thread at a time. fri_hip_encode_image_symbols always works this way. */
 int fri_hip_encode_symbols_batch_dev(fri_hip_plan *plan, uint32_t n_images, const uint8_t *d_pixels, size_t pixel_stride, const int32_t qmatrix[32], int fit, float *d_params,
                                      int32_t *d_coefs, size_t coef_stride, uint16_t *d_node_words, size_t word_stride, uint16_t *d_symbols, size_t symbol_stride,
                                      uint32_t *d_hist, uint64_t *d_n_out_of_alphabet, uint64_t *d_fit_out_of_range, void *stream);
