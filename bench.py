@@ -400,7 +400,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": measured_traffic(tiling=(tuning or {}).get("winner") or "interleaved/band16/cells8"),
-            "kernel": "fwd_transform_quant_kernel<1,false,true,4,true,true,false>",
+            "kernel": "fwd_transform_quant_kernel<1,false,true,4,true,true,false,false>",
             "kernel_us": round(kernel_us, 3),
             "algorithmic_bytes_per_launch": alg_bytes,
         },

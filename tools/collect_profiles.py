@@ -43,7 +43,7 @@ if "== K1 batch form" in full:
     bval = lambda name: float(re.search(name + r"\s+n=\s*\d+\s+mean=\s*([0-9.]+)", bt).group(1))
     bf, bw = bval("FETCH_SIZE") / 24, bval("WRITE_SIZE") / 24
     json.dump({
-        "kernel": "fwd_transform_quant_kernel<1,false,true,4,true,true,false>, grid.y = 24", "workload": "ONE launch over 24 distinct 4096x4096x1 images (fri_hip_transform_quant_batch_dev), per image",
+        "kernel": "fwd_transform_quant_kernel<1,false,true,4,true,true,false,false>, grid.y = 24", "workload": "ONE launch over 24 distinct 4096x4096x1 images (fri_hip_transform_quant_batch_dev), per image",
         "tiling": tiling, "bytes_convention": "counter KiB x 1024", "source": f"profiles/{rnd}_k1_pmc_summary.txt", "fetch_size_kb_raw_per_image": round(bf, 1), "write_size_kb_per_image": round(bw, 1),
         "correction": "FETCH_SIZE x2 (gfx950 reports half the bytes of 16 B/lane coalesced reads, MI355X_MICROARCH.md section HBM); WRITE_SIZE exact for 16 B/lane stores",
         "hbm_bytes_per_launch": int(round((2 * bf + bw) * 1024)), "note": "hbm_bytes_per_launch is per IMAGE here (the key name is the one bench.py reads)",
@@ -52,7 +52,7 @@ txt = full.split("== K1 batch form")[0].split("== K1 RGB")[0]
 val = lambda name: float(re.search(name + r"\s+n=\s*\d+\s+mean=\s*([0-9.]+)", txt).group(1))
 fetch, write = val("FETCH_SIZE"), val("WRITE_SIZE")
 out = {
-    "kernel": "fwd_transform_quant_kernel<1,false,true,4,true,true,false>",
+    "kernel": "fwd_transform_quant_kernel<1,false,true,4,true,true,false,false>",
     "workload": "4096x4096x1, single-image launches rotating over 32 slots (every byte from / to HBM)",
     "tiling": tiling,
     "bytes_convention": "counter KiB x 1024",
