@@ -110,6 +110,9 @@ struct fri_hip_plan {
     // caller does not ask for the coefficients (fri_hip_encode_image_symbols; fri_hip_encode_symbols_batch_dev with d_coefs == NULL). Half the bytes written and read three times.
     int16_t *d_coefs16 = nullptr;
     size_t coefs16_planes = 0;
+    hipEvent_t ev_coefs16 = nullptr;    // behind the last chain that used them: a chain on ANOTHER stream waits for it before it overwrites the planes
+    hipStream_t coefs16_stream = nullptr;
+    bool coefs16_used = false;
     uint16_t *d_symbols = nullptr;      // fri_hip_encode_image_symbols: [C][geo.n_some]
     uint16_t *d_words = nullptr;        // ... and the scan's halfword planes [C][F][512] the stream is gathered from
     uint32_t acc_next = 0;
@@ -799,6 +802,7 @@ int fri_hip_plan_destroy(fri_hip_plan *p) {
             if (d) (void)hipFree(d);
         if (p->d_stream_order) (void)hipFree(p->d_stream_order);
         if (p->d_coefs16) (void)hipFree(p->d_coefs16);
+        if (p->ev_coefs16) (void)hipEventDestroy(p->ev_coefs16);
         if (p->d_symbols) (void)hipFree(p->d_symbols);
         if (p->d_words) (void)hipFree(p->d_words);
         if (p->h_fit) (void)hipHostFree(p->h_fit);
@@ -1219,6 +1223,17 @@ static int ensure_coefs16(fri_hip_plan *p, size_t planes) {
     p->coefs16_planes = planes;
     return FRI_HIP_OK;
 }
+// The planes belong to one chain at a time. Chains on one stream are ordered by it; a chain on another stream first waits for the event the previous one left.
+static int coefs16_begin(fri_hip_plan *p, hipStream_t s) {
+    if (p->coefs16_used && p->coefs16_stream != s && p->ev_coefs16) HIP_TRY(p->ctx, hipStreamWaitEvent(s, p->ev_coefs16, 0));
+    return FRI_HIP_OK;
+}
+static int coefs16_end(fri_hip_plan *p, hipStream_t s) {
+    if (!p->ev_coefs16) HIP_TRY(p->ctx, hipEventCreateWithFlags(&p->ev_coefs16, hipEventDisableTiming));
+    HIP_TRY(p->ctx, hipEventRecord(p->ev_coefs16, s));
+    p->coefs16_stream = s, p->coefs16_used = true;
+    return FRI_HIP_OK;
+}
 static int ensure_encode_staging(fri_hip_plan *p, bool node_arrays = true) {
     fri_hip_ctx *c = p->ctx;
     const size_t C = p->geo.channels, plane = p->geo.centers.size() * kCell;
@@ -1374,8 +1389,10 @@ int fri_hip_encode_symbols_batch_dev(fri_hip_plan *p, uint32_t n_images, const u
     if (int rc = check_q(qmatrix, q)) return rc;
     HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    if (compact)
+    if (compact) {
         if (int rc = ensure_coefs16(p, (size_t)n_images * C)) return rc;
+        if (int rc = coefs16_begin(p, s)) return rc;
+    }
     HIP_TRY(p->ctx, launch_fwd_transform_quant(p->dev, n_images, d_pixels, pixel_stride, d_coefs, coef_stride, q, s, chain_wants_cached_coefficients(p, n_images, fit),
                                                compact ? p->d_coefs16 : nullptr));
     PredBatch b;
@@ -1390,6 +1407,8 @@ int fri_hip_encode_symbols_batch_dev(fri_hip_plan *p, uint32_t n_images, const u
         if (int rc = fit_chain(p, b, (unsigned long long *)d_fit_out_of_range, s, nullptr, nullptr, kPredForwardOutput)) return rc;
     if (int rc = predict_launch(p, b, nullptr, nullptr, d_hist, d_n_out_of_alphabet, kPredForwardOutput, s)) return rc;
     HIP_TRY(p->ctx, launch_symbol_gather(p->d_stream_order, n, b.n_planes, d_node_words, b.out_stride, d_symbols, C > 1 ? n : symbol_stride, s));
+    if (compact) // (the scan was the planes' last reader; the event sits behind the gather, which is later than it must be and costs nothing)
+        if (int rc = coefs16_end(p, s)) return rc;
     return FRI_HIP_OK;
 }
 
@@ -1611,12 +1630,14 @@ int fri_hip_encode_image_symbols(fri_hip_plan *p, const uint8_t *pixels, const i
     HIP_TRY(c, hipMemcpy(p->d_pixels, pixels, fri_hip_plan_pixel_bytes(p), hipMemcpyHostToDevice));
     // nobody outside sees the coefficients of this call: compact planes (int16, None as 0) between the forward kernel, the fit and the scan
     if (int rc = ensure_coefs16(p, C)) return rc;
+    if (int rc = coefs16_begin(p, nullptr)) return rc;
     HIP_TRY(c, launch_fwd_transform_quant(p->dev, 1, p->d_pixels, 0, nullptr, 0, q, nullptr, false, p->d_coefs16));
     // the scan in its halfword form (no bucket / prediction arrays are written at all), then the gather into stream order
     if (int rc = predict_image_dev(p, nullptr, fit, value_params, width_params, nullptr, nullptr, p->d_hist_all, (uint64_t *)p->d_oob_all, kPredForwardOutput, nullptr, p->d_words,
                                    p->d_coefs16))
         return rc;
     HIP_TRY(c, launch_symbol_gather(p->d_stream_order, n, (uint32_t)C, p->d_words, plane, p->d_symbols, n, nullptr));
+    if (int rc = coefs16_end(p, nullptr)) return rc;
     HIP_TRY(c, hipMemcpy(symbols, p->d_symbols, C * n * sizeof(uint16_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(hist, p->d_hist_all, C * 10 * 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(n_out_of_alphabet, p->d_oob_all, C * sizeof(uint64_t), hipMemcpyDeviceToHost));

@@ -85,3 +85,36 @@ def test_compact_planes_grow_with_the_batch(ctx):
         got = _run(P, torch, imgs, True, params, compact=True)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[3].view(np.uint32), ref[3].view(np.uint32))
     P.close()
+
+
+def test_compact_chains_on_two_streams_take_turns(ctx):
+    """The planes belong to one chain at a time: a chain on another stream waits for the previous one's event. Eight chains alternating over two streams without a host
+    synchronise in between, each with its own outputs, give what eight ordered chains give."""
+    import torch
+
+    import frave_amd as fa
+
+    w, h, c = 1000, 700, 1
+    P = fa.Plan(ctx, w, h, c)
+    P.set_stream_order()
+    plane, n = P.num_cells * 512, P.num_some
+    vp, wp = random_params(3)
+    params = np.stack([np.asarray(vp, np.float32).reshape(3, 6), np.asarray(wp, np.float32).reshape(3, 6)])
+    imgs = [gen_image("noise" if k % 2 else "smooth", w, h, c, 200 + k) for k in range(8)]
+    want = [_run(P, torch, [im], True, params, compact=False)[0] for im in imgs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bufs = []
+    for k, im in enumerate(imgs):
+        d_px = torch.from_numpy(im.reshape(-1).copy()).cuda()
+        bufs.append(dict(px=d_px, w=torch.empty(plane, dtype=torch.uint16, device="cuda"), st=torch.full((n + 8,), 0xFFFF, dtype=torch.uint16, device="cuda"),
+                         h=torch.empty((10, 1024), dtype=torch.int32, device="cuda"), o=torch.empty(1, dtype=torch.int64, device="cuda"), r=torch.empty(1, dtype=torch.int64, device="cuda"),
+                         par=torch.from_numpy(params.reshape(-1).copy()).cuda()))
+    torch.cuda.synchronize()
+    for k, b in enumerate(bufs):
+        s = streams[k % 2]
+        P.encode_symbols_batch_dev(1, b["px"].data_ptr(), P.pixel_bytes, None, True, b["par"].data_ptr(), 0, plane, b["w"].data_ptr(), plane, b["st"].data_ptr(), n,
+                                   b["h"].data_ptr(), b["o"].data_ptr(), b["r"].data_ptr(), stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    for k, b in enumerate(bufs):
+        assert np.array_equal(b["st"].cpu().numpy()[:n], want[k][0, 0]), k
+    P.close()
