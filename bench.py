@@ -218,6 +218,14 @@ def extras(plan, ctx, torch, np, d_px, d_co, slots, alg_bytes, stream, full=Fals
     d_par.copy_(torch.from_numpy(np.stack([vp, wp]).reshape(-1)))
     res["chain_to_symbol_stream_given_params_compact"] = entry(timed(lambda k: symrun(k, False, 0)), alg_bytes + k2w_bytes + k5_bytes)
     res["chain_to_symbol_stream_with_fit_compact"] = entry(timed(lambda k: symrun(k, True, 0)), alg_bytes + k2w_bytes + k5_bytes + 2 * k4_bytes)
+    # ... and with d_node_words = NULL as well: the scan writes every symbol to its place in the stream (a table of stream positions, the inverse of the order); no gather kernel
+    dirrun = lambda k, fit: plan.encode_symbols_batch_dev(1, px(k), pstride, None, fit, d_par.data_ptr(), 0, cstride, 0, plane, d_sym.data_ptr(), n_sym, d_h.data_ptr(), d_o.data_ptr(),
+                                                          d_rng.data_ptr(), stream=stream)
+    d_par.copy_(torch.from_numpy(np.stack([vp, wp]).reshape(-1)))
+    res["chain_to_symbol_stream_given_params_direct"] = entry(timed(lambda k: dirrun(k, False)), alg_bytes + k2w_bytes + k5_bytes)
+    res["chain_to_symbol_stream_with_fit_direct"] = entry(timed(lambda k: dirrun(k, True)), alg_bytes + k2w_bytes + k5_bytes + 2 * k4_bytes)
+    for key in ("chain_to_symbol_stream_given_params_direct", "chain_to_symbol_stream_with_fit_direct"):
+        res[key]["note"] = "d_coefs = d_node_words = NULL: int16 coefficient planes, the scan writes the stream itself (no node words, no gather kernel); same streams, histograms and parameters"
     for key in ("chain_to_symbol_stream_given_params_compact", "chain_to_symbol_stream_with_fit_compact"):
         res[key]["note"] = "d_coefs = NULL: int16 coefficient planes inside the chain (fri_hip_encode_symbols_batch_dev); same streams, histograms and parameters"
     del d_words, d_sym

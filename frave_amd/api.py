@@ -353,7 +353,8 @@ class Plan:
     def encode_symbols_batch_dev(self, n_images, d_pixels, pixel_stride, qmatrix, fit, d_params, d_coefs, coef_stride, d_node_words, word_stride, d_symbols, symbol_stride,
                                  d_hist, d_oob, d_fit_range=0, stream=0):
         """fri_hip_encode_symbols_batch_dev: forward -> [fit] -> scan (halfword form) -> gather into stream order; everything in device memory, asynchronous.
-        d_coefs = 0 / None: the coefficients stay inside the chain as the plan's compact int16 planes (same streams, histograms and parameters; faster)."""
+        d_coefs = 0 / None: the coefficients stay inside the chain as the plan's compact int16 planes (same streams, histograms and parameters; faster);
+        d_node_words = 0 / None as well: the scan writes the streams itself, no node words, no gather kernel (faster still)."""
         q = _q(qmatrix)
         _check(load_library().fri_hip_encode_symbols_batch_dev(self._h, n_images, d_pixels, pixel_stride, _p(q), 1 if fit else 0, d_params, d_coefs, coef_stride, d_node_words,
                                                                word_stride, d_symbols, symbol_stride, d_hist, d_oob, d_fit_range, stream), "fri_hip_encode_symbols_batch_dev", self.ctx)

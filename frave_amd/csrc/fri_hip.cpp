@@ -106,6 +106,7 @@ struct fri_hip_plan {
     hipEvent_t ev_fit = nullptr;
     bool assume_forward = false; // fri_hip_plan_assume_forward_coefficients
     uint32_t *d_stream_order = nullptr; // fri_hip_plan_set_stream_order: node index of the i-th symbol of a channel, [geo.n_some]
+    uint32_t *d_stream_pos = nullptr;   // ... and its inverse, [F][512]: the position of a node's symbol in a channel's stream (None nodes: ~0, never used) - the scan's STREAM form
     // The symbol-stream chains' compact coefficient planes (round 5): int16, None as 0, [planes][F][512] - between the forward kernel, the fit and the scan when the
     // caller does not ask for the coefficients (fri_hip_encode_image_symbols; fri_hip_encode_symbols_batch_dev with d_coefs == NULL). Half the bytes written and read three times.
     int16_t *d_coefs16 = nullptr;
@@ -801,6 +802,7 @@ int fri_hip_plan_destroy(fri_hip_plan *p) {
         for (void *d : {(void *)p->d_bucket_all, (void *)p->d_prediction_all, (void *)p->d_hist_all, (void *)p->d_oob_all})
             if (d) (void)hipFree(d);
         if (p->d_stream_order) (void)hipFree(p->d_stream_order);
+        if (p->d_stream_pos) (void)hipFree(p->d_stream_pos);
         if (p->d_coefs16) (void)hipFree(p->d_coefs16);
         if (p->ev_coefs16) (void)hipEventDestroy(p->ev_coefs16);
         if (p->d_symbols) (void)hipFree(p->d_symbols);
@@ -1273,7 +1275,8 @@ static int fit_chain(fri_hip_plan *p, const PredBatch &b, unsigned long long *d_
 // device-side fit above, then the parameters and the range counts come back through pinned memory behind an event the host waits for
 // while the scan kernel, already queued behind them, runs).
 static int predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, float *value_params, float *width_params, uint8_t *d_bucket, int32_t *d_prediction,
-                             uint32_t *d_hist, uint64_t *d_oob, int trust, hipStream_t s, uint16_t *d_words = nullptr, const int16_t *d_coefs16 = nullptr) {
+                             uint32_t *d_hist, uint64_t *d_oob, int trust, hipStream_t s, uint16_t *d_words = nullptr, const int16_t *d_coefs16 = nullptr,
+                             uint16_t *d_streams = nullptr) {
     fri_hip_ctx *c = p->ctx;
     const uint32_t C = p->geo.channels;
     const size_t plane = p->geo.centers.size() * kCell;
@@ -1284,6 +1287,7 @@ static int predict_image_dev(fri_hip_plan *p, const int32_t *d_coefs, int fit, f
     b.coef_stride = plane;
     b.out_stride = plane;
     b.words = d_words; // (the halfword form of the scan: see fri_hip_encode_image_symbols)
+    if (d_streams) b.words = d_streams, b.out_stride = p->geo.n_some, b.stream_pos = p->d_stream_pos; // (its stream form: the channels' streams one behind the other, written by the scan itself)
     if (!fit) {
         for (uint32_t ch = 0; ch < C; ch++) {
             std::memcpy(b.pp[ch].value, value_params + ch * 18, sizeof(b.pp[ch].value));
@@ -1378,10 +1382,13 @@ int fri_hip_encode_symbols_batch_dev(fri_hip_plan *p, uint32_t n_images, const u
     if (int rc = need_device(p)) return rc;
     const uint32_t C = p->geo.channels;
     const size_t plane = p->geo.centers.size() * kCell, image = (size_t)C * plane, n = p->geo.n_some;
-    if (!d_pixels || !d_params || !d_node_words || !d_symbols || !d_hist || !d_n_out_of_alphabet || !n_images || (uint64_t)n_images * C > 65535u || !p->d_stream_order)
+    if (!d_pixels || !d_params || !d_symbols || !d_hist || !d_n_out_of_alphabet || !n_images || (uint64_t)n_images * C > 65535u || !p->d_stream_order)
         return FRI_HIP_ERR_INVALID_ARGUMENT;
     const bool compact = d_coefs == nullptr; // the caller does not want the coefficients: they travel between the kernels as the plan's int16 planes
+    const bool direct = d_node_words == nullptr; // ... nor the node words: the scan writes every symbol straight to its place in the stream, no gather kernel
+    if (direct && !compact) return FRI_HIP_ERR_INVALID_ARGUMENT; // (the stream form of the scan exists for the compact planes only)
     if (compact) coef_stride = image;
+    if (direct) word_stride = image;
     if (n_images > 1 && (pixel_stride < fri_hip_plan_pixel_bytes(p) || coef_stride < image || word_stride < image || symbol_stride < (size_t)C * n)) return FRI_HIP_ERR_INVALID_ARGUMENT;
     // evenly spaced planes, as above; a channel's stream follows the previous channel's
     if (C > 1 && n_images > 1 && (coef_stride != image || word_stride != image || symbol_stride != (size_t)C * n)) return FRI_HIP_ERR_INVALID_ARGUMENT;
@@ -1403,10 +1410,11 @@ int fri_hip_encode_symbols_batch_dev(fri_hip_plan *p, uint32_t n_images, const u
     b.out_stride = C > 1 ? plane : word_stride;
     b.params = reinterpret_cast<const PredictParams *>(d_params);
     b.words = d_node_words;
+    if (direct) b.words = d_symbols, b.out_stride = C > 1 ? n : symbol_stride, b.stream_pos = p->d_stream_pos; // the planes' streams, one behind the other as the gather would lay them
     if (fit)
         if (int rc = fit_chain(p, b, (unsigned long long *)d_fit_out_of_range, s, nullptr, nullptr, kPredForwardOutput)) return rc;
     if (int rc = predict_launch(p, b, nullptr, nullptr, d_hist, d_n_out_of_alphabet, kPredForwardOutput, s)) return rc;
-    HIP_TRY(p->ctx, launch_symbol_gather(p->d_stream_order, n, b.n_planes, d_node_words, b.out_stride, d_symbols, C > 1 ? n : symbol_stride, s));
+    if (!direct) HIP_TRY(p->ctx, launch_symbol_gather(p->d_stream_order, n, b.n_planes, d_node_words, b.out_stride, d_symbols, C > 1 ? n : symbol_stride, s));
     if (compact) // (the scan was the planes' last reader; the event sits behind the gather, which is later than it must be and costs nothing)
         if (int rc = coefs16_end(p, s)) return rc;
     return FRI_HIP_OK;
@@ -1596,6 +1604,12 @@ int fri_hip_plan_set_stream_order(fri_hip_plan *p, const uint32_t *order, uint64
     HIP_TRY(c, hipSetDevice(c->device));
     if (!p->d_stream_order) HIP_TRY(c, hipMalloc((void **)&p->d_stream_order, (n ? n : 1) * sizeof(uint32_t)));
     HIP_TRY(c, hipMemcpy(p->d_stream_order, order, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    { // the inverse: where a node's symbol sits in the stream (the scan writes the stream directly when nobody asks for the node words)
+        std::vector<uint32_t> pos(F * kCell, 0xFFFFFFFFu);
+        for (uint64_t i = 0; i < n; i++) pos[order[i]] = (uint32_t)i;
+        if (!p->d_stream_pos) HIP_TRY(c, hipMalloc((void **)&p->d_stream_pos, pos.size() * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemcpy(p->d_stream_pos, pos.data(), pos.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     return FRI_HIP_OK;
 }
 
@@ -1622,9 +1636,8 @@ int fri_hip_encode_image_symbols(fri_hip_plan *p, const uint8_t *pixels, const i
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = ensure_staging(p)) return rc;
     if (int rc = ensure_encode_staging(p, false)) return rc;
-    const size_t C = p->geo.channels, plane = p->geo.centers.size() * kCell, n = p->geo.n_some;
+    const size_t C = p->geo.channels, n = p->geo.n_some;
     if (!p->d_symbols) HIP_TRY(c, hipMalloc((void **)&p->d_symbols, (C * n ? C * n : 1) * sizeof(uint16_t)));
-    if (!p->d_words) HIP_TRY(c, hipMalloc((void **)&p->d_words, C * plane * sizeof(uint16_t)));
     QMatrix q;
     if (int rc = check_q(qmatrix, q)) return rc;
     HIP_TRY(c, hipMemcpy(p->d_pixels, pixels, fri_hip_plan_pixel_bytes(p), hipMemcpyHostToDevice));
@@ -1632,11 +1645,10 @@ int fri_hip_encode_image_symbols(fri_hip_plan *p, const uint8_t *pixels, const i
     if (int rc = ensure_coefs16(p, C)) return rc;
     if (int rc = coefs16_begin(p, nullptr)) return rc;
     HIP_TRY(c, launch_fwd_transform_quant(p->dev, 1, p->d_pixels, 0, nullptr, 0, q, nullptr, false, p->d_coefs16));
-    // the scan in its halfword form (no bucket / prediction arrays are written at all), then the gather into stream order
-    if (int rc = predict_image_dev(p, nullptr, fit, value_params, width_params, nullptr, nullptr, p->d_hist_all, (uint64_t *)p->d_oob_all, kPredForwardOutput, nullptr, p->d_words,
-                                   p->d_coefs16))
+    // the scan in its stream form: no bucket / prediction arrays, no node words, no gather kernel - every symbol goes straight to its place in its channel's stream
+    if (int rc = predict_image_dev(p, nullptr, fit, value_params, width_params, nullptr, nullptr, p->d_hist_all, (uint64_t *)p->d_oob_all, kPredForwardOutput, nullptr, nullptr,
+                                   p->d_coefs16, p->d_symbols))
         return rc;
-    HIP_TRY(c, launch_symbol_gather(p->d_stream_order, n, (uint32_t)C, p->d_words, plane, p->d_symbols, n, nullptr));
     if (int rc = coefs16_end(p, nullptr)) return rc;
     HIP_TRY(c, hipMemcpy(symbols, p->d_symbols, C * n * sizeof(uint16_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(hist, p->d_hist_all, C * 10 * 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost));

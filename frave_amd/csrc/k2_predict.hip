@@ -70,6 +70,8 @@ struct PredArgs {
     uint32_t serial;           // this launch's number on this accumulator (never 0): what the clearing workgroups publish and everybody polls for
     uint32_t n_tiles;
     uint16_t *words;      // predict_histogram_kernel3<., true>: bucket << 10 | symbol per node, [n_planes] planes out_stride apart, INSTEAD of bucket / prediction
+    const uint32_t *stream_pos; // STREAM form (round 5): [F][512] position of every node in a channel's symbol stream (the inverse of the stream order; None nodes: unused) -
+                          // `words` is then the plane's STREAM (out_stride = distance of two planes' streams) and a node's halfword goes straight to its place in it
     int32_t trusted;      // the caller vouches for |coefficient| <= 256 (this library's forward kernel wrote them) and enqueues no exact kernel: a plane that
                           // raises `inexact` all the same reports n_oob = ~0 (an error the host maps to FRI_HIP_ERR_OUT_OF_RANGE) and lowers the flag itself
     PredictParams pp;     // this plane's parameters (filled per plane inside the kernel)
@@ -281,9 +283,12 @@ __device__ __forceinline__ int p3_node_of(int lane, int n) {
 // Role 1 leaves as one dwordx4 + one dword store, role 0 as two dwordx2 + two short stores.
 // WORDS: the cell leaves as one halfword per node, bucket << 10 | symbol - the counter index the node bumped, which is what the emitter codes
 // (k5_stream.hip takes it from there) - instead of 5 bytes of bucket and prediction: role 1 one dwordx2, role 0 two dword stores to `wd`.
-template <int IMG, int ROLE, int CELL, bool WORDS>
+// STREAM (with WORDS, round 5): wd is the plane's symbol stream and pos[j] the place of the lane's j-th node in it (PredArgs::stream_pos): the halfwords of the Some nodes
+// go there directly - four two-byte stores under the nodes' masks instead of one or two wide ones - and neither node-word plane nor gather kernel exist.
+template <int IMG, int ROLE, int CELL, bool WORDS, bool STREAM = false>
 __device__ __forceinline__ void p3_half(const uint32_t (&addr)[4][6], float (&ga)[6], float (&gb)[6], const int (&own)[4], const PredictParams &pp, bool interior, uint32_t some4,
-                                        int lane, uint32_t *s_hist, const uint16_t *s_bkt, uint8_t *bd, int32_t *pd, uint16_t *wd, uint8_t *junk, int ablate) {
+                                        int lane, uint32_t *s_hist, const uint16_t *s_bkt, uint8_t *bd, int32_t *pd, uint16_t *wd, uint8_t *junk, int ablate,
+                                        const uint32_t (&pos)[4] = {0, 0, 0, 0}, bool has = true) {
     constexpr int kOff = IMG * kP3ImageBytes + CELL * kP3SlotBytes;
     uint32_t b12[4], bin[4], sym[4];
     int pred[4];
@@ -328,6 +333,16 @@ __device__ __forceinline__ void p3_half(const uint32_t (&addr)[4][6], float (&ga
     // How the four nodes leave. Called at the end of BOTH branches below rather than behind their merge: the boundary branch changes predictions and
     // buckets, and behind a merge the common path paid six register copies per cell for that.
     auto leave = [&](const int (&pr)[4], const uint32_t (&bk)[4]) {
+        if (WORDS && STREAM) {
+            if (!has) return; // (a block slot without a retained cell: nothing belongs to the stream)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool lf = ROLE == 0 && j < 2 && lane == 0;                 // heap nodes 0 and 1: the LF pass writes them
+                const bool some = interior ? !lf : ((some4 >> j) & 1u) != 0;      // (the LF nodes' bits of some4 are already cleared)
+                if (some && !(ablate & 32)) wd[pos[j]] = (uint16_t)(bin[j] >> 2);  // bin = 4 x (bucket << 10 | symbol), out of alphabet: 4 x kHistBins
+            }
+            return;
+        }
         if (WORDS) {
             // bin = 4 x (bucket << 10 | symbol) (out of alphabet: 4 x kHistBins, "bucket 10" - no such symbol may be emitted, n_out_of_alphabet says so);
             // two nodes per dword: the low two bits of a bin are zero, so bin1 << 14 lands on bit 16
@@ -430,7 +445,7 @@ __device__ __forceinline__ void p3_lf_hop_b(const PredArgs &a, const int32_t *pl
     x.value = at(cell);
     x.mask0 = a.valid_mask[(size_t)cell * 16];
 }
-template <bool WORDS>
+template <bool WORDS, bool STREAM = false>
 __device__ __forceinline__ void p3_lf_finish(const PredArgs &a, uint32_t *s_hist, const P3LfItem &it, const P3LfValues &x) {
     const int cell = pred_slot_cell(it.raw);
     if (cell < 0) return;
@@ -444,6 +459,10 @@ __device__ __forceinline__ void p3_lf_finish(const PredArgs &a, uint32_t *s_hist
     const uint32_t sym = pack_signed(sub_w(x.value, prediction));
     const uint32_t counter = sym < 1024u ? (b12 >> 2) + sym : (uint32_t)kHistBins;
     if (some) atomicAdd(&s_hist[counter], 1u);
+    if (WORDS && STREAM) {
+        if (some) a.words[a.stream_pos[(size_t)cell * kCell + it.node]] = (uint16_t)counter;
+        return;
+    }
     if (WORDS) {
         a.words[(size_t)cell * kCell + it.node] = (uint16_t)counter;
         return;
@@ -653,12 +672,22 @@ template <bool C16>
 __device__ __forceinline__ void p3_unpack_own(i32x4 &v) {
     if (C16) v = i32x4{(int)(short)v.x, v.x >> 16, (int)(short)v.y, v.y >> 16};
 }
+// the stream positions of the lane's four nodes of a cell (PredArgs::stream_pos), laid out like its own values
+template <int ROLE>
+__device__ __forceinline__ u32x4 p3_load_pos(const uint32_t *stream_pos, size_t cell, uint32_t lane) {
+    const uint32_t *base = stream_pos + cell * kCell;
+    if (ROLE) return reinterpret_cast<const u32x4 *>(base + 256)[lane];
+    const i32x2 a = reinterpret_cast<const i32x2 *>(base)[lane], b = reinterpret_cast<const i32x2 *>(base + 128)[lane];
+    return u32x4{(uint32_t)a.x, (uint32_t)a.y, (uint32_t)b.x, (uint32_t)b.y};
+}
 
 // OWN_CUR / OWN_NXT: the lane's own values (exact int32, for the residuals) of this tile's two cells and, loaded here, of the next
 // tile's; the two register sets swap roles from tile to tile (IMG), so nothing is copied.
-template <int IMG, int ROLE, bool CHECK, bool WORDS, bool C16 = false>
+// STREAM: pos_cur / pos_nxt - the stream positions of the lane's nodes in this tile's two cells and, loaded here next to the own values, in the next tile's.
+template <int IMG, int ROLE, bool CHECK, bool WORDS, bool C16 = false, bool STREAM = false>
 __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane, P3Lds &lds, int it, bool more, uint32_t next2_tile, int tid, int lane, int wave, int slot_a,
-                                        const P3Lane &L, float (&ga)[6], float (&gb)[6], const i32x4 (&own_cur)[2], i32x4 (&own_nxt)[2]) {
+                                        const P3Lane &L, float (&ga)[6], float (&gb)[6], const i32x4 (&own_cur)[2], i32x4 (&own_nxt)[2], const u32x4 (&pos_cur)[2],
+                                        u32x4 (&pos_nxt)[2]) {
     uint32_t *s_hist = lds.hist;
     const uint16_t *s_bkt = lds.bkt;
     const int32_t *cur_slots = lds.ring[it % 3], *nxt_slots = lds.ring[(it + 1) % 3];
@@ -675,6 +704,7 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
             raw_own[c] = __builtin_amdgcn_readfirstlane(nxt_slots[slot_a + c]);
             const int cell = max(pred_slot_cell(raw_own[c]), 0);
             own_nxt[c] = p3_load_own<ROLE, C16>(plane, (size_t)cell, (uint32_t)lane);
+            if (STREAM) pos_nxt[c] = p3_load_pos<ROLE>(a.stream_pos, (size_t)cell, (uint32_t)lane);
             if (ROLE == 1) st_own_mask[c] = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u]; // the level-8 waves have registers to spare
         }
         p3_issue_halo<C16>(plane, nxt_slots, L.halo_ring, L.halo_heap, st_halo);
@@ -690,7 +720,8 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
         const size_t junk = ((size_t)blockIdx.x * kP3Waves + wave) * kPredJunkBytes;
         uint8_t *bd = has && a.bucket ? a.bucket + (size_t)cell * kCell : a.junk + junk;
         int32_t *pd = has && a.prediction ? a.prediction + (size_t)cell * kCell : reinterpret_cast<int32_t *>(a.junk + junk + 512);
-        uint16_t *wd = WORDS && has ? a.words + (size_t)cell * kCell : reinterpret_cast<uint16_t *>(a.junk + junk + 512);
+        uint16_t *wd = WORDS && STREAM ? a.words : WORDS && has ? a.words + (size_t)cell * kCell : reinterpret_cast<uint16_t *>(a.junk + junk + 512);
+        const uint32_t pos4[4] = {pos_cur[c].x, pos_cur[c].y, pos_cur[c].z, pos_cur[c].w};
         uint32_t some4 = 0;
         if (!interior && has) { // boundary cell: node p is bit (p & 31) of mask word p >> 5
             const uint32_t *m = lds.masks[IMG][slot_a + c];
@@ -720,9 +751,9 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
                 __builtin_nontemporal_store((uint16_t)0, reinterpret_cast<uint16_t *>(bd + 128) + lane);
             }
         } else if (c == 0) {
-            p3_half<IMG, ROLE, 0, WORDS>(L.addr, ga, gb, own4, a.pp, interior, some4, lane, s_hist, s_bkt, bd, pd, wd, a.junk + junk, ablate_flags(a.ablate));
+            p3_half<IMG, ROLE, 0, WORDS, STREAM>(L.addr, ga, gb, own4, a.pp, interior, some4, lane, s_hist, s_bkt, bd, pd, wd, a.junk + junk, ablate_flags(a.ablate), pos4, has);
         } else {
-            p3_half<IMG, ROLE, 1, WORDS>(L.addr, ga, gb, own4, a.pp, interior, some4, lane, s_hist, s_bkt, bd, pd, wd, a.junk + junk, ablate_flags(a.ablate));
+            p3_half<IMG, ROLE, 1, WORDS, STREAM>(L.addr, ga, gb, own4, a.pp, interior, some4, lane, s_hist, s_bkt, bd, pd, wd, a.junk + junk, ablate_flags(a.ablate), pos4, has);
         }
     }
 
@@ -730,6 +761,7 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
         // The staged registers are consumed from here on, not earlier: left alone, the compiler hoists uses of the next tile's own
         // values to the top of the iteration and waits for the loads there - in front of the arithmetic they are meant to hide behind.
         asm volatile("" : "+v"(own_nxt[0]), "+v"(own_nxt[1]), "+v"(st_halo.v));
+        if (STREAM) asm volatile("" : "+v"(pos_nxt[0]), "+v"(pos_nxt[1]));
         p3_unpack_own<C16>(own_nxt[0]), p3_unpack_own<C16>(own_nxt[1]);
         // The image the staging writes into is a compile-time constant per unrolled phase, so the nine write addresses of a lane (image + slot +
         // lane position) are loop invariants to the compiler: it hoists them out of the tile loop into registers the loop does not have - and
@@ -753,7 +785,7 @@ __device__ __forceinline__ void p3_tile(const PredArgs &a, const int32_t *plane,
     trace_stamp(a.trace, blockIdx.x, 2 + it, tid);
 }
 
-template <int ROLE, bool CHECK, bool WORDS, bool C16 = false>
+template <int ROLE, bool CHECK, bool WORDS, bool C16 = false, bool STREAM = false>
 __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, int lane, int wave, uint32_t &early_poll) {
     uint8_t *s_cells = lds.cells[0];
     int32_t *s_ring = &lds.ring[0][0];
@@ -783,6 +815,7 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
     }
     float ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     i32x4 own_a[2] = {i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}}, own_b[2] = {i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
+    u32x4 pos_a[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}}, pos_b[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}}; // STREAM: see p3_tile
 
     const PredTileWalk walk(a.n_tiles);
     if (walk.first >= walk.end) { // (a workgroup without a tile still takes part in the hand-over - and clears its part of the histogram if it is one of the first ten)
@@ -813,6 +846,7 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
             raw_own[c] = __builtin_amdgcn_readfirstlane(s_ring[slot_a + c]);
             const int cell = max(pred_slot_cell(raw_own[c]), 0);
             own_a[c] = p3_load_own<ROLE, C16>(plane, (size_t)cell, (uint32_t)lane);
+            if (STREAM) pos_a[c] = p3_load_pos<ROLE>(a.stream_pos, (size_t)cell, (uint32_t)lane);
             if (ROLE == 1) st_own_mask[c] = (a.valid_mask + (size_t)cell * 16)[(uint32_t)lane & 15u];
         }
         P3Halo st_halo;
@@ -828,7 +862,7 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
         }
         m = __builtin_fmaxf(m, p3_commit_halo<CHECK>(st_halo, s_cells, L.halo_lds));
         if (CHECK) p3_check(m, lane, a.inexact);
-        if (ROLE == 1 && !(ablate_flags(a.ablate) & 1)) p3_lf_finish<WORDS>(a, lds.hist, lf_item, lf_values);
+        if (ROLE == 1 && !(ablate_flags(a.ablate) & 1)) p3_lf_finish<WORDS, STREAM>(a, lds.hist, lf_item, lf_values);
     }
     if (ROLE == 1) {
         for (uint32_t base = kLfTilesPerPass; base < my_tiles; base += kLfTilesPerPass) { // more than 16 tiles per workgroup (large images): further passes, two round trips each
@@ -837,7 +871,7 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
             P3LfValues x;
             p3_lf_hop_a(a, walk.first + k * walk.step, k < my_tiles, lf_tid, it);
             p3_lf_hop_b<C16>(a, plane, it, x);
-            if (!(ablate_flags(a.ablate) & 1)) p3_lf_finish<WORDS>(a, lds.hist, it, x);
+            if (!(ablate_flags(a.ablate) & 1)) p3_lf_finish<WORDS, STREAM>(a, lds.hist, it, x);
         }
     }
     // Only LDS is handed over here. __syncthreads() also waits for the LF pass's scattered global stores to be acknowledged: 1.8 us between "the first
@@ -848,10 +882,10 @@ __device__ __forceinline__ void p3_run(const PredArgs &a, P3Lds &lds, int tid, i
 
     int it = 0;
     for (uint32_t tile = walk.first; tile < walk.end;) { // unrolled by two: the LDS image a tile lives in is a compile-time constant
-        p3_tile<0, ROLE, CHECK, WORDS, C16>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_a, own_b);
+        p3_tile<0, ROLE, CHECK, WORDS, C16, STREAM>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_a, own_b, pos_a, pos_b);
         tile += walk.step, it++;
         if (tile >= walk.end) break;
-        p3_tile<1, ROLE, CHECK, WORDS, C16>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_b, own_a);
+        p3_tile<1, ROLE, CHECK, WORDS, C16, STREAM>(a, plane, lds, it, tile + walk.step < walk.end, min(tile + 2 * walk.step, last), tid, lane, wave, slot_a, L, ga, gb, own_b, own_a, pos_b, pos_a);
         tile += walk.step, it++;
     }
 }
@@ -884,7 +918,7 @@ __device__ __forceinline__ PredArgs pred_plane_view(const PredArgs &a0, uint32_t
 // <= 255 by construction and the staging does not look (18 max operations per lane and tile). CHECK = true: any int32 array; a value the LDS image
 // cannot hold raises the plane's `inexact` flag (see PredArgs::trusted for what happens then).
 // WORDS: see p3_half (instantiated for the library's own coefficients only).
-template <bool CHECK, bool WORDS, bool C16 = false>
+template <bool CHECK, bool WORDS, bool C16 = false, bool STREAM = false>
 __global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const PredArgs a0) {
     PredArgs a = pred_plane_view(a0, blockIdx.y);
     if (C16) a.coefs = reinterpret_cast<const int32_t *>(reinterpret_cast<const int16_t *>(a0.coefs) + blockIdx.y * a0.coef_stride); // (a compact plane: halfwords)
@@ -903,9 +937,9 @@ __global__ void __launch_bounds__(kP3Threads) predict_histogram_kernel3(const Pr
         reinterpret_cast<uint32_t *>(s_cells + (i / ((kP3ImageBytes - kP3ZeroOff) / 4)) * kP3ImageBytes + kP3ZeroOff)[i % ((kP3ImageBytes - kP3ZeroOff) / 4)] = 0;
     uint32_t early_poll = 0;
     if (wave & 1)
-        p3_run<1, CHECK, WORDS, C16>(a, lds, tid, lane, wave, early_poll);
+        p3_run<1, CHECK, WORDS, C16, STREAM>(a, lds, tid, lane, wave, early_poll);
     else
-        p3_run<0, CHECK, WORDS, C16>(a, lds, tid, lane, wave, early_poll);
+        p3_run<0, CHECK, WORDS, C16, STREAM>(a, lds, tid, lane, wave, early_poll);
     lds_barrier(); // the table is complete; nobody waits here for the last tile's output stores
     trace_stamp(a.trace, blockIdx.x, 13, tid);
     pred_hand_over<CHECK>(a, s_hist, reinterpret_cast<uint32_t *>(s_ring), tid, kP3Threads, early_poll);
@@ -1030,7 +1064,11 @@ hipError_t launch_predict_histogram(const DevicePlan &p, uint32_t *acc, uint32_t
     a.halo_list = p.halo_list;
     a.ablate = p.k2_ablate;
     (void)hipGetLastError(); // the check behind the launch must not pick up an error an earlier, unrelated call left behind
-    if (b.words && b.coefs16)
+    a.stream_pos = b.stream_pos;
+    if (b.stream_pos && !(b.words && b.coefs16)) return hipErrorInvalidValue; // the stream form: the compact symbol-stream chains only
+    if (b.words && b.coefs16 && b.stream_pos)
+        hipLaunchKernelGGL((predict_histogram_kernel3<false, true, true, true>), dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
+    else if (b.words && b.coefs16)
         hipLaunchKernelGGL((predict_histogram_kernel3<false, true, true>), dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);
     else if (b.words)
         hipLaunchKernelGGL((predict_histogram_kernel3<false, true>), dim3(blocks, b.n_planes), dim3(kP3Threads), 0, stream, a);

@@ -98,6 +98,7 @@ struct PredBatch {
     size_t coef_stride = 0, out_stride = 0;
     const PredictParams *params = nullptr;
     PredictParams pp[3] = {}; // used when params is NULL: plane k takes pp[min(k, 2)] (one image's channels travel as kernel arguments)
+    const uint32_t *stream_pos = nullptr; // K2 only, with words and coefs16: [F][512] stream position of every node - `words` is then the planes' STREAMS (out_stride apart) and the scan writes them directly
     uint16_t *words = nullptr; // K2 only, with kPredForwardOutput only: write bucket << 10 | symbol per node ([n_planes] planes, out_stride apart) and neither bucket nor prediction
 };
 // K2. acc: n_planes x kPredAccWords words of hand-over bookkeeping, zero when allocated; serial: the number of this launch on `acc` (1, 2, ...: the caller counts; never 0).

@@ -18,7 +18,7 @@ def ctx():
     c.close()
 
 
-def _run(P, torch, imgs, fit, params, compact, q=None):
+def _run(P, torch, imgs, fit, params, compact, q=None, direct=False):
     n_img, c = len(imgs), P.channels
     plane, n = P.num_cells * 512, P.num_some
     d_px = torch.from_numpy(np.stack([im.reshape(-1) for im in imgs])).cuda()
@@ -30,7 +30,7 @@ def _run(P, torch, imgs, fit, params, compact, q=None):
     d_r = torch.full((n_img, c), -1, dtype=torch.int64, device="cuda")
     d_par = torch.from_numpy(np.broadcast_to(params, (n_img, c, 2, 3, 6)).astype(np.float32).copy()).cuda()
     s = torch.cuda.current_stream().cuda_stream
-    P.encode_symbols_batch_dev(n_img, d_px.data_ptr(), P.pixel_bytes, q, fit, d_par.data_ptr(), 0 if compact else d_co.data_ptr(), c * plane, d_w.data_ptr(), c * plane,
+    P.encode_symbols_batch_dev(n_img, d_px.data_ptr(), P.pixel_bytes, q, fit, d_par.data_ptr(), 0 if compact else d_co.data_ptr(), c * plane, 0 if direct else d_w.data_ptr(), c * plane,
                                d_st.data_ptr(), c * n, d_h.data_ptr(), d_o.data_ptr(), d_r.data_ptr() if fit else None, stream=s)
     torch.cuda.synchronize()
     st = d_st.cpu().numpy()
@@ -65,6 +65,11 @@ def test_compact_planes_change_nothing_the_caller_sees(ctx, shape):
                 for k in range(n_img):
                     for ch in range(c):
                         assert np.array_equal(got[5][k, ch][order], ref[5][k, ch][order])  # the node words of the Some nodes
+                # ... and without the node words either (d_node_words = NULL): the scan writes the streams itself, no gather kernel
+                dr = _run(P, torch, imgs, fit, params, compact=True, q=q, direct=True)
+                assert np.array_equal(dr[0], ref[0]), "streams written by the scan"
+                assert np.array_equal(dr[1], ref[1]) and np.array_equal(dr[2], ref[2]) and np.array_equal(dr[3].view(np.uint32), ref[3].view(np.uint32))
+                assert (dr[5] == 0xEEEE).all()  # nobody touched the node-word buffer
     P.close()
 
 

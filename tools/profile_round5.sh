@@ -68,7 +68,7 @@ unset SWEEP_C K1_SLOTS
 cd $R
 python3 tools/kernel_stats_from_traces.py $OUT > $OUT/kernel_stats_round5.csv
 cat $OUT/kernel_stats_round5.csv
-for needle in "predict_histogram_kernel3<true, false, false>" "predict_histogram_kernel3<false, false, false>" "predict_histogram_kernel3<false, true, false>" "fit_accumulate_kernel2<0" "fit_accumulate_kernel2<1" inverse_transform symbol_gather symbol_stream; do
+for needle in "predict_histogram_kernel3<true, false, false, false>" "predict_histogram_kernel3<false, false, false, false>" "predict_histogram_kernel3<false, true, false, false>" "fit_accumulate_kernel2<0" "fit_accumulate_kernel2<1" inverse_transform symbol_gather symbol_stream; do
   echo "== $needle: mean per launch (FETCH_SIZE / WRITE_SIZE in KiB) =="
   for p in sq1 sq2 tcc1 tcc2 ic1; do python3 tools/pmc_summary.py $OUT/$p "$needle"; done
 done > $OUT/pmc_k2_k4_k3_k5_summary.txt
