@@ -115,7 +115,6 @@ struct fri_hip_plan {
     hipStream_t coefs16_stream = nullptr;
     bool coefs16_used = false;
     uint16_t *d_symbols = nullptr;      // fri_hip_encode_image_symbols: [C][geo.n_some]
-    uint16_t *d_words = nullptr;        // ... and the scan's halfword planes [C][F][512] the stream is gathered from
     uint32_t acc_next = 0;
     bool acc_dirty = false; // a launch on this plan failed: the accumulators are re-zeroed before the next use
     hipEvent_t ev_begin = nullptr, ev_end = nullptr; // timing helper's events, created with the plan (creating an event is not work to be timed)
@@ -806,7 +805,6 @@ int fri_hip_plan_destroy(fri_hip_plan *p) {
         if (p->d_coefs16) (void)hipFree(p->d_coefs16);
         if (p->ev_coefs16) (void)hipEventDestroy(p->ev_coefs16);
         if (p->d_symbols) (void)hipFree(p->d_symbols);
-        if (p->d_words) (void)hipFree(p->d_words);
         if (p->h_fit) (void)hipHostFree(p->h_fit);
         if (p->ev_fit) (void)hipEventDestroy(p->ev_fit);
         if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
