@@ -1632,7 +1632,7 @@ int fri_hip_encode_image_symbols(fri_hip_plan *p, const uint8_t *pixels, const i
     if (!pixels || !value_params || !width_params || !symbols || !hist || !n_out_of_alphabet || !p->d_stream_order) return FRI_HIP_ERR_INVALID_ARGUMENT;
     fri_hip_ctx *c = p->ctx;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (int rc = ensure_staging(p)) return rc;
+    if (!p->d_pixels) HIP_TRY(c, hipMalloc((void **)&p->d_pixels, fri_hip_plan_pixel_bytes(p))); // (of the single-image staging only the pixels: no int32 planes, no node arrays here)
     if (int rc = ensure_encode_staging(p, false)) return rc;
     const size_t C = p->geo.channels, n = p->geo.n_some;
     if (!p->d_symbols) HIP_TRY(c, hipMalloc((void **)&p->d_symbols, (C * n ? C * n : 1) * sizeof(uint16_t)));
